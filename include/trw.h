@@ -1,0 +1,143 @@
+/*
+ * trw.h -- C ABI of the MI355X (gfx950) CSR random-walk library, libtrw_hip.so.
+ *
+ * This is the drop-in boundary for ONE hot path of Sachinx0e/torch_random_walk:
+ * the CSR walker behind torch_rw.rw.walk.  Each entry point names the reference
+ * interface it replaces (paths relative to the reference repo root).  Plain
+ * pointers and sizes only -- no torch types.  All pointers except `status`
+ * outputs are DEVICE pointers valid on the device that is current when the call
+ * is made; the caller owns every buffer.  Calls are asynchronous on
+ * `hip_stream` (a hipStream_t, NULL = the null stream) unless stated otherwise
+ * and allocate nothing after the first call on a device (which uploads a 190 KB
+ * constant jump table once).
+ */
+#ifndef TRW_H
+#define TRW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRW_VERSION 100 /* 0.1.0 */
+
+/* ---- RNG contract ------------------------------------------------------- */
+/* The reference's CPU path draws from ONE process-global glibc rand() stream,
+ * seeded once per call (csrc/cpu/rw_cpu.cpp:60,118) and consumed walker-major.
+ *
+ * TRW_RNG_GLIBC   reference-exact.  Uniform walks (p == 1 && q == 1) consume
+ *                 exactly one draw per step, so walker i, step s uses stream
+ *                 index (walker_base+i)*L + s-1; every walker jumps straight
+ *                 to its window (exact jump-ahead of the lagged-Fibonacci
+ *                 recurrence) and the launch is fully parallel.  Biased walks
+ *                 consume a data-dependent number of draws, so the stream is
+ *                 an inherently serial chain: this mode then runs ONE wave
+ *                 that replays the chain in order (bit-exact, slow; meant for
+ *                 the small inputs on which the reference itself is
+ *                 deterministic).  Requires walker_base == 0 for biased walks.
+ * TRW_RNG_WALKER  per-walker counter stream: Philox4x32-10, key (seed, 0),
+ *                 counter (walker_lo, walker_hi, draw/4, 0), value =
+ *                 word[draw%4] >> 1 (31 bits, like rand()).  Shard- and
+ *                 launch-geometry-invariant; fully parallel for biased walks.
+ * TRW_RNG_AUTO    uniform -> GLIBC.  biased -> GLIBC when walker_base == 0 and
+ *                 n_walkers <= 32768/(walk_length+1) (the reference's
+ *                 parallel_for grain, rw_cpu.cpp:137 -- the regime in which
+ *                 csrc/cpu output is defined independently of its thread
+ *                 count), WALKER otherwise.
+ */
+#define TRW_RNG_AUTO   0
+#define TRW_RNG_GLIBC  1
+#define TRW_RNG_WALKER 2
+
+/* ---- error codes (return values; 0 = success) --------------------------- */
+#define TRW_OK            0
+#define TRW_E_ARG        (-1)  /* null pointer, negative size, walk_length < 1, ... */
+#define TRW_E_WORKSPACE  (-2)  /* workspace missing or too small                     */
+#define TRW_E_HIP        (-3)  /* a HIP runtime call or kernel launch failed          */
+#define TRW_E_RNG_MODE   (-4)  /* rng_mode not usable for this call                   */
+#define TRW_E_RANGE      (-5)  /* stream position beyond 2^48 draws                   */
+/* device-side status bits, returned by trw_walk_status() */
+#define TRW_ST_DEGREE0    1    /* a walker stood on a node with no out-edges (the
+                                  reference divides by zero there, rw_cpu.cpp:20)  */
+#define TRW_ST_NODE_RANGE 2    /* a start node or a col_idx entry outside [0,n)    */
+#define TRW_ST_BAD_CSR    4    /* row_ptr not monotone within [0, nnz]             */
+#define TRW_ST_TRIAL_CAP  8    /* 2^20 consecutive rejections at one step; the
+                                  candidate was force-accepted (the reference
+                                  would still be spinning, rw_cpu.cpp:166)         */
+
+int trw_version(void);
+
+/* Text of the last error on the calling thread ("" if none). */
+const char *trw_last_error(void);
+
+/* Bytes of device scratch trw_walk_csr_hip needs for this call shape
+ * (>= 256; status block + per-lane RNG windows). */
+size_t trw_walk_csr_workspace_bytes(int64_t n_nodes, int64_t nnz, int64_t n_walkers,
+                                    int32_t walk_length, double p, double q, int32_t rng_mode);
+
+/*
+ * The CSR walk.  Replaces the reference's
+ *     torch::Tensor walk_gpu(row_ptr, column_idx, target_nodes, p, q, walk_length, seed)
+ * (csrc/cuda/rw_cuda.h:4-10, called from csrc/rw_init.cpp:20-21) and produces,
+ * on the GPU, what walk_cpu (csrc/cpu/rw_cpu.cpp:203-226) produces.
+ *
+ *   row_ptr  [n_nodes+1] int64   CSR row offsets          (reference arg 1)
+ *   col_idx  [nnz]       int64   CSR column indices       (reference arg 2)
+ *   targets  [n_walkers] int64   start nodes, contiguous  (reference arg 3)
+ *   walker_base                  global index of targets[0]; lets a shard of a
+ *                                larger batch reproduce exactly the rows the
+ *                                unsharded call would (no reference counterpart:
+ *                                the reference is single-device)
+ *   p, q, walk_length, seed      as the reference; p == 1.0 && q == 1.0 selects
+ *                                the uniform walk by exact comparison
+ *                                (rw_cpu.cpp:220)
+ *   out      [n_walkers][walk_length+1] int64 row-major; column 0 = start node
+ *   workspace / workspace_bytes  device scratch, see above; 16-byte aligned
+ *
+ * Returns TRW_OK or a negative code (trw_last_error() has the text).  Data
+ * problems found on the device (degree-0 node, node id out of range) do not
+ * fault: the walker stays where it is, a status bit is set, and
+ * trw_walk_status() reports it.
+ */
+int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes,
+                     const int64_t *col_idx, int64_t nnz,
+                     const int64_t *targets, int64_t n_walkers,
+                     int64_t walker_base,
+                     double p, double q, int32_t walk_length, int32_t seed,
+                     int32_t rng_mode,
+                     int64_t *out,
+                     void *workspace, size_t workspace_bytes,
+                     void *hip_stream);
+
+/* Synchronises `hip_stream` and copies the status block of the last walk that
+ * used `workspace` to the host: status[0] = OR of TRW_ST_* bits,
+ * status[1] = 1 if some CSR row was found unsorted (biased walks only; the
+ * membership test then scans linearly like rw_cpu.cpp:32-56 instead of
+ * bisecting), status[2] = the RNG mode that ran (TRW_RNG_GLIBC/WALKER),
+ * status[3] = reserved.  Returns TRW_OK or TRW_E_HIP. */
+int trw_walk_status(const void *workspace, void *hip_stream, int64_t status[4]);
+
+/* Integer form of the reference's accept test (rw_cpu.cpp:169-194):
+ * (double)r / (double)RAND_MAX < prob  <=>  r < trw_accept_threshold(prob).
+ * Host helper, exported so tests can pin it against the fp64 expression. */
+uint32_t trw_accept_threshold(double prob);
+
+/* Host helper: fills window[31] with the glibc TYPE_3 generator words in front
+ * of draw index `pos` after srand(seed), using the library's jump tables
+ * (the same tables the device uses).  Exported for tests. */
+void trw_glibc_window_at(int32_t seed, uint64_t pos, uint32_t window[31]);
+
+/* Instrumentation for bench.py (not thread-safe, one call in flight): when
+ * enabled, every trw_walk_csr_hip records HIP events on its stream around its
+ * two phases; trw_profile_last() synchronises the last one and returns the
+ * device time of the prepare phase (jump-ahead windows / row-order probe) and
+ * of the walk kernel itself, in milliseconds. */
+int trw_profile_enable(int on);
+int trw_profile_last(double *prepare_ms, double *walk_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRW_H */

@@ -1,0 +1,376 @@
+/*
+ * trw_oracle.c -- TEST INFRASTRUCTURE ONLY (see trw_oracle.h).
+ *
+ * Plain-C restatement of the reference's CSR random-walk hot path.  Every
+ * function cites the reference lines it follows (paths relative to the
+ * reference repo root).  Nothing here is compiled into, linked by or called
+ * from the product library.
+ */
+#include "trw_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------ */
+/* glibc srand()/rand(), TYPE_3 additive feedback generator                  */
+/* (GNU libc stdlib/random_r.c; called by the reference at                   */
+/*  csrc/cpu/rw_cpu.cpp:20,60,118,169).  r[k] = r[k-3] + r[k-31] mod 2^32,   */
+/*  output r[k] >> 1, 310 values discarded after seeding.                    */
+/* ------------------------------------------------------------------------ */
+
+#define GL_DEG 31
+#define GL_SEP 3
+
+typedef struct {
+    uint32_t w[GL_DEG]; /* w[(pos+j) % 31] = r[pos + 313 + j], j = 0..30      */
+    uint32_t slot;      /* pos % 31                                           */
+} glibc_state;
+
+static void glibc_seed_window(int32_t seed, uint32_t win[GL_DEG])
+{
+    /* random_r.c __srandom_r: seed 0 becomes 1; Schrage's 16807 LCG fills
+     * r[1..30] with C's truncating signed division on the int32 word. */
+    uint32_t r[344];
+    uint32_t s = (uint32_t)seed;
+    if (s == 0) s = 1;
+    r[0] = s;
+    int32_t word = (int32_t)s;
+    for (int i = 1; i < GL_DEG; ++i) {
+        long hi = word / 127773;
+        long lo = word % 127773;
+        word = (int32_t)(16807 * lo - 2836 * hi);
+        if (word < 0) word += 2147483647;
+        r[i] = (uint32_t)word;
+    }
+    for (int i = 31; i < 34; ++i) r[i] = r[i - 31];
+    for (int i = 34; i < 344; ++i) r[i] = r[i - 31] + r[i - 3];
+    for (int j = 0; j < GL_DEG; ++j) win[j] = r[313 + j];
+}
+
+static void glibc_init(glibc_state *st, int32_t seed)
+{
+    glibc_seed_window(seed, st->w);
+    st->slot = 0;
+}
+
+static inline int32_t glibc_next(glibc_state *st)
+{
+    uint32_t j = st->slot;
+    uint32_t k = j + (GL_DEG - GL_SEP);
+    if (k >= GL_DEG) k -= GL_DEG;
+    uint32_t v = st->w[j] + st->w[k]; /* r[k] = r[k-31] + r[k-3] */
+    st->w[j] = v;
+    st->slot = (j + 1 == GL_DEG) ? 0 : j + 1;
+    return (int32_t)(v >> 1);
+}
+
+/* Jump-ahead.  The recurrence is linear over Z/2^32 with characteristic
+ * polynomial x^31 = x^28 + 1, so r[q+J+m] = sum_i g_i r[q+i+m] where
+ * g = x^J mod (x^31 - x^28 - 1). */
+static void poly_mulmod(const uint32_t a[GL_DEG], const uint32_t b[GL_DEG], uint32_t out[GL_DEG])
+{
+    uint32_t c[2 * GL_DEG - 1];
+    memset(c, 0, sizeof c);
+    for (int i = 0; i < GL_DEG; ++i) {
+        if (!a[i]) continue;
+        for (int j = 0; j < GL_DEG; ++j) c[i + j] += a[i] * b[j];
+    }
+    for (int d = 2 * GL_DEG - 2; d >= GL_DEG; --d) {
+        c[d - GL_SEP] += c[d];
+        c[d - GL_DEG] += c[d];
+    }
+    memcpy(out, c, GL_DEG * sizeof(uint32_t));
+}
+
+static void poly_xpow(uint64_t J, uint32_t g[GL_DEG])
+{
+    uint32_t base[GL_DEG], acc[GL_DEG], tmp[GL_DEG];
+    memset(base, 0, sizeof base);
+    memset(acc, 0, sizeof acc);
+    base[1] = 1; /* x   */
+    acc[0] = 1;  /* 1   */
+    while (J) {
+        if (J & 1) { poly_mulmod(acc, base, tmp); memcpy(acc, tmp, sizeof acc); }
+        J >>= 1;
+        if (J) { poly_mulmod(base, base, tmp); memcpy(base, tmp, sizeof base); }
+    }
+    memcpy(g, acc, sizeof acc);
+}
+
+static void window_apply(const uint32_t g[GL_DEG], const uint32_t win[GL_DEG], uint32_t out[GL_DEG])
+{
+    uint32_t ext[2 * GL_DEG - 1];
+    memcpy(ext, win, GL_DEG * sizeof(uint32_t));
+    for (int t = 0; t < GL_DEG - 1; ++t) ext[GL_DEG + t] = ext[t] + ext[t + GL_DEG - GL_SEP];
+    for (int m = 0; m < GL_DEG; ++m) {
+        uint32_t acc = 0;
+        for (int i = 0; i < GL_DEG; ++i) acc += g[i] * ext[i + m];
+        out[m] = acc;
+    }
+}
+
+void trw_oracle_glibc_window_at(int32_t seed, uint64_t pos, uint32_t window[31])
+{
+    uint32_t w0[GL_DEG], g[GL_DEG];
+    glibc_seed_window(seed, w0);
+    poly_xpow(pos, g);
+    window_apply(g, w0, window);
+}
+
+static void glibc_init_at(glibc_state *st, int32_t seed, uint64_t pos)
+{
+    if (pos == 0) { glibc_init(st, seed); return; }
+    trw_oracle_glibc_window_at(seed, pos, st->w);
+    st->slot = 0;
+}
+
+void trw_oracle_glibc_stream(int32_t seed, uint64_t start, uint64_t n, int32_t *out)
+{
+    glibc_state st;
+    glibc_init_at(&st, seed, start);
+    for (uint64_t i = 0; i < n; ++i) out[i] = glibc_next(&st);
+}
+
+void trw_oracle_libc_stream(int32_t seed, uint64_t n, int32_t *out)
+{
+    srand((unsigned)seed);
+    for (uint64_t i = 0; i < n; ++i) out[i] = rand();
+}
+
+/* ------------------------------------------------------------------------ */
+/* Philox4x32-10 (Salmon et al., SC'11) -- the per-walker counter stream.    */
+/* ------------------------------------------------------------------------ */
+
+void trw_oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+int32_t trw_oracle_walker_draw(int32_t seed, uint64_t walker, uint64_t draw)
+{
+    uint32_t ctr[4] = { (uint32_t)walker, (uint32_t)(walker >> 32), (uint32_t)(draw >> 2), 0u };
+    uint32_t key[2] = { (uint32_t)seed, 0u };
+    uint32_t o[4];
+    trw_oracle_philox4x32_10(ctr, key, o);
+    return (int32_t)(o[draw & 3] >> 1);
+}
+
+/* ------------------------------------------------------------------------ */
+/* RNG front-end shared by the walk loops                                     */
+/* ------------------------------------------------------------------------ */
+
+typedef struct {
+    int mode;
+    glibc_state gl;
+    /* walker stream */
+    int32_t seed;
+    uint64_t walker;
+    uint64_t draw;
+    uint32_t blk[4];
+    uint64_t blk_index; /* which philox block is cached, ~0 = none */
+    uint64_t ndraws;
+} rng_t;
+
+static inline int32_t rng_next(rng_t *g)
+{
+    g->ndraws++;
+    switch (g->mode) {
+    case TRW_ORACLE_RNG_LIBC:
+        return rand();
+    case TRW_ORACLE_RNG_WALKER: {
+        uint64_t d = g->draw++;
+        uint64_t b = d >> 2;
+        if (b != g->blk_index) {
+            uint32_t ctr[4] = { (uint32_t)g->walker, (uint32_t)(g->walker >> 32), (uint32_t)b, 0u };
+            uint32_t key[2] = { (uint32_t)g->seed, 0u };
+            trw_oracle_philox4x32_10(ctr, key, g->blk);
+            g->blk_index = b;
+        }
+        return (int32_t)(g->blk[d & 3] >> 1);
+    }
+    default:
+        return glibc_next(&g->gl);
+    }
+}
+
+static inline void rng_begin_walker(rng_t *g, uint64_t walker, int32_t walk_length)
+{
+    if (g->mode == TRW_ORACLE_RNG_WALKER) {
+        g->walker = walker;
+        g->draw = 0;
+        g->blk_index = ~(uint64_t)0;
+    } else if (g->mode == TRW_ORACLE_RNG_GLIBC_INDEXED) {
+        glibc_init_at(&g->gl, g->seed, walker * (uint64_t)walk_length);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* The walk                                                                   */
+/* ------------------------------------------------------------------------ */
+
+void trw_oracle_probs(double p, double q, double prob[3])
+{
+    /* rw_cpu.cpp:130-134 */
+    double max_prob_init = fmax(1.0 / p, 1);
+    double max_prob = fmax(max_prob_init, 1.0 / q);
+    prob[0] = 1.0 / p / max_prob;
+    prob[1] = 1.0 / max_prob;
+    prob[2] = 1.0 / q / max_prob;
+}
+
+uint32_t trw_oracle_accept_threshold(double prob)
+{
+    /* (double)r / (double)RAND_MAX is monotone non-decreasing in r, so the
+     * accept set { r : r/RAND_MAX < prob } is a prefix [0, T). */
+    const double rmax = (double)RAND_MAX;
+    if (!(prob > 0.0)) return 0; /* also NaN */
+    uint64_t lo = 0, hi = (uint64_t)1 << 31; /* answer in [lo, hi] */
+    while (lo < hi) {
+        uint64_t mid = (lo + hi) >> 1;
+        if ((double)mid / rmax < prob) lo = mid + 1; else hi = mid;
+    }
+    return (uint32_t)lo;
+}
+
+typedef struct {
+    const int64_t *row_ptr;
+    const int64_t *col_idx;
+    int64_t n_nodes, nnz;
+    int err;
+} graph_t;
+
+/* sample_neighbor, rw_cpu.cpp:7-30.  rand() is promoted to int64 before the
+ * modulo; the bounds check falls back to the current node. */
+static inline int64_t sample_neighbor(graph_t *g, int64_t node, rng_t *rng)
+{
+    if (node < 0 || node >= g->n_nodes) { g->err = TRW_ORACLE_E_RANGE; return node; }
+    int64_t column_start = g->row_ptr[node];
+    int64_t column_end = g->row_ptr[node + 1];
+    int64_t deg = column_end - column_start;
+    if (deg == 0) { /* the reference divides by zero here (SIGFPE) */
+        g->err = TRW_ORACLE_E_DEGREE0;
+        (void)rng_next(rng);
+        return node;
+    }
+    int64_t nbr_idx = column_start + ((int64_t)rng_next(rng) % deg);
+    if (nbr_idx >= 0 && nbr_idx < g->nnz) return g->col_idx[nbr_idx];
+    return node;
+}
+
+/* is_neighbor(new_node, previous_node), rw_cpu.cpp:32-56: linear early-exit
+ * scan of previous_node's row for new_node. */
+static inline int is_neighbor(graph_t *g, int64_t new_node, int64_t previous_node, uint64_t *scanned)
+{
+    if (previous_node < 0 || previous_node >= g->n_nodes) { g->err = TRW_ORACLE_E_RANGE; return 0; }
+    int64_t column_start = g->row_ptr[previous_node];
+    int64_t column_end = g->row_ptr[previous_node + 1];
+    for (int64_t i = column_start; i < column_end; ++i) {
+        if (scanned) ++*scanned;
+        if (g->col_idx[i] == new_node) return 1;
+    }
+    return 0;
+}
+
+int trw_oracle_walk_csr(const int64_t *row_ptr, int64_t n_nodes,
+                        const int64_t *col_idx, int64_t nnz,
+                        const int64_t *targets, int64_t n_walkers,
+                        int64_t walker_base,
+                        double p, double q, int32_t walk_length, int32_t seed,
+                        int32_t rng_mode,
+                        int64_t *out,
+                        trw_oracle_counters *counters,
+                        int64_t *draws_per_walker)
+{
+    if (!row_ptr || (!col_idx && nnz) || (!targets && n_walkers) || (!out && n_walkers)) return TRW_ORACLE_E_ARG;
+    if (n_nodes < 0 || nnz < 0 || n_walkers < 0 || walker_base < 0 || walk_length < 1) return TRW_ORACLE_E_ARG;
+    if (rng_mode < 0 || rng_mode > 3) return TRW_ORACLE_E_ARG;
+
+    /* rw_cpu.cpp:220: exact-equality dispatch. */
+    const int uniform = (p == 1.0 && q == 1.0);
+    const int sequential = (rng_mode == TRW_ORACLE_RNG_GLIBC_SEQ || rng_mode == TRW_ORACLE_RNG_LIBC);
+    if (rng_mode == TRW_ORACLE_RNG_GLIBC_INDEXED && !uniform) return TRW_ORACLE_E_ARG;
+    if (sequential && !uniform && walker_base != 0) return TRW_ORACLE_E_ARG;
+    if (rng_mode == TRW_ORACLE_RNG_LIBC && walker_base != 0) return TRW_ORACLE_E_ARG;
+
+    graph_t g = { row_ptr, col_idx, n_nodes, nnz, 0 };
+    rng_t rng;
+    memset(&rng, 0, sizeof rng);
+    rng.mode = rng_mode;
+    rng.seed = seed;
+    /* rw_cpu.cpp:60 / :118: the stream is seeded once per call. */
+    if (rng_mode == TRW_ORACLE_RNG_LIBC) srand((unsigned)seed);
+    else if (rng_mode == TRW_ORACLE_RNG_GLIBC_SEQ)
+        glibc_init_at(&rng.gl, seed, (uint64_t)walker_base * (uint64_t)walk_length);
+
+    double prob[3];
+    trw_oracle_probs(p, q, prob);
+
+    trw_oracle_counters cnt;
+    memset(&cnt, 0, sizeof cnt);
+    uint64_t *scanned = counters ? &cnt.scan_entries_total : NULL;
+
+    const int64_t walk_size = (int64_t)walk_length + 1; /* rw_cpu.cpp:216 */
+
+    for (int64_t i = 0; i < n_walkers; ++i) {
+        int64_t *walk = out + i * walk_size;
+        uint64_t draws_before = rng.ndraws;
+        rng_begin_walker(&rng, (uint64_t)walker_base + (uint64_t)i, walk_length);
+
+        int64_t target_node = targets[i];
+        walk[0] = target_node; /* rw_cpu.cpp:92 / :156 */
+
+        if (uniform) {
+            /* uniform_walk hot loop, rw_cpu.cpp:95-104 */
+            int64_t previous_node = target_node;
+            for (int64_t s = 1; s < walk_size; ++s) {
+                int64_t next_node = sample_neighbor(&g, previous_node, &rng);
+                walk[s] = next_node;
+                previous_node = next_node;
+            }
+        } else {
+            /* biased_walk hot loop, rw_cpu.cpp:159-198 */
+            walk[1] = sample_neighbor(&g, target_node, &rng);
+            int64_t previous_node = walk[1];
+            for (int64_t s = 2; s < walk_size; ++s) {
+                int64_t selected_node = -1;
+                int64_t t_node = walk[s - 2];
+                while (1) {
+                    /* both draws are always consumed, candidate first */
+                    int64_t new_node = sample_neighbor(&g, previous_node, &rng);
+                    double random_prob = ((double)rng_next(&rng) / (double)RAND_MAX);
+                    cnt.trials_total++;
+                    if (g.err) { selected_node = new_node; break; }
+                    if (new_node == t_node) {
+                        if (random_prob < prob[0]) { selected_node = new_node; break; }
+                    } else {
+                        cnt.membership_tests++;
+                        if (is_neighbor(&g, new_node, t_node, scanned)) {
+                            if (random_prob < prob[1]) { selected_node = new_node; break; }
+                        } else if (random_prob < prob[2]) { selected_node = new_node; break; }
+                    }
+                }
+                walk[s] = selected_node;
+                previous_node = selected_node;
+            }
+        }
+        if (draws_per_walker) draws_per_walker[i] = (int64_t)(rng.ndraws - draws_before);
+        if (g.err) break;
+    }
+    cnt.draws_total = rng.ndraws;
+    if (counters) *counters = cnt;
+    return g.err;
+}

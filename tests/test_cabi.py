@@ -1,0 +1,86 @@
+"""The C ABI library: loads, exports what include/trw.h declares, host helpers agree with the oracle.
+No kernel is launched here (no GPU in this tier)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "trw.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(trw_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported():
+    from torch_random_walk_amd import _native
+    lib = ctypes.CDLL(_native.HIP_LIB_PATH)
+    names = _declared_functions()
+    assert "trw_walk_csr_hip" in names and len(names) >= 8
+    for name in names:
+        assert hasattr(lib, name), "libtrw_hip.so does not export %s" % name
+
+
+def test_version_and_constants():
+    from torch_random_walk_amd import _native
+    assert _native.cabi().trw_version() == 100
+    assert (_native.RNG_AUTO, _native.RNG_GLIBC, _native.RNG_WALKER) == (0, 1, 2)
+    assert _native.ext.abi_version() == 100
+
+
+@pytest.mark.parametrize("p,q", [(0.25, 4.0), (0.7, 0.5), (2.0, 1.0), (1.0, 1.0 + 1e-12), (1e-3, 1e3), (5.0, 0.2)])
+def test_accept_threshold_matches_oracle(p, q):
+    from torch_random_walk_amd import _native
+    for prob in O.probs(p, q):
+        assert _native.cabi().trw_accept_threshold(prob) == O.accept_threshold(prob)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 10, -1, 2**31 - 1, -2**31])
+@pytest.mark.parametrize("pos", [0, 1, 255, 256, 80 * 12345, 2**24 + 17, 2**40 + 3, 2**48 - 1])
+def test_jump_tables_match_oracle(seed, pos):
+    from torch_random_walk_amd import _native
+    w = (ctypes.c_uint32 * 31)()
+    _native.cabi().trw_glibc_window_at(seed, pos, w)
+    assert list(w) == O.glibc_window_at(seed, pos).tolist()
+
+
+def test_window_reproduces_libc_draws(libc_vectors):
+    """Stepping the recurrence from a jumped window gives the real libc outputs."""
+    from torch_random_walk_amd import _native
+    deep = libc_vectors["deep"]
+    samples = deep["samples"]["10"]
+    for k in (1, 7, len(samples) - 1):
+        pos = k * deep["stride"]
+        w = (ctypes.c_uint32 * 31)()
+        _native.cabi().trw_glibc_window_at(10, pos, w)
+        draw = ((w[0] + w[28]) & 0xFFFFFFFF) >> 1
+        assert draw == samples[k]
+
+
+def test_workspace_bytes():
+    from torch_random_walk_amd import _native
+    f = _native.cabi().trw_walk_csr_workspace_bytes
+    assert f(10, 20, 0, 5, 1.0, 1.0, 0) >= 256
+    assert f(10, 20, 1000, 80, 0.5, 2.0, 0) == 256           # biased: status block only
+    assert f(10, 20, 1000, 80, 1.0, 1.0, 2) == 256           # uniform on the walker stream: no windows
+    assert f(10, 20, 1000, 80, 1.0, 1.0, 0) >= 256 + 1000 * 124
+
+
+def test_argument_errors_return_codes_without_touching_the_gpu():
+    from torch_random_walk_amd import _native
+    L = _native.cabi()
+    rc = L.trw_walk_csr_hip(None, 1, None, 0, None, 0, 0, 1.0, 1.0, 3, 1, 0, None, None, 0, None)
+    assert rc == -1 and b"row_ptr" in L.trw_last_error()
+    buf = np.zeros(8, dtype=np.int64)
+    ptr = buf.ctypes.data
+    assert L.trw_walk_csr_hip(ptr, 1, ptr, 1, ptr, 1, 0, 1.0, 1.0, 0, 1, 0, ptr, None, 0, None) == -1   # walk_length 0
+    assert L.trw_walk_csr_hip(ptr, 1, ptr, 1, ptr, 1, 0, 0.0, 1.0, 3, 1, 0, ptr, None, 0, None) == -1   # p = 0
+    assert L.trw_walk_csr_hip(ptr, 1, ptr, 1, ptr, 1, 0, 1.0, 1.0, 3, 1, 0, ptr, None, 0, None) == -2   # no workspace
+    assert L.trw_walk_csr_hip(ptr, 1, ptr, 1, ptr, 1, 0, 1.0, 1.0, 3, 1, 7, ptr, ptr, 4096, None) == -4  # rng mode
+    assert L.trw_walk_csr_hip(ptr, 1, ptr, 1, ptr, 1, 5, 0.5, 2.0, 3, 1, 1, ptr, ptr, 4096, None) == -4  # serial chain + base

@@ -1,0 +1,299 @@
+"""HIP path vs the CPU oracle on a real MI355X (pytest -m gpu).
+
+Bit-exact is the bar everywhere: this is integer index work.  Small cases are
+compared element for element with the oracle; BASELINE-sized cases are checked
+through size-independent properties (every step is an edge, determinism,
+shard invariance) plus an oracle comparison on a sample of rows.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests.helpers import hub_graph, random_graph
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def rw():
+    assert torch.cuda.is_available(), "the -m gpu tier needs a GPU"
+    from torch_rw import rw as _rw
+    return _rw
+
+
+def _dev(*arrays):
+    return [torch.as_tensor(np.asarray(a), dtype=torch.int64).to(DEV) for a in arrays]
+
+
+def _hip(rw, rp, ci, tg, p, q, L, seed, **kw):
+    d_rp, d_ci, d_tg = _dev(rp, ci, tg)
+    out = rw.walk_ex(d_rp, d_ci, d_tg, p, q, L, seed, **kw)
+    return out.cpu().numpy()
+
+
+# ---- the reference's own goldens through the reference's own call -------------------------
+
+def test_readme_uniform_golden(rw, golden):
+    from torch_rw import utils
+    import networkx as nx
+    g = nx.Graph()
+    for a, b in golden["graph"]["edges"]:
+        g.add_edge(a, b)
+    row_ptr, col_idx = utils.to_csr(g)
+    nodes = utils.nodes_tensor(g)
+    c = golden["uniform_cpu"]
+    walks = rw.walk(row_ptr=row_ptr.to(DEV), col_idx=col_idx.to(DEV), target_nodes=nodes.to(DEV),
+                    p=1.0, q=1.0, walk_length=6, seed=10)
+    assert walks.dtype == torch.int64 and walks.device.type == "cuda" and tuple(walks.shape) == (5, 7)
+    assert walks.cpu().tolist() == c["walks"]          # reference tests/test_rw.py:49-53 (CPU golden)
+
+
+def test_readme_biased_golden(rw, golden):
+    g = golden["graph"]
+    c = golden["biased_cpu"]
+    d_rp, d_ci, d_tg = _dev(g["row_ptr"], g["col_idx"], g["nodes"])
+    walks = rw.walk(row_ptr=d_rp, col_idx=d_ci, target_nodes=d_tg, p=0.7, q=0.5, walk_length=6, seed=10)
+    assert walks.cpu().tolist() == c["walks"]          # reference tests/test_rw.py:116-120 (CPU golden)
+
+
+# ---- uniform walks: literal csrc/cpu output via jump-ahead ----------------------------------
+
+@pytest.mark.parametrize("L", [1, 2, 5, 30, 31, 32, 62, 80, 100])
+def test_uniform_glibc_equals_oracle_lengths(rw, L):
+    rp, ci = random_graph(500, 5, 21)
+    tg = np.random.default_rng(L).integers(0, 500, 1000)
+    ref = O.walk(rp, ci, tg, 1.0, 1.0, L, 10)
+    assert (_hip(rw, rp, ci, tg, 1.0, 1.0, L, 10) == ref).all()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 10, 123456, -1, -(2**31), 2**31 - 1])
+def test_uniform_glibc_equals_oracle_seeds(rw, seed):
+    rp, ci = hub_graph(400, 3)
+    tg = np.random.default_rng(5).integers(0, 400, 777)
+    ref = O.walk(rp, ci, tg, 1.0, 1.0, 20, seed)
+    assert (_hip(rw, rp, ci, tg, 1.0, 1.0, 20, seed) == ref).all()
+
+
+@pytest.mark.parametrize("chain", [1, 2, 3, 4, 7])
+def test_uniform_glibc_chain_lengths(rw, chain, monkeypatch):
+    """Walkers chained per lane is launch geometry, never visible in the output."""
+    monkeypatch.setenv("TRW_GLIBC_CHAIN", str(chain))
+    rp, ci = random_graph(300, 4, 8)
+    tg = np.random.default_rng(chain).integers(0, 300, 1001)
+    ref = O.walk(rp, ci, tg, 1.0, 1.0, 17, 10)
+    assert (_hip(rw, rp, ci, tg, 1.0, 1.0, 17, 10) == ref).all()
+
+
+def test_uniform_glibc_walker_base(rw):
+    rp, ci = random_graph(300, 4, 9)
+    tg = np.random.default_rng(1).integers(0, 300, 900)
+    ref = O.walk(rp, ci, tg, 1.0, 1.0, 80, 10)
+    for lo, hi in ((0, 1), (1, 400), (400, 900)):
+        got = _hip(rw, rp, ci, tg[lo:hi], 1.0, 1.0, 80, 10, walker_base=lo)
+        assert (got == ref[lo:hi]).all()
+    # far into the stream: more than 2^32 draws ahead
+    base = 2**33 // 80 + 12345
+    ref_far = O.walk(rp, ci, tg[:64], 1.0, 1.0, 80, 10, rng_mode=O.RNG_GLIBC_INDEXED, walker_base=base)
+    assert (_hip(rw, rp, ci, tg[:64], 1.0, 1.0, 80, 10, walker_base=base) == ref_far).all()
+
+
+def test_uniform_walker_stream_equals_oracle(rw):
+    rp, ci = hub_graph(500, 4)
+    tg = np.random.default_rng(2).integers(0, 500, 1500)
+    for L in (1, 3, 4, 5, 80):
+        ref = O.walk(rp, ci, tg, 1.0, 1.0, L, 77, rng_mode=O.RNG_WALKER, walker_base=1000)
+        got = _hip(rw, rp, ci, tg, 1.0, 1.0, L, 77, walker_base=1000, rng_mode=rw.RNG_WALKER)
+        assert (got == ref).all()
+
+
+# ---- biased walks ------------------------------------------------------------------------
+
+PQ = [(0.25, 4.0), (0.7, 0.5), (2.0, 1.0), (1.0, 1.0 + 1e-12), (4.0, 0.25)]
+
+
+@pytest.mark.parametrize("p,q", PQ)
+def test_biased_walker_equals_oracle(rw, p, q):
+    rp, ci = random_graph(200, 4, 31)
+    tg = np.random.default_rng(3).integers(0, 200, 2000)
+    ref = O.walk(rp, ci, tg, p, q, 20, 10, rng_mode=O.RNG_WALKER)
+    got = _hip(rw, rp, ci, tg, p, q, 20, 10, rng_mode=rw.RNG_WALKER)
+    assert (got == ref).all()
+
+
+def test_biased_walker_hub_graph_L80(rw):
+    rp, ci = hub_graph(1024, 6)
+    tg = np.random.default_rng(4).integers(0, 1024, 512)
+    ref = O.walk(rp, ci, tg, 0.25, 4.0, 80, 10, rng_mode=O.RNG_WALKER, walker_base=2**32 + 5)
+    got = _hip(rw, rp, ci, tg, 0.25, 4.0, 80, 10, rng_mode=rw.RNG_WALKER, walker_base=2**32 + 5)
+    assert (got == ref).all()
+
+
+def test_biased_walker_unsorted_rows_take_the_scan_path(rw):
+    rp, ci = random_graph(300, 5, 41, sort_rows=False)
+    assert any((np.diff(ci[rp[v]:rp[v + 1]]) < 0).any() for v in range(300))
+    tg = np.arange(300)
+    ref = O.walk(rp, ci, tg, 0.5, 2.0, 25, 3, rng_mode=O.RNG_WALKER)
+    got = _hip(rw, rp, ci, tg, 0.5, 2.0, 25, 3, rng_mode=rw.RNG_WALKER)
+    assert (got == ref).all()
+
+
+def test_biased_directed_asymmetry(rw):
+    rp = np.array([0, 2, 4, 5], dtype=np.int64)
+    ci = np.array([1, 2, 0, 2, 0], dtype=np.int64)
+    tg = np.zeros(256, dtype=np.int64)
+    ref = O.walk(rp, ci, tg, 0.5, 2.0, 12, 3, rng_mode=O.RNG_WALKER)
+    assert (_hip(rw, rp, ci, tg, 0.5, 2.0, 12, 3, rng_mode=rw.RNG_WALKER) == ref).all()
+
+
+@pytest.mark.parametrize("p,q", PQ)
+def test_biased_glibc_serial_replay_equals_reference_semantics(rw, p, q):
+    """TRW_RNG_GLIBC on a biased walk replays the reference's single serial stream."""
+    rp, ci = random_graph(200, 4, 51)
+    tg = np.random.default_rng(6).integers(0, 200, 300)
+    ref = O.walk(rp, ci, tg, p, q, 20, 10, rng_mode=O.RNG_GLIBC_SEQ)
+    got = _hip(rw, rp, ci, tg, p, q, 20, 10, rng_mode=rw.RNG_GLIBC)
+    assert (got == ref).all()
+
+
+def test_auto_mode_rule(rw):
+    """AUTO: biased walks replay the reference's stream up to its parallel_for grain
+    (32768/(L+1) walkers, rw_cpu.cpp:137), and use the per-walker stream beyond."""
+    rp, ci = random_graph(100, 4, 61)
+    L = 80
+    grain = 32768 // (L + 1)
+    tg = np.random.default_rng(7).integers(0, 100, grain + 1)
+    small = _hip(rw, rp, ci, tg[:grain], 0.5, 2.0, L, 10)
+    assert (small == O.walk(rp, ci, tg[:grain], 0.5, 2.0, L, 10, rng_mode=O.RNG_GLIBC_SEQ)).all()
+    big = _hip(rw, rp, ci, tg, 0.5, 2.0, L, 10)
+    assert (big == O.walk(rp, ci, tg, 0.5, 2.0, L, 10, rng_mode=O.RNG_WALKER)).all()
+
+
+# ---- boundary behaviour --------------------------------------------------------------------
+
+def test_edge_cases(rw):
+    rp, ci = random_graph(50, 3, 71)
+    d_rp, d_ci = _dev(rp, ci)
+    empty = rw.walk(d_rp, d_ci, torch.empty(0, dtype=torch.int64, device=DEV), 1.0, 1.0, 6, 1)
+    assert tuple(empty.shape) == (0, 7)
+    empty_b = rw.walk(d_rp, d_ci, torch.empty(0, dtype=torch.int64, device=DEV), 0.5, 2.0, 6, 1)
+    assert tuple(empty_b.shape) == (0, 7)
+    # duplicates are independent walkers
+    tg = np.full(64, 7)
+    assert (_hip(rw, rp, ci, tg, 1.0, 1.0, 12, 5) == O.walk(rp, ci, tg, 1.0, 1.0, 12, 5)).all()
+    # strided view of the targets (the reference's accessors honour strides)
+    base = torch.arange(100, dtype=torch.int64, device=DEV) % 50
+    strided = base[::2]
+    assert not strided.is_contiguous()
+    got = rw.walk(d_rp, d_ci, strided, 1.0, 1.0, 9, 3).cpu().numpy()
+    assert (got == O.walk(rp, ci, strided.cpu().numpy(), 1.0, 1.0, 9, 3)).all()
+    # walk_length = 1 on the biased path
+    assert (_hip(rw, rp, ci, [3, 4, 5], 0.5, 2.0, 1, 1, rng_mode=rw.RNG_WALKER)
+            == O.walk(rp, ci, [3, 4, 5], 0.5, 2.0, 1, 1, rng_mode=O.RNG_WALKER)).all()
+
+
+def test_errors_are_python_exceptions(rw):
+    rp, ci = random_graph(50, 3, 81)
+    d_rp, d_ci, d_tg = _dev(rp, ci, np.arange(50))
+    with pytest.raises(RuntimeError, match="expected scalar type Long"):
+        rw.walk(d_rp.to(torch.int32), d_ci, d_tg, 1.0, 1.0, 5, 1)
+    with pytest.raises(RuntimeError, match="walk_length"):
+        rw.walk(d_rp, d_ci, d_tg, 1.0, 1.0, 0, 1)
+    with pytest.raises(RuntimeError, match="same device|CUDA tensor"):
+        rw.walk(d_rp, d_ci.cpu(), d_tg, 1.0, 1.0, 5, 1)
+    # degree-0 node: the reference dies with SIGFPE (rw_cpu.cpp:20); here it is an exception
+    rp0 = np.array([0, 1, 1, 2], dtype=np.int64)
+    ci0 = np.array([1, 0], dtype=np.int64)
+    for p, q in ((1.0, 1.0), (0.5, 2.0)):
+        with pytest.raises(RuntimeError, match="no out-edges"):
+            rw.walk(*_dev(rp0, ci0, [0, 2]), p, q, 4, 1)
+    # start node outside the graph
+    with pytest.raises(RuntimeError, match="outside"):
+        rw.walk(d_rp, d_ci, torch.tensor([0, 50], device=DEV), 1.0, 1.0, 4, 1)
+    with pytest.raises(RuntimeError, match="outside"):
+        rw.walk(d_rp, d_ci, torch.tensor([-1], device=DEV), 0.5, 2.0, 4, 1)
+    # the launch is asynchronous and unchecked when asked to be (the reference's behaviour)
+    out = rw.walk_ex(d_rp, d_ci, torch.tensor([0, 50], device=DEV), 1.0, 1.0, 4, 1, check=False)
+    torch.cuda.synchronize()
+    assert out[1].tolist() == [50] * 5
+
+
+def test_runs_on_the_callers_stream(rw):
+    rp, ci = random_graph(200, 4, 91)
+    d_rp, d_ci, d_tg = _dev(rp, ci, np.arange(200))
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        out = rw.walk(d_rp, d_ci, d_tg, 1.0, 1.0, 30, 10)
+    s.synchronize()
+    assert (out.cpu().numpy() == O.walk(rp, ci, np.arange(200), 1.0, 1.0, 30, 10)).all()
+
+
+# ---- through the bare C ABI ----------------------------------------------------------------
+
+def test_c_abi_direct_call(rw):
+    from torch_random_walk_amd import _native
+    L = _native.cabi()
+    rp, ci = random_graph(300, 4, 101)
+    tg = np.random.default_rng(8).integers(0, 300, 500)
+    d_rp, d_ci, d_tg = _dev(rp, ci, tg)
+    for p, q, mode, omode in ((1.0, 1.0, 1, O.RNG_GLIBC_SEQ), (0.25, 4.0, 2, O.RNG_WALKER)):
+        out = torch.empty((500, 41), dtype=torch.int64, device=DEV)
+        nbytes = L.trw_walk_csr_workspace_bytes(300, len(ci), 500, 40, p, q, mode)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = L.trw_walk_csr_hip(d_rp.data_ptr(), 300, d_ci.data_ptr(), len(ci), d_tg.data_ptr(), 500, 0, p, q,
+                                40, 10, mode, out.data_ptr(), ws.data_ptr(), nbytes, stream)
+        assert rc == 0, L.trw_last_error()
+        st = (ctypes.c_int64 * 4)()
+        assert L.trw_walk_status(ws.data_ptr(), stream, st) == 0
+        assert st[0] == 0 and st[2] == mode
+        assert (out.cpu().numpy() == O.walk(rp, ci, tg, p, q, 40, 10, rng_mode=omode)).all()
+
+
+# ---- BASELINE-sized runs: properties + sampled oracle rows --------------------------------
+
+def _check_big(rw, rp, ci, tg, p, q, L, seed, omode, sample=2000):
+    from torch_random_walk_amd import graphs
+    w1 = rw.walk(rp, ci, tg, p, q, L, seed)
+    w2 = rw.walk(rp, ci, tg, p, q, L, seed)
+    assert torch.equal(w1, w2)                                   # deterministic
+    assert torch.equal(w1[:, 0], tg)                             # column 0 = start node
+    assert int(w1.min()) >= 0 and int(w1.max()) < rp.numel() - 1
+    assert graphs.walks_follow_edges(rp, ci, w1)                 # every step is an edge
+    n = tg.numel()
+    half = n // 2 + 3                                            # shard invariance
+    mode = rw.RNG_GLIBC if (p == 1.0 and q == 1.0) else rw.RNG_WALKER
+    a = rw.walk_ex(rp, ci, tg[:half], p, q, L, seed, walker_base=0, rng_mode=mode)
+    b = rw.walk_ex(rp, ci, tg[half:], p, q, L, seed, walker_base=half, rng_mode=mode)
+    assert torch.equal(torch.cat([a, b]), w1)
+    # sampled rows against the oracle (global walker index = row index)
+    rp_h, ci_h = rp.cpu().numpy(), ci.cpu().numpy()
+    rows = np.unique(np.concatenate([[0, 1, n - 1], np.random.default_rng(0).integers(0, n, sample)]))
+    tg_h = tg.cpu().numpy()
+    got = w1[torch.as_tensor(rows, device=w1.device)].cpu().numpy()
+    for r, g in zip(rows, got):
+        ref = O.walk(rp_h, ci_h, tg_h[r:r + 1], p, q, L, seed, rng_mode=omode, walker_base=int(r))
+        assert (ref[0] == g).all(), "row %d differs" % r
+
+
+def test_config2_er100k_uniform_full_size(rw):
+    """BASELINE config 2: Erdos-Renyi 100k nodes / 1M edges, p=q=1, L=80, 10 walks per node."""
+    from torch_random_walk_amd import graphs
+    rp, ci = graphs.erdos_renyi(100_000, 1_000_000, seed=1, device=DEV)
+    tg = torch.arange(100_000, device=DEV).repeat(10)
+    _check_big(rw, rp, ci, tg, 1.0, 1.0, 80, 10, O.RNG_GLIBC_INDEXED)
+
+
+def test_config3_rmat_biased_reduced_walkers(rw):
+    """BASELINE config 3's graph family at 1M nodes / 10M edges (the full 10M/100M graph runs in
+    bench.py): node2vec p=0.25 q=4, L=80."""
+    from torch_random_walk_amd import graphs
+    rp, ci = graphs.rmat(1_000_000, 10_000_000, seed=1, device=DEV)
+    tg = torch.arange(1_000_000, device=DEV)[:200_000]
+    _check_big(rw, rp, ci, tg, 0.25, 4.0, 80, 10, O.RNG_WALKER, sample=300)
+    _check_big(rw, rp, ci, tg, 1.0, 1.0, 80, 10, O.RNG_GLIBC_INDEXED, sample=300)

@@ -1,0 +1,131 @@
+// torch_rw_native -- the PyTorch-ROCm face of libtrw_hip.so.
+//
+// Plays the role of the reference's pybind dispatcher (csrc/rw_init.cpp:11-25,
+// m.def("walk") at :134) for the CSR walk path only: same module name, same
+// function name, same seven positional arguments.  Everything below the
+// argument checks is the C ABI of include/trw.h; torch is used for device
+// memory (output + scratch through the caching allocator), the device guard and
+// the current stream.
+//
+// CPU tensors are refused: this build is the MI355X path and carries no CPU
+// walker to fall back to.
+#include <torch/extension.h>
+
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+
+#include <atomic>
+#include <string>
+
+#include "../../include/trw.h"
+
+namespace {
+
+std::atomic<int> g_rng_mode{TRW_RNG_AUTO};
+std::atomic<bool> g_check{true};
+
+void check_index_tensor(const torch::Tensor &t, const char *name)
+{
+    // reference: CHECK_CUDA (csrc/cuda/utils.cuh:7, used at rw_cuda.cu:194-196)
+    TORCH_CHECK(t.is_cuda(), name,
+                " must be a CUDA tensor (torch_rw_native here is the MI355X HIP build; it has no CPU walker)");
+    // reference: the int64 accessor raises this text for any other dtype
+    TORCH_CHECK(t.scalar_type() == torch::kInt64, "expected scalar type Long but found ",
+                c10::toString(t.scalar_type()), " (", name, ")");
+    TORCH_CHECK(t.dim() == 1, name, " must be 1-dimensional, got ", t.dim(), " dimensions");
+}
+
+std::string status_text(int64_t bits)
+{
+    std::string s;
+    if (bits & TRW_ST_DEGREE0) s += "a walker reached a node with no out-edges (the reference divides by zero there); ";
+    if (bits & TRW_ST_NODE_RANGE) s += "a start node or col_idx entry is outside [0, num_nodes); ";
+    if (bits & TRW_ST_BAD_CSR) s += "row_ptr is not a monotone sequence within [0, len(col_idx)]; ";
+    if (bits & TRW_ST_TRIAL_CAP) s += "a rejection loop exceeded 2^20 trials at one step; ";
+    return s;
+}
+
+// walk_ex: the reference's seven arguments plus the two this library adds.
+torch::Tensor walk_ex(const torch::Tensor &row_ptr, const torch::Tensor &col_idx, const torch::Tensor &target_nodes,
+                      double p, double q, int64_t walk_length, int64_t seed, int64_t walker_base, int64_t rng_mode,
+                      bool check)
+{
+    check_index_tensor(row_ptr, "row_ptr");
+    check_index_tensor(col_idx, "col_idx");
+    check_index_tensor(target_nodes, "target_nodes");
+    TORCH_CHECK(row_ptr.device() == col_idx.device() && row_ptr.device() == target_nodes.device(),
+                "row_ptr, col_idx and target_nodes must be on the same device");
+    TORCH_CHECK(row_ptr.numel() >= 1, "row_ptr must have num_nodes + 1 entries");
+    TORCH_CHECK(walk_length >= 1, "walk_length must be >= 1, got ", walk_length);
+    TORCH_CHECK(walk_length < (int64_t(1) << 31) && seed >= INT32_MIN && seed <= INT32_MAX,
+                "walk_length/seed must fit the reference's int arguments");
+
+    const c10::hip::HIPGuard guard(row_ptr.device());
+    const auto stream = c10::hip::getCurrentHIPStream(row_ptr.device().index());
+
+    // the reference's accessors honour strides; the C ABI wants dense arrays
+    const auto rp = row_ptr.contiguous();
+    const auto ci = col_idx.contiguous();
+    const auto tg = target_nodes.contiguous();
+    const int64_t n_nodes = rp.numel() - 1;
+    const int64_t nnz = ci.numel();
+    const int64_t n_walkers = tg.numel();
+
+    // rw_cuda.cu:201-203: a fresh [N, L+1] int64 tensor on the inputs' device
+    auto walks = torch::empty({n_walkers, walk_length + 1}, rp.options());
+
+    const size_t ws_bytes =
+        trw_walk_csr_workspace_bytes(n_nodes, nnz, n_walkers, (int32_t)walk_length, p, q, (int32_t)rng_mode);
+    auto workspace = torch::empty({(int64_t)ws_bytes}, rp.options().dtype(torch::kUInt8));
+
+    int rc;
+    {
+        pybind11::gil_scoped_release nogil;
+        rc = trw_walk_csr_hip(rp.data_ptr<int64_t>(), n_nodes, ci.data_ptr<int64_t>(), nnz, tg.data_ptr<int64_t>(),
+                              n_walkers, walker_base, p, q, (int32_t)walk_length, (int32_t)seed, (int32_t)rng_mode,
+                              walks.data_ptr<int64_t>(), workspace.data_ptr(), ws_bytes, (void *)stream.stream());
+    }
+    TORCH_CHECK(rc == TRW_OK, "torch_rw walk failed (", rc, "): ", trw_last_error());
+
+    if (check) {
+        int64_t status[4] = {0, 0, 0, 0};
+        {
+            pybind11::gil_scoped_release nogil;
+            rc = trw_walk_status(workspace.data_ptr(), (void *)stream.stream(), status);
+        }
+        TORCH_CHECK(rc == TRW_OK, "torch_rw status read failed (", rc, "): ", trw_last_error());
+        TORCH_CHECK(status[0] == 0, "torch_rw walk: ", status_text(status[0]), "status bits ", status[0]);
+    }
+    return walks;
+}
+
+// The reference's signature, verbatim (rw_init.cpp:11-17).
+torch::Tensor walk(const torch::Tensor &row_ptr, const torch::Tensor &column_idx, const torch::Tensor &target_nodes,
+                   const double p, const double q, const int walk_length, const int seed)
+{
+    return walk_ex(row_ptr, column_idx, target_nodes, p, q, walk_length, seed, 0, g_rng_mode.load(), g_check.load());
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
+{
+    m.doc() = "MI355X-native CSR random walks behind the torch_rw.rw.walk surface";
+    m.def("walk", &walk, "walk", pybind11::arg("row_ptr"), pybind11::arg("col_idx"), pybind11::arg("target_nodes"),
+          pybind11::arg("p"), pybind11::arg("q"), pybind11::arg("walk_length"), pybind11::arg("seed"));
+    m.def("walk_ex", &walk_ex, "walk with an explicit global walker base, RNG mode and status check",
+          pybind11::arg("row_ptr"), pybind11::arg("col_idx"), pybind11::arg("target_nodes"), pybind11::arg("p"),
+          pybind11::arg("q"), pybind11::arg("walk_length"), pybind11::arg("seed"), pybind11::arg("walker_base") = 0,
+          pybind11::arg("rng_mode") = (int64_t)TRW_RNG_AUTO, pybind11::arg("check") = true);
+    m.def("set_rng_mode", [](int64_t mode) {
+        TORCH_CHECK(mode == TRW_RNG_AUTO || mode == TRW_RNG_GLIBC || mode == TRW_RNG_WALKER, "unknown rng mode ", mode);
+        g_rng_mode.store((int)mode);
+    });
+    m.def("get_rng_mode", []() { return (int64_t)g_rng_mode.load(); });
+    m.def("set_check", [](bool on) { g_check.store(on); });
+    m.def("get_check", []() { return g_check.load(); });
+    m.def("abi_version", []() { return (int64_t)trw_version(); });
+    m.attr("RNG_AUTO") = (int64_t)TRW_RNG_AUTO;
+    m.attr("RNG_GLIBC") = (int64_t)TRW_RNG_GLIBC;
+    m.attr("RNG_WALKER") = (int64_t)TRW_RNG_WALKER;
+}

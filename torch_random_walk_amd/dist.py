@@ -1,0 +1,62 @@
+"""Start-node batches sharded over the GPUs of one node.
+
+The reference is single-device (csrc/cuda/rw_cuda.cu:198); this is the one
+multi-GPU step the path has.  The CSR is replicated on every rank, the start
+nodes are block-partitioned, each rank walks its block with the block's global
+offset as ``walker_base`` (so the assembled result is bit-identical to the
+single-GPU call), and ONE collective gathers the row blocks.  No collective is
+needed by the walk itself.
+"""
+import torch
+import torch.distributed as dist
+
+from . import rw
+
+
+def shard_bounds(n, world_size, rank):
+    """Block partition: rank r owns [r*B, min(n, (r+1)*B)), B = ceil(n / world_size)."""
+    block = (n + world_size - 1) // world_size if world_size > 0 else n
+    lo = min(n, rank * block)
+    hi = min(n, lo + block)
+    return lo, hi, block
+
+
+def walk_sharded(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, group=None, gather="root",
+                 rng_mode=None, walk_fn=None):
+    """Walk ``target_nodes`` (the full batch, same on every rank) across the ranks of ``group``.
+
+    gather: "root"  -> rank 0 returns the full ``[N, L+1]`` tensor, other ranks return their block
+            "all"   -> every rank returns the full tensor (all_gather)
+            "none"  -> every rank returns its own block only
+    rng_mode: default = GLIBC for uniform walks (indexed jump-ahead shards exactly),
+              WALKER for biased walks (the serial glibc chain cannot be sharded).
+    walk_fn: override of ``rw.walk_ex`` (the CPU tests plug the oracle in here).
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n = int(target_nodes.numel())
+    lo, hi, block = shard_bounds(n, world, rank)
+    if rng_mode is None:
+        rng_mode = rw.RNG_GLIBC if (p == 1.0 and q == 1.0) else rw.RNG_WALKER
+    fn = walk_fn or rw.walk_ex
+    mine = fn(row_ptr, col_idx, target_nodes[lo:hi], p, q, walk_length, seed, walker_base=lo, rng_mode=rng_mode)
+    if world == 1 or gather == "none":
+        return mine
+    cols = walk_length + 1
+    padded = mine
+    if hi - lo < block:  # equal-sized pieces for the collective; the pad rows are dropped below
+        padded = torch.zeros((block, cols), dtype=mine.dtype, device=mine.device)
+        padded[: hi - lo] = mine
+    if gather == "all":
+        full = torch.empty((world * block, cols), dtype=mine.dtype, device=mine.device)
+        dist.all_gather_into_tensor(full, padded.contiguous(), group=group)
+        return full[:n]
+    if gather == "root":
+        if rank == 0:
+            full = torch.empty((world * block, cols), dtype=mine.dtype, device=mine.device)
+            pieces = list(full.split(block, dim=0))
+            dist.gather(padded.contiguous(), pieces, dst=0, group=group)
+            return full[:n]
+        dist.gather(padded.contiguous(), None, dst=0, group=group)
+        return mine
+    raise ValueError("gather must be 'root', 'all' or 'none'")

@@ -1,0 +1,43 @@
+"""The reference's Python surface for the CSR walk (torch_rw/rw.py:3-4), on MI355X.
+
+``walk`` keeps the reference's name, parameter names and order.  ``walk_ex`` adds
+the two things a sharded caller needs (global walker base, explicit RNG mode).
+"""
+from ._native import ext as torch_rw_native
+from ._native import RNG_AUTO, RNG_GLIBC, RNG_WALKER  # noqa: F401
+
+
+def walk(row_ptr, col_idx, target_nodes, p, q, walk_length, seed):
+    """Random walks of ``walk_length`` steps from every node in ``target_nodes``.
+
+    Same contract as the reference (torch_rw/rw.py:3-4 -> csrc/rw_init.cpp:11-25):
+    int64 CSR tensors in, ``[len(target_nodes), walk_length+1]`` int64 out on the
+    inputs' device, column 0 = start node; ``p == 1.0 and q == 1.0`` selects the
+    uniform walk, anything else the node2vec rejection sampler.
+    """
+    return torch_rw_native.walk(row_ptr, col_idx, target_nodes, p, q, walk_length, seed)
+
+
+def walk_ex(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, walker_base=0, rng_mode=RNG_AUTO,
+            check=True):
+    """``walk`` with an explicit global index for ``target_nodes[0]`` and RNG mode.
+
+    A shard that passes the global offset of its slice reproduces exactly the rows
+    the unsharded call would have produced (include/trw.h, TRW_RNG_*).
+    """
+    return torch_rw_native.walk_ex(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, walker_base,
+                                   rng_mode, check)
+
+
+def set_rng_mode(mode):
+    """Process-wide RNG mode used by ``walk`` (RNG_AUTO / RNG_GLIBC / RNG_WALKER)."""
+    torch_rw_native.set_rng_mode(mode)
+
+
+def get_rng_mode():
+    return torch_rw_native.get_rng_mode()
+
+
+def set_check(on):
+    """Whether ``walk`` synchronises and raises on device-side data faults (default True)."""
+    torch_rw_native.set_check(bool(on))

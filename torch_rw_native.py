@@ -1,0 +1,12 @@
+"""Top-level alias so that `import torch_rw_native` (reference torch_rw/rw.py:1) resolves
+to the MI355X extension built in torch_random_walk_amd/."""
+from torch_random_walk_amd._native import ext as _ext
+
+walk = _ext.walk
+walk_ex = _ext.walk_ex
+set_rng_mode = _ext.set_rng_mode
+get_rng_mode = _ext.get_rng_mode
+set_check = _ext.set_check
+get_check = _ext.get_check
+abi_version = _ext.abi_version
+RNG_AUTO, RNG_GLIBC, RNG_WALKER = _ext.RNG_AUTO, _ext.RNG_GLIBC, _ext.RNG_WALKER
