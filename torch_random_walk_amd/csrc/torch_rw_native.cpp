@@ -11,8 +11,10 @@
 // walker to fall back to.
 #include <torch/extension.h>
 
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+// PyTorch-ROCm presents its HIP devices under the "cuda" device type; these are the guard and
+// stream accessors that go with that.
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include <atomic>
 #include <string>
@@ -60,8 +62,8 @@ torch::Tensor walk_ex(const torch::Tensor &row_ptr, const torch::Tensor &col_idx
     TORCH_CHECK(walk_length < (int64_t(1) << 31) && seed >= INT32_MIN && seed <= INT32_MAX,
                 "walk_length/seed must fit the reference's int arguments");
 
-    const c10::hip::HIPGuard guard(row_ptr.device());
-    const auto stream = c10::hip::getCurrentHIPStream(row_ptr.device().index());
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(row_ptr.device());
+    const auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(row_ptr.device().index());
 
     // the reference's accessors honour strides; the C ABI wants dense arrays
     const auto rp = row_ptr.contiguous();
