@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py -- walk-steps/s of the CSR random-walk hot path on 1..8 MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch: every rank walks one walk
+of `walk_length` steps from each of its start nodes (weak scaling: the batch per
+GPU is fixed; rank r's walkers carry global indices r*B .. r*B+B-1, i.e. the
+job is "world_size walks per node", node2vec's `r` parameter), and for N > 1
+the row blocks are gathered on rank 0 with ONE RCCL collective, inside the
+timed region.  Inputs are resident in HBM before timing starts.
+
+Workloads (BASELINE.json `configs`):
+  rmat10m_biased   configs[2]  RMAT 10M nodes / 100M edges, node2vec p=0.25 q=4, L=80   (default:
+                               the graph the north-star target is quoted on)
+  rmat10m_uniform  same graph, p=q=1 (reference-exact glibc draws)
+  er100k_uniform   configs[1]  Erdos-Renyi 100k nodes / 1M edges, p=q=1, L=80, 10 walks per node
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the walk
+kernel), its duration measured with HIP events on the launch stream through the
+library's own instrumentation hook; `cpu_baseline` times the oracle's
+libc-rand() single-thread mode (the reference's csrc/cpu algorithm) on a bounded
+sample of the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+
+WORKLOADS = {
+    "rmat10m_biased": dict(graph="rmat", nodes=10_000_000, edges=100_000_000, p=0.25, q=4.0, walks_per_node=1),
+    "rmat10m_uniform": dict(graph="rmat", nodes=10_000_000, edges=100_000_000, p=1.0, q=1.0, walks_per_node=1),
+    "er100k_uniform": dict(graph="er", nodes=100_000, edges=1_000_000, p=1.0, q=1.0, walks_per_node=10),
+    # small variants for quick checks / CI on the GPU box
+    "rmat1m_biased": dict(graph="rmat", nodes=1_000_000, edges=10_000_000, p=0.25, q=4.0, walks_per_node=1),
+    "rmat1m_uniform": dict(graph="rmat", nodes=1_000_000, edges=10_000_000, p=1.0, q=1.0, walks_per_node=1),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="rmat10m_biased", choices=sorted(WORKLOADS))
+    ap.add_argument("--walk-length", type=int, default=80)
+    ap.add_argument("--seed", type=int, default=10)
+    ap.add_argument("--graph-seed", type=int, default=1)
+    ap.add_argument("--no-gather", action="store_true", help="N>1: leave the row blocks on their ranks")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from torch_random_walk_amd import _native, graphs, rw
+    from torch_random_walk_amd.dist import shard_bounds  # noqa: F401  (the partition rule this bench follows)
+
+    cfg = WORKLOADS[args.workload]
+    L = args.walk_length
+    p, q = cfg["p"], cfg["q"]
+    uniform = (p == 1.0 and q == 1.0)
+    n = cfg["nodes"]
+
+    # ---- synthetic graph, generated on the device from a seed (identical on every rank) ----
+    t0 = time.time()
+    if cfg["graph"] == "rmat":
+        row_ptr, col_idx = graphs.rmat(n, cfg["edges"], seed=args.graph_seed, device=dev)
+    else:
+        row_ptr, col_idx = graphs.erdos_renyi(n, cfg["edges"], seed=args.graph_seed, device=dev)
+    nnz = int(col_idx.numel())
+    targets = torch.arange(n, device=dev, dtype=torch.int64).repeat(cfg["walks_per_node"])
+    B = int(targets.numel())          # walkers per GPU (fixed: weak scaling)
+    walker_base = rank * B            # global walker index of this rank's first walker
+    torch.cuda.synchronize()
+    t_graph = time.time() - t0
+
+    mode = rw.RNG_GLIBC if uniform else rw.RNG_WALKER
+    gather = (world > 1) and not args.no_gather
+    full = None
+    if gather and rank == 0:
+        full = torch.empty((world * B, L + 1), dtype=torch.int64, device=dev)
+
+    def one_step():
+        walks = rw.walk_ex(row_ptr, col_idx, targets, p, q, L, args.seed, walker_base=walker_base,
+                           rng_mode=mode, check=False)
+        if gather:
+            if rank == 0:
+                dist.gather(walks, list(full.split(B, dim=0)), dst=0)
+            else:
+                dist.gather(walks, None, dst=0)
+        return walks
+
+    lib = _native.cabi()
+    for _ in range(args.warmup):
+        walks = one_step()
+    torch.cuda.synchronize()
+
+    # ---- timed region: exactly K steps between barriers -------------------------------------
+    lib.trw_profile_enable(1)
+    kernel_ms, prepare_ms, finish_ms = [], [], []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        walks = one_step()
+        a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        # reading the events of step k waits for that step's kernels; the next step is not queued yet
+        if lib.trw_profile_last(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) == 0:
+            prepare_ms.append(a.value)
+            kernel_ms.append(b.value)
+            finish_ms.append(c.value)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    lib.trw_profile_enable(0)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # ---- device-side status of the last step (validity of what was timed) -------------------
+    chk = rw.walk_ex(row_ptr, col_idx, targets[:1024], p, q, L, args.seed, walker_base=walker_base,
+                     rng_mode=mode, check=True)
+    assert torch.equal(chk, walks[:1024]), "timed output differs from a checked re-run"
+
+    # ---- algorithmic bytes of one launch ----------------------------------------
+    counters = None
+    if uniform:
+        alg_bytes = B * (16 + 32 * L)
+    else:
+        lib.trw_profile_enable(2)
+        nbytes = lib.trw_walk_csr_workspace_bytes(n, nnz, B, L, p, q, mode)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        out = torch.empty((B, L + 1), dtype=torch.int64, device=dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = lib.trw_walk_csr_hip(row_ptr.data_ptr(), n, col_idx.data_ptr(), nnz, targets.data_ptr(), B,
+                                  walker_base, p, q, L, args.seed, mode, out.data_ptr(), ws.data_ptr(), nbytes,
+                                  stream)
+        assert rc == 0, lib.trw_last_error()
+        c = (ctypes.c_uint64 * 4)()
+        assert lib.trw_walk_counters(ws.data_ptr(), stream, c) == 0
+        lib.trw_profile_enable(0)
+        assert torch.equal(out, walks), "counting variant of the kernel produced different walks"
+        trials, fetches, tests, probes = (int(x) for x in c)
+        counters = dict(trials=trials, candidate_loads=fetches, membership_tests=tests, bisect_entries=probes)
+        # int64-API-layout bytes the algorithm as run must move (with this kernel's
+        # own counts): per walker 8 B target + 8 B column 0 + 32 B first step; per later step
+        # 16 B row_ptr pair + 8 B stored column; 8 B per candidate entry actually loaded and per
+        # col_idx entry a bisection reads.  (The reference's own access pattern -- a candidate load
+        # and a linear row scan on every trial -- would count many times more.)
+        alg_bytes = B * 16 + B * 32 + (L - 1) * B * (16 + 8) + 8 * fetches + 8 * probes
+        del out, ws
+
+    steps_per_launch = B * L
+    k_ms = sum(kernel_ms) / max(1, len(kernel_ms))
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            with open(pmc_path) as f:
+                traffic = json.load(f).get(args.workload, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    # ---- CPU baseline: the reference's algorithm on a bounded sample (rank 0, N = 1 only) ------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as O
+        rp_h, ci_h = row_ptr.cpu().numpy(), col_idx.cpu().numpy()
+        g = torch.Generator().manual_seed(12345)
+        perm = torch.randperm(B, generator=g)
+        probe = 500 if not uniform else 5000
+        tg_h = targets.cpu()[perm[:probe]].numpy()
+        _, dt = O.walk_timed(rp_h, ci_h, tg_h, p, q, L, args.seed, rng_mode=O.RNG_LIBC)
+        rate = probe * L / dt
+        sample = int(min(B, max(probe, args.cpu_seconds * rate / L)))
+        tg_h = targets.cpu()[perm[:sample]].numpy()
+        _, dt = O.walk_timed(rp_h, ci_h, tg_h, p, q, L, args.seed, rng_mode=O.RNG_LIBC)
+        cpu = dict(value=sample * L / dt, unit="walk-steps/s", cores=1, kind="port",
+                   sample="first %d start nodes of a seeded permutation of the batch, %d steps, %.1f s, "
+                          "oracle libc srand/rand single thread (the reference's csrc/cpu algorithm; its "
+                          "multi-threaded run is slower and non-deterministic, SURVEY 0.2)" % (sample, sample * L, dt))
+
+    if rank == 0:
+        total_steps = world * B * L * args.steps
+        line = {
+            "metric": "walk-steps/s",
+            "value": total_steps / elapsed,
+            "unit": "walk-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int64",
+            "data": "synthetic",
+            "walks_per_s": world * B * args.steps / elapsed,
+            "config": {
+                "workload": args.workload,
+                "graph": "%s nodes=%d directed_edges=%d (+ring) nnz=%d graph_seed=%d" % (
+                    cfg["graph"], n, cfg["edges"], nnz, args.graph_seed),
+                "p": p, "q": q, "walk_length": L, "seed": args.seed,
+                "walkers_per_gpu": B, "global_walkers": world * B,
+                "rng": "glibc-indexed (csrc/cpu-exact)" if uniform else "per-walker philox4x32-10",
+                "partition": "start nodes block-sharded, CSR replicated",
+                "collective": "one RCCL gather to rank 0 inside the timed step" if gather else "none",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "uniform_glibc_kernel" if uniform else "biased_walker_kernel",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "units_per_launch": steps_per_launch,
+                "kernel_ms": k_ms,
+                "prepare_ms": sum(prepare_ms) / max(1, len(prepare_ms)),
+                "finish_ms": sum(finish_ms) / max(1, len(finish_ms)),
+                "kernel_steps_per_s": steps_per_launch / (k_ms * 1e-3) if k_ms > 0 else None,
+                "counters": counters,
+            },
+            "cpu_baseline": cpu,
+            "graph_build_s": t_graph,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -9,7 +9,10 @@
  * is made; the caller owns every buffer.  Calls are asynchronous on
  * `hip_stream` (a hipStream_t, NULL = the null stream) unless stated otherwise
  * and allocate nothing after the first call on a device (which uploads a 190 KB
- * constant jump table once).
+ * constant jump table once).  Environment knobs (debug/tests): TRW_GLIBC_CHAIN=k
+ * walkers chained per lane in the uniform kernel; TRW_FORCE_WIDE=1 use the int64
+ * kernels; TRW_NO_POS=1 disable the located-t shortcut of the biased kernel.
+ * None of them changes a result.
  */
 #ifndef TRW_H
 #define TRW_H
@@ -73,7 +76,9 @@ int trw_version(void);
 const char *trw_last_error(void);
 
 /* Bytes of device scratch trw_walk_csr_hip needs for this call shape
- * (>= 256; status block + per-lane RNG windows). */
+ * (>= 256): status block, per-lane RNG windows (uniform walks), the uint32
+ * shadow of the CSR (4*(n_nodes+1+nnz) bytes) and the uint32 staging planes
+ * (4*n_walkers*(walk_length+1) bytes). */
 size_t trw_walk_csr_workspace_bytes(int64_t n_nodes, int64_t nnz, int64_t n_walkers,
                                     int32_t walk_length, double p, double q, int32_t rng_mode);
 
@@ -116,7 +121,7 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes,
  * status[1] = 1 if some CSR row was found unsorted (biased walks only; the
  * membership test then scans linearly like rw_cpu.cpp:32-56 instead of
  * bisecting), status[2] = the RNG mode that ran (TRW_RNG_GLIBC/WALKER),
- * status[3] = reserved.  Returns TRW_OK or TRW_E_HIP. */
+ * status[3] = 1 if the uint32-shadow kernels ran, 0 for the int64 kernels.  Returns TRW_OK or TRW_E_HIP. */
 int trw_walk_status(const void *workspace, void *hip_stream, int64_t status[4]);
 
 /* Integer form of the reference's accept test (rw_cpu.cpp:169-194):
@@ -129,13 +134,22 @@ uint32_t trw_accept_threshold(double prob);
  * (the same tables the device uses).  Exported for tests. */
 void trw_glibc_window_at(int32_t seed, uint64_t pos, uint32_t window[31]);
 
-/* Instrumentation for bench.py (not thread-safe, one call in flight): when
- * enabled, every trw_walk_csr_hip records HIP events on its stream around its
- * two phases; trw_profile_last() synchronises the last one and returns the
- * device time of the prepare phase (jump-ahead windows / row-order probe) and
- * of the walk kernel itself, in milliseconds. */
-int trw_profile_enable(int on);
-int trw_profile_last(double *prepare_ms, double *walk_ms);
+/* Instrumentation for bench.py (not thread-safe, one call in flight).
+ * trw_profile_enable(flags): bit 0 -- every trw_walk_csr_hip records HIP events
+ * on its stream around its three phases; trw_profile_last() synchronises the
+ * last call's events and returns, in milliseconds, the device time of
+ *   prepare  (uint32 shadow CSR + validation; glibc jump-ahead windows),
+ *   walk     (the walk kernel itself -- the dominant kernel),
+ *   finish   (staging planes -> [N, L+1] int64 rows).
+ * bit 1 -- the biased walker kernel also counts its work into the workspace
+ * (a separately compiled variant, not the one that is timed);
+ * trw_walk_counters() synchronises and returns
+ *   [0] rejection trials, [1] candidate entries loaded from col_idx,
+ *   [2] membership tests performed, [3] col_idx entries read by bisections
+ *   (membership tests and the once-per-step location of t in prev's row). */
+int trw_profile_enable(int flags);
+int trw_profile_last(double *prepare_ms, double *walk_ms, double *finish_ms);
+int trw_walk_counters(const void *workspace, void *hip_stream, uint64_t counters[4]);
 
 #ifdef __cplusplus
 }

@@ -66,10 +66,16 @@ def test_window_reproduces_libc_draws(libc_vectors):
 def test_workspace_bytes():
     from torch_random_walk_amd import _native
     f = _native.cabi().trw_walk_csr_workspace_bytes
-    assert f(10, 20, 0, 5, 1.0, 1.0, 0) >= 256
-    assert f(10, 20, 1000, 80, 0.5, 2.0, 0) == 256           # biased: status block only
-    assert f(10, 20, 1000, 80, 1.0, 1.0, 2) == 256           # uniform on the walker stream: no windows
-    assert f(10, 20, 1000, 80, 1.0, 1.0, 0) >= 256 + 1000 * 124
+    n, nnz, N, L = 10, 20, 1000, 80
+    shadow = 4 * (n + 1) + 4 * nnz
+    stage = 4 * N * (L + 1)
+    assert f(n, nnz, 0, 5, 1.0, 1.0, 0) >= 256
+    assert f(n, nnz, N, L, 0.5, 2.0, 1) == 256                        # serial glibc replay: status block only
+    assert f(n, nnz, N, L, 1.0, 1.0, 2) == 256                        # uniform on the walker stream: int64 kernels
+    assert shadow + stage <= f(n, nnz, N, L, 0.5, 2.0, 2) - 256 <= shadow + stage + 4 * 256
+    assert f(n, nnz, N, L, 1.0, 1.0, 0) >= 256 + N * 124 + shadow + stage
+    assert f(2**31, nnz, N, L, 0.5, 2.0, 2) == 256                    # too many nodes for the uint32 shadow
+    assert f(n, 2**32, N, L, 0.5, 2.0, 2) == 256
 
 
 def test_argument_errors_return_codes_without_touching_the_gpu():

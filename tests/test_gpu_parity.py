@@ -251,8 +251,54 @@ def test_c_abi_direct_call(rw):
         assert rc == 0, L.trw_last_error()
         st = (ctypes.c_int64 * 4)()
         assert L.trw_walk_status(ws.data_ptr(), stream, st) == 0
-        assert st[0] == 0 and st[2] == mode
+        assert st[0] == 0 and st[2] == mode and st[3] == 1
         assert (out.cpu().numpy() == O.walk(rp, ci, tg, p, q, 40, 10, rng_mode=omode)).all()
+
+
+@pytest.mark.parametrize("env", [{"TRW_FORCE_WIDE": "1"}, {"TRW_NO_POS": "1"}, {}])
+def test_kernel_variants_agree(rw, env, monkeypatch):
+    """The int64 kernels, the narrow kernels with and without the located-t shortcut: same walks."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rp, ci = hub_graph(600, 12)
+    tg = np.random.default_rng(9).integers(0, 600, 1500)
+    for p, q in ((0.25, 4.0), (4.0, 0.25), (0.7, 0.5)):
+        ref = O.walk(rp, ci, tg, p, q, 30, 10, rng_mode=O.RNG_WALKER)
+        assert (_hip(rw, rp, ci, tg, p, q, 30, 10, rng_mode=rw.RNG_WALKER) == ref).all()
+    ref = O.walk(rp, ci, tg, 1.0, 1.0, 30, 10)
+    assert (_hip(rw, rp, ci, tg, 1.0, 1.0, 30, 10) == ref).all()
+    # duplicates inside a row (multi-edges) keep their weight in the candidate draw
+    rp2 = np.array([0, 4, 6, 8], dtype=np.int64)
+    ci2 = np.array([1, 1, 1, 2, 0, 2, 0, 1], dtype=np.int64)
+    tg2 = np.arange(3).repeat(100)
+    ref = O.walk(rp2, ci2, tg2, 0.25, 4.0, 20, 5, rng_mode=O.RNG_WALKER)
+    assert (_hip(rw, rp2, ci2, tg2, 0.25, 4.0, 20, 5, rng_mode=rw.RNG_WALKER) == ref).all()
+
+
+def test_work_counters(rw):
+    """The counting variant of the biased kernel: same walks, trial count equal to the oracle's."""
+    from torch_random_walk_amd import _native
+    L = _native.cabi()
+    rp, ci = hub_graph(500, 14)
+    tg = np.random.default_rng(10).integers(0, 500, 3000)
+    ref, cnt = O.walk(rp, ci, tg, 0.25, 4.0, 40, 10, rng_mode=O.RNG_WALKER, return_counters=True)
+    d_rp, d_ci, d_tg = _dev(rp, ci, tg)
+    out = torch.empty((3000, 41), dtype=torch.int64, device=DEV)
+    nbytes = L.trw_walk_csr_workspace_bytes(500, len(ci), 3000, 40, 0.25, 4.0, 2)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    stream = torch.cuda.current_stream().cuda_stream
+    L.trw_profile_enable(2)
+    try:
+        rc = L.trw_walk_csr_hip(d_rp.data_ptr(), 500, d_ci.data_ptr(), len(ci), d_tg.data_ptr(), 3000, 0, 0.25, 4.0,
+                                40, 10, 2, out.data_ptr(), ws.data_ptr(), nbytes, stream)
+        assert rc == 0, L.trw_last_error()
+        c = (ctypes.c_uint64 * 4)()
+        assert L.trw_walk_counters(ws.data_ptr(), stream, c) == 0
+    finally:
+        L.trw_profile_enable(0)
+    assert (out.cpu().numpy() == ref).all()
+    assert c[0] == cnt["trials_total"]
+    assert c[1] <= c[0] and c[2] <= cnt["membership_tests"]      # most trials never touch memory
 
 
 # ---- BASELINE-sized runs: properties + sampled oracle rows --------------------------------

@@ -47,7 +47,9 @@ def cabi():
         L.trw_glibc_window_at.restype = None
         L.trw_profile_enable.argtypes = [ctypes.c_int]
         L.trw_profile_enable.restype = ctypes.c_int
-        L.trw_profile_last.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        L.trw_profile_last.argtypes = [ctypes.POINTER(ctypes.c_double)] * 3
         L.trw_profile_last.restype = ctypes.c_int
+        L.trw_walk_counters.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_uint64)]
+        L.trw_walk_counters.restype = ctypes.c_int
         _cabi = L
     return _cabi

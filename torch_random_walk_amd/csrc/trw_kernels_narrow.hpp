@@ -1,0 +1,421 @@
+// trw_kernels_narrow.hpp -- the production kernels: 32-bit shadow CSR, staged output.
+//
+// What the profile of the int64 kernels showed (profiles/r01_*): both walks are
+// bound by the number of cache lines that miss L2 (5.5e10 64-byte fetches/s, i.e.
+// the memory system's random-access ceiling), and every 8-byte scattered store
+// cost 32 bytes of HBM write.  So these kernels are built to touch fewer lines:
+//
+//   csr_shadow_kernel     one streaming pass: int64 CSR -> uint32 shadow (half the
+//                         footprint, twice the entries per line), validates it and
+//                         counts order descents so the walk knows whether rows are sorted
+//   uniform_glibc_kernel  reference-exact uniform walk; lanes write their steps
+//                         lane-contiguously into a uint32 staging plane (one 256-byte
+//                         store per wave and step instead of 64 scattered ones)
+//   biased_walker_kernel  node2vec rejection sampling on the per-walker stream; most
+//                         trials are decided without touching memory (see below)
+//   transpose_rows_kernel staging planes -> the caller's [N, L+1] int64 rows through an
+//                         LDS tile, whole 512-byte row segments per wave store
+//
+// Included by trw_hip.hip only.  Valid for n_nodes < 2^31 and nnz < 2^32.
+#pragma once
+
+namespace {
+
+constexpr int kStDescents = 8;    // status slot: adjacent pairs col[e] > col[e+1]
+constexpr int kStBoundary = 9;    // status slot: such pairs that straddle a row boundary
+
+// ---------------------------------------------------------------------------
+// Shadow CSR
+// ---------------------------------------------------------------------------
+// col32[e] = col_idx[e], row32[v] = row_ptr[v]; out-of-contract values are
+// clamped (so nothing downstream can index outside the arrays) and reported.
+// Rows are all sorted  <=>  every descent col[e-1] > col[e] sits on a row
+// boundary  <=>  status[kStDescents] == status[kStBoundary].
+template <bool kOrder>
+__global__ void __launch_bounds__(kBlock)
+csr_shadow_kernel(const int64_t *__restrict__ row_ptr, const int64_t *__restrict__ col_idx, int64_t n_nodes,
+                  int64_t nnz, uint32_t *__restrict__ row32, uint32_t *__restrict__ col32,
+                  int64_t *__restrict__ status)
+{
+    const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    uint32_t st = 0;
+    uint32_t desc = 0, bdesc = 0;
+    for (int64_t e = tid; e < nnz; e += stride) {
+        const int64_t c = col_idx[e];
+        const bool ok = (uint64_t)c < (uint64_t)n_nodes;
+        if (!ok) st |= TRW_ST_NODE_RANGE;
+        col32[e] = ok ? (uint32_t)c : 0u;
+        if (kOrder && e + 1 < nnz) desc += (c > col_idx[e + 1]) ? 1u : 0u;
+    }
+    for (int64_t v = tid; v <= n_nodes; v += stride) {
+        int64_t r = row_ptr[v];
+        bool bad = r < 0 || r > nnz;
+        if (v < n_nodes && row_ptr[v + 1] < r) bad = true;
+        if (bad) st |= TRW_ST_BAD_CSR;
+        r = r < 0 ? 0 : (r > nnz ? nnz : r);
+        row32[v] = (uint32_t)r;
+        if (kOrder && v >= 1 && r > 0 && r < nnz && row_ptr[v - 1] < r)  // first node whose row starts at r
+            bdesc += (col_idx[r - 1] > col_idx[r]) ? 1u : 0u;
+    }
+    if (st) atomicOr((unsigned long long *)&status[0], (unsigned long long)st);
+    if (kOrder) {
+        const uint64_t a = wave_sum(desc), b = wave_sum(bdesc);
+        if ((threadIdx.x & 63) == 0) {
+            if (a) atomicAdd((unsigned long long *)&status[kStDescents], (unsigned long long)a);
+            if (b) atomicAdd((unsigned long long *)&status[kStBoundary], (unsigned long long)b);
+        }
+    }
+}
+
+// The row of `node` in the shadow.  row32 is clamped to [0, nnz]; a non-monotone
+// pair (already reported by csr_shadow_kernel) reads as an empty row.
+__device__ __forceinline__ void load_row32(const uint32_t *__restrict__ row32, uint32_t node, uint32_t &start,
+                                           uint32_t &deg)
+{
+    const uint32_t a = row32[node];
+    const uint32_t b = row32[node + 1];
+    start = a;
+    deg = b >= a ? b - a : 0u;
+}
+
+// ---------------------------------------------------------------------------
+// Uniform walk, reference-exact draws (uniform_walk, rw_cpu.cpp:58-107)
+// ---------------------------------------------------------------------------
+// Lane l owns walkers [l*G, l*G+G): G*L consecutive words of the glibc stream,
+// produced in registers (one add per draw on a statically indexed 31-word
+// window, loop unrolled by the generator order).  Column k = g*(L+1)+s of the
+// lane goes to stage[k*nlanes + l]: the 64 lanes of a wave store 256 contiguous
+// bytes.  A step is two dependent gathers: row32[v],row32[v+1] then col32[...].
+__global__ void __launch_bounds__(kBlock)
+uniform_glibc_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32,
+                     const int64_t *__restrict__ targets, int64_t n_nodes, int64_t n_walkers, int32_t L, int32_t G,
+                     int64_t nlanes, const uint32_t *__restrict__ win, uint32_t *__restrict__ stage,
+                     int64_t *__restrict__ status)
+{
+    const int64_t lane = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (lane == 0) {
+        status[2] = TRW_RNG_GLIBC;
+        status[3] = 1;
+    }
+    if (lane >= nlanes) return;
+
+    uint32_t w[kGlDeg];
+#pragma unroll
+    for (int j = 0; j < kGlDeg; ++j) w[j] = win[(int64_t)j * nlanes + lane];
+
+    uint32_t st = 0;
+    int64_t walker = lane * G;
+    int32_t s = 0;  // next column of the current walker; 0 = start a new walker
+    uint32_t cur = 0;
+    uint32_t *sp = stage + lane;  // advances by nlanes per column written
+    bool live = false, mine = false;
+    const int32_t total = G * L;
+
+    auto step = [&](uint32_t r) {
+        if (s == 0) {  // wave-uniform: every lane starts its next walker together
+            mine = walker < n_walkers;
+            live = mine;
+            if (mine) {
+                const int64_t tg = targets[walker];
+                if ((uint64_t)tg >= (uint64_t)n_nodes) {  // reported; transpose_rows_kernel fills the row
+                    st |= TRW_ST_NODE_RANGE;
+                    live = false;
+                }
+                cur = (uint32_t)tg;
+                *sp = cur;
+            }
+            sp += nlanes;
+            s = 1;
+        }
+        if (live) {
+            uint32_t start, deg;
+            load_row32(row32, cur, start, deg);
+            if (deg == 0) {
+                st |= TRW_ST_DEGREE0;  // rw_cpu.cpp:20 divides by zero here
+            } else {
+                cur = col32[start + r % deg];
+            }
+        }
+        if (mine) *sp = cur;
+        sp += nlanes;
+        if (++s > L) {
+            s = 0;
+            ++walker;
+        }
+    };
+    int32_t d0 = 0;
+    for (; d0 + kGlDeg <= total; d0 += kGlDeg) {
+#pragma unroll
+        for (int j = 0; j < kGlDeg; ++j) {
+            const uint32_t v = w[j] + w[(j + kGlDeg - kGlSep) % kGlDeg];
+            w[j] = v;
+            step(v >> 1);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kGlDeg - 1; ++j) {
+        if (d0 + j < total) {  // wave-uniform tail
+            const uint32_t v = w[j] + w[(j + kGlDeg - kGlSep) % kGlDeg];
+            w[j] = v;
+            step(v >> 1);
+        }
+    }
+    if (st) atomicOr((unsigned long long *)&status[0], (unsigned long long)st);
+}
+
+// ---------------------------------------------------------------------------
+// Staging planes -> [N, L+1] int64 rows
+// ---------------------------------------------------------------------------
+// Walker i = lane*G + g keeps column c at stage[(g*(L+1)+c)*nlanes + lane].  A
+// block moves 64 lanes x one g: planes are read 256 bytes per wave, rows are
+// written 512 bytes per wave, through a padded LDS tile (conflict-free both ways).
+__global__ void __launch_bounds__(kBlock)
+transpose_rows_kernel(const uint32_t *__restrict__ stage, const int64_t *__restrict__ targets, int64_t n_nodes,
+                      int64_t n_walkers, int32_t L, int32_t G, int64_t nlanes, int64_t *__restrict__ out)
+{
+    __shared__ uint32_t tile[64][65];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t lane0 = (int64_t)blockIdx.x * 64;
+    const int32_t g = blockIdx.y;
+    const int32_t cols = L + 1;
+    for (int32_t c0 = 0; c0 < cols; c0 += 64) {
+        const int32_t nc = cols - c0 < 64 ? cols - c0 : 64;
+        for (int32_t cc = wave; cc < nc; cc += 4) {
+            const int64_t l = lane0 + lane;
+            tile[cc][lane] = l < nlanes ? stage[((int64_t)g * cols + c0 + cc) * nlanes + l] : 0u;
+        }
+        __syncthreads();
+        for (int32_t r = wave; r < 64; r += 4) {
+            const int64_t i = (lane0 + r) * G + g;
+            if (lane0 + r < nlanes && i < n_walkers && lane < nc) {
+                const int64_t tg = targets[i];
+                const bool dead = (uint64_t)tg >= (uint64_t)n_nodes;  // reported by the walk kernel
+                out[i * cols + c0 + lane] = dead ? tg : (int64_t)tile[lane][r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Biased (node2vec) walk on the per-walker stream (biased_walk, rw_cpu.cpp:109-201)
+// ---------------------------------------------------------------------------
+
+// n % d for many n and one d: LLVM's exact 32-bit expansion with the
+// reciprocal hoisted out (one Newton step on v_rcp_f32, two corrections).
+struct FastMod {
+    uint32_t d, z;
+    __device__ __forceinline__ void init(uint32_t den)
+    {
+        d = den;
+        z = (uint32_t)(__builtin_amdgcn_rcpf((float)den) * 4294966784.0f);  // 0x4f7ffffe
+        z += __umulhi(z, (0u - den) * z);
+    }
+    __device__ __forceinline__ uint32_t mod(uint32_t x) const
+    {
+        uint32_t r = x - __umulhi(x, z) * d;
+        if (r >= d) r -= d;
+        if (r >= d) r -= d;
+        return r;
+    }
+};
+
+// First offset in [0, n) whose entry is >= x (n if none); rows sorted ascending.
+__device__ __forceinline__ uint32_t lower_bound32(const uint32_t *__restrict__ col32, uint32_t start, uint32_t n,
+                                                  uint32_t x, uint32_t &probes)
+{
+    uint32_t lo = 0;
+    while (n > 0) {
+        const uint32_t half = n >> 1;
+        const uint32_t v = col32[start + lo + half];
+        ++probes;
+        if (v < x) {
+            lo += half + 1;
+            n -= half + 1;
+        } else {
+            n = half;
+        }
+    }
+    return lo;
+}
+
+// is_neighbor(x, t) (rw_cpu.cpp:32-56): does t's row contain x?
+template <bool kSorted>
+__device__ __forceinline__ bool row_contains32(const uint32_t *__restrict__ col32, uint32_t start, uint32_t deg,
+                                               uint32_t x, uint32_t &probes)
+{
+    if (kSorted) {
+        const uint32_t lo = lower_bound32(col32, start, deg, x, probes);
+        if (lo >= deg) return false;
+        ++probes;
+        return col32[start + lo] == x;
+    }
+    for (uint32_t e = 0; e < deg; ++e) {
+        ++probes;
+        if (col32[start + e] == x) return true;
+    }
+    return false;
+}
+
+struct BiasedParams {
+    uint32_t t0, t1, t2;  // accept iff draw < t_k, k = distance class of the candidate (0: back to t,
+                          // 1: neighbour of t, 2: neither) -- the reference's fp64 compares as integers
+    uint32_t lo, hi;      // min(t1,t2), max(t1,t2)
+};
+
+// One walker per lane.  Draw 0 picks the first neighbour; trial k of the
+// rejection loop consumes draws 2k+1 (candidate index) and 2k+2 (acceptance),
+// both always and in that order (rw_cpu.cpp:168-169), so the outcome of every
+// trial is fixed by the stream -- but most trials can be DECIDED without
+// reading the graph:
+//   * draw >= hi: no candidate other than t itself could be accepted.  With
+//     sorted rows the offsets at which t sits in prev's row are known per step
+//     (one bisection when the step starts, kPos), so the trial is decided from
+//     the candidate's offset alone: no load.
+//   * lo <= draw < hi is the only band in which is_neighbor() matters; below lo
+//     every candidate is accepted, so the membership test is skipped there.
+// Lanes advance through their own steps independently (a lane that accepts
+// early starts its next step at once); columns go to stage[s*n_walkers + i].
+template <bool kSorted, bool kPos, bool kCount>
+__device__ __forceinline__ void biased_walk_lane(const uint32_t *__restrict__ row32,
+                                                 const uint32_t *__restrict__ col32, uint32_t target, int64_t i,
+                                                 int64_t n_walkers, uint64_t gw, int32_t L, uint32_t seed,
+                                                 const BiasedParams &bp, uint32_t *__restrict__ stage, uint32_t &st,
+                                                 uint32_t &n_trials, uint32_t &n_fetch, uint32_t &n_tests,
+                                                 uint32_t &n_probes)
+{
+    uint32_t blk[4];
+    uint32_t bi = 0;
+    walker_block(gw, bi, seed, blk);
+
+    // step 1: uniform neighbour of the start node (rw_cpu.cpp:159)
+    uint32_t t = target, t_start, t_deg;
+    load_row32(row32, t, t_start, t_deg);
+    uint32_t prev = t;
+    if (t_deg == 0) st |= TRW_ST_DEGREE0;
+    else prev = col32[t_start + (blk[0] >> 1) % t_deg];
+    uint32_t *sp = stage + n_walkers + i;  // column 1
+    *sp = prev;
+    sp += n_walkers;
+
+    uint32_t p_start, p_deg;
+    load_row32(row32, prev, p_start, p_deg);
+    FastMod fm;
+    uint32_t pos_lo = 0, pos_hi = 0;  // offsets of t inside prev's row: [pos_lo, pos_hi)
+    auto enter_step = [&]() {
+        if (p_deg == 0) return;
+        fm.init(p_deg);
+        if (kPos) {
+            pos_lo = lower_bound32(col32, p_start, p_deg, t, n_probes);
+            pos_hi = pos_lo;
+            while (pos_hi < p_deg && (++n_probes, col32[p_start + pos_hi] == t)) ++pos_hi;
+        }
+    };
+    enter_step();
+
+    int32_t s = 2;
+    uint32_t rejected = 0;
+    bool odd = false;  // which half of the Philox block the next trial draws from
+    while (s <= L) {
+        uint32_t rc, ru;
+        if (!odd) {
+            rc = blk[1] >> 1;
+            ru = blk[2] >> 1;
+        } else {
+            rc = blk[3] >> 1;
+            walker_block(gw, ++bi, seed, blk);
+            ru = blk[0] >> 1;
+        }
+        odd = !odd;
+        if (kCount) ++n_trials;
+
+        bool accept;
+        uint32_t x;
+        if (p_deg == 0) {  // dead end: reported, the walker stays (the reference divides by zero)
+            st |= TRW_ST_DEGREE0;
+            x = prev;
+            accept = true;
+        } else {
+            const uint32_t idx = fm.mod(rc);
+            if (kPos && ru >= bp.hi) {
+                x = t;
+                accept = ru < bp.t0 && idx >= pos_lo && idx < pos_hi;
+            } else {
+                x = col32[p_start + idx];
+                if (kCount) ++n_fetch;
+                if (x == t) accept = ru < bp.t0;
+                else if (ru < bp.lo) accept = true;
+                else if (ru >= bp.hi) accept = false;
+                else {
+                    if (kCount) ++n_tests;
+                    accept = ru < (row_contains32<kSorted>(col32, t_start, t_deg, x, n_probes) ? bp.t1 : bp.t2);
+                }
+            }
+        }
+        if (!accept && ++rejected >= kTrialCap) {
+            st |= (uint32_t)kStTrialCap;
+            if (kPos && ru >= bp.hi) x = col32[p_start + fm.mod(rc)];
+            accept = true;
+        }
+        if (accept) {
+            *sp = x;
+            sp += n_walkers;
+            t = prev;
+            t_start = p_start;
+            t_deg = p_deg;
+            prev = x;
+            ++s;
+            rejected = 0;
+            if (s <= L) {
+                load_row32(row32, prev, p_start, p_deg);
+                enter_step();
+            }
+        }
+    }
+}
+
+template <bool kPos, bool kCount>
+__global__ void __launch_bounds__(kBlock)
+biased_walker_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32,
+                     const int64_t *__restrict__ targets, int64_t n_nodes, int64_t n_walkers, int64_t walker_base,
+                     int32_t L, uint32_t seed, BiasedParams bp, uint32_t *__restrict__ stage,
+                     int64_t *__restrict__ status)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i == 0) {
+        status[2] = TRW_RNG_WALKER;
+        status[3] = 1;
+    }
+    const bool sorted = status[kStDescents] == status[kStBoundary];
+    uint32_t st = 0;
+    uint32_t n_trials = 0, n_fetch = 0, n_tests = 0, n_probes = 0;
+    if (i < n_walkers) {
+        const int64_t tg = targets[i];
+        stage[i] = (uint32_t)tg;  // column 0
+        if ((uint64_t)tg >= (uint64_t)n_nodes) {
+            st |= TRW_ST_NODE_RANGE;  // transpose_rows_kernel fills the row with the bad id
+        } else {
+            const uint64_t gw = (uint64_t)walker_base + (uint64_t)i;
+            if (sorted)
+                biased_walk_lane<true, kPos, kCount>(row32, col32, (uint32_t)tg, i, n_walkers, gw, L, seed, bp, stage,
+                                                     st, n_trials, n_fetch, n_tests, n_probes);
+            else
+                biased_walk_lane<false, false, kCount>(row32, col32, (uint32_t)tg, i, n_walkers, gw, L, seed, bp,
+                                                       stage, st, n_trials, n_fetch, n_tests, n_probes);
+        }
+    }
+    if (st) atomicOr((unsigned long long *)&status[0], (unsigned long long)st);
+    if (kCount) {  // whole waves reach this point together
+        const uint64_t a = wave_sum(n_trials), b = wave_sum(n_fetch), c = wave_sum(n_tests), d = wave_sum(n_probes);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd((unsigned long long *)&status[4], (unsigned long long)a);
+            atomicAdd((unsigned long long *)&status[5], (unsigned long long)b);
+            atomicAdd((unsigned long long *)&status[6], (unsigned long long)c);
+            atomicAdd((unsigned long long *)&status[7], (unsigned long long)d);
+        }
+    }
+}
+
+}  // namespace
