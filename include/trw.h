@@ -121,7 +121,7 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes,
  * status[1] = 1 if some CSR row was found unsorted (biased walks only; the
  * membership test then scans linearly like rw_cpu.cpp:32-56 instead of
  * bisecting), status[2] = the RNG mode that ran (TRW_RNG_GLIBC/WALKER),
- * status[3] = 1 if the uint32-shadow kernels ran, 0 for the int64 kernels.  Returns TRW_OK or TRW_E_HIP. */
+ * status[3] = 0 int64 kernels, 1 uint32-shadow kernels, 2 shadow + edge hash table.  Returns TRW_OK or TRW_E_HIP. */
 int trw_walk_status(const void *workspace, void *hip_stream, int64_t status[4]);
 
 /* Integer form of the reference's accept test (rw_cpu.cpp:169-194):

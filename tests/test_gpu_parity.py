@@ -134,7 +134,9 @@ def test_biased_walker_hub_graph_L80(rw):
     assert (got == ref).all()
 
 
-def test_biased_walker_unsorted_rows_take_the_scan_path(rw):
+@pytest.mark.parametrize("hash_path", ["0", "1"])
+def test_biased_walker_unsorted_rows_take_the_scan_path(rw, hash_path, monkeypatch):
+    monkeypatch.setenv("TRW_HASH", hash_path)
     rp, ci = random_graph(300, 5, 41, sort_rows=False)
     assert any((np.diff(ci[rp[v]:rp[v + 1]]) < 0).any() for v in range(300))
     tg = np.arange(300)
@@ -197,7 +199,9 @@ def test_edge_cases(rw):
             == O.walk(rp, ci, [3, 4, 5], 0.5, 2.0, 1, 1, rng_mode=O.RNG_WALKER)).all()
 
 
-def test_errors_are_python_exceptions(rw):
+@pytest.mark.parametrize("hash_path", ["0", "1"])
+def test_errors_are_python_exceptions(rw, hash_path, monkeypatch):
+    monkeypatch.setenv("TRW_HASH", hash_path)
     rp, ci = random_graph(50, 3, 81)
     d_rp, d_ci, d_tg = _dev(rp, ci, np.arange(50))
     with pytest.raises(RuntimeError, match="expected scalar type Long"):
@@ -251,13 +255,20 @@ def test_c_abi_direct_call(rw):
         assert rc == 0, L.trw_last_error()
         st = (ctypes.c_int64 * 4)()
         assert L.trw_walk_status(ws.data_ptr(), stream, st) == 0
-        assert st[0] == 0 and st[2] == mode and st[3] == 1
+        assert st[0] == 0 and st[2] == mode and st[3] in (1, 2)   # 1: uint32-shadow kernels, 2: + edge table
         assert (out.cpu().numpy() == O.walk(rp, ci, tg, p, q, 40, 10, rng_mode=omode)).all()
 
 
-@pytest.mark.parametrize("env", [{"TRW_FORCE_WIDE": "1"}, {"TRW_NO_POS": "1"}, {}])
+VARIANTS = [{"TRW_FORCE_WIDE": "1"},                      # int64 kernels
+            {"TRW_HASH": "0"},                           # bisection kernel, located-t shortcut
+            {"TRW_HASH": "0", "TRW_NO_POS": "1"},        # bisection kernel, every candidate loaded
+            {"TRW_HASH": "1"},                           # edge table + state machine
+            {"TRW_HASH": "1", "TRW_NO_POS": "1"}]
+
+
+@pytest.mark.parametrize("env", VARIANTS)
 def test_kernel_variants_agree(rw, env, monkeypatch):
-    """The int64 kernels, the narrow kernels with and without the located-t shortcut: same walks."""
+    """Every kernel variant of the biased walk (and the uniform walk beside it): same walks."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     rp, ci = hub_graph(600, 12)
@@ -275,8 +286,10 @@ def test_kernel_variants_agree(rw, env, monkeypatch):
     assert (_hip(rw, rp2, ci2, tg2, 0.25, 4.0, 20, 5, rng_mode=rw.RNG_WALKER) == ref).all()
 
 
-def test_work_counters(rw):
+@pytest.mark.parametrize("hash_path", ["0", "1"])
+def test_work_counters(rw, hash_path, monkeypatch):
     """The counting variant of the biased kernel: same walks, trial count equal to the oracle's."""
+    monkeypatch.setenv("TRW_HASH", hash_path)
     from torch_random_walk_amd import _native
     L = _native.cabi()
     rp, ci = hub_graph(500, 14)

@@ -106,7 +106,9 @@ struct Plan {
     bool windows = false;  // glibc jump-ahead windows needed
     int32_t G = 1;         // walkers chained per lane (uniform glibc)
     int64_t nlanes = 0;
-    size_t off_win = 0, off_row32 = 0, off_col32 = 0, off_stage = 0, total = 0;
+    bool hash = false;     // biased: edge hash table + state-machine kernel
+    uint32_t hash_mask = 0;
+    size_t off_win = 0, off_row32 = 0, off_col32 = 0, off_stage = 0, off_table = 0, total = 0;
 };
 
 Plan make_plan(int64_t n_nodes, int64_t nnz, int64_t n_walkers, int32_t L, bool uniform, int32_t rng_mode)
@@ -132,11 +134,25 @@ Plan make_plan(int64_t n_nodes, int64_t nnz, int64_t n_walkers, int32_t L, bool 
     pl.narrow = fits && ((uniform && may_glibc) || (!uniform && may_walker));
     if (pl.narrow) {
         pl.off_row32 = off;
-        off += align_up((size_t)(n_nodes + 1) * sizeof(uint32_t), 256);
+        off += align_up((size_t)(n_nodes + 1 + 4) * sizeof(uint32_t), 256);  // +4: 16-byte gathers at the last node
         pl.off_col32 = off;
         off += align_up((size_t)nnz * sizeof(uint32_t) + 64, 256);
         pl.off_stage = off;
         off += align_up((size_t)pl.nlanes * pl.G * (size_t)(L + 1) * sizeof(uint32_t), 256);
+        // The edge table costs one pass over the graph per call, so it is built when the batch
+        // is going to make more membership queries than the graph has edges (TRW_HASH=0/1 forces).
+        if (!uniform) {
+            uint64_t cap = 1024;
+            while (cap < 2 * (uint64_t)nnz) cap <<= 1;
+            const long forced = env_long("TRW_HASH", 0, 1, -1);
+            const bool worth = (__int128)n_walkers * L >= (__int128)nnz / 4;
+            if (cap <= ((uint64_t)1 << 31) && (forced == 1 || (forced == -1 && worth))) {
+                pl.hash = true;
+                pl.hash_mask = (uint32_t)(cap - 1);
+                pl.off_table = off;
+                off += (size_t)cap * 16;
+            }
+        }
     }
     pl.total = off;
     return pl;
@@ -158,6 +174,19 @@ void prof_mark(int k, hipStream_t stream)
     if (!g_prof.ev[k] && hipEventCreate(&g_prof.ev[k]) != hipSuccess) return;
     (void)hipEventRecord(g_prof.ev[k], stream);
     if (k == 3) g_prof.valid = true;
+}
+
+int device_cu_count()
+{
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cus[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cus[dev] = v;
+    }
+    return cus[dev];
 }
 
 unsigned stream_grid(int64_t items)
@@ -249,6 +278,7 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col
     uint32_t *row32 = (uint32_t *)(ws + pl.off_row32);
     uint32_t *col32 = (uint32_t *)(ws + pl.off_col32);
     uint32_t *stage = (uint32_t *)(ws + pl.off_stage);
+    uint32_t *table = (uint32_t *)(ws + pl.off_table);
     const int64_t L = walk_length;
     const unsigned walker_grid = (unsigned)((n_walkers + kBlock - 1) / kBlock);
 
@@ -265,6 +295,12 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col
         else
             csr_shadow_kernel<true><<<grid, kBlock, 0, stream>>>(row_ptr, col_idx, n_nodes, nnz, row32, col32,
                                                                  status);
+    }
+    if (pl.narrow && pl.hash && mode == TRW_RNG_WALKER) {
+        e = hipMemsetAsync(table, 0xFF, ((size_t)pl.hash_mask + 1) * 16, stream);
+        if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(edge table)");
+        edge_table_build_kernel<<<stream_grid(nnz), kBlock, 0, stream>>>(row32, col32, n_nodes, nnz, table,
+                                                                       pl.hash_mask);
     }
     const unsigned lane_grid = (unsigned)((pl.nlanes + kBlock - 1) / kBlock);
     if (uniform && mode == TRW_RNG_GLIBC) {
@@ -290,7 +326,8 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col
         bp.hi = th.t1 < th.t2 ? th.t2 : th.t1;
         // Locating t inside prev's row once per step pays when at least half of the trials draw
         // above `hi` (and can then be decided from the candidate's offset alone).
-        use_pos = bp.t0 > bp.hi && bp.hi <= (1u << 30) && env_long("TRW_NO_POS", 0, 1, 0) == 0;
+        // (With the edge table the location costs one probe, so any share of such draws pays.)
+        use_pos = bp.t0 > bp.hi && (pl.hash || bp.hi <= (1u << 30)) && env_long("TRW_NO_POS", 0, 1, 0) == 0;
         if (!pl.narrow && n_nodes > 0) {
             int64_t blocks = (n_nodes + kBlock - 1) / kBlock;
             if (blocks > 256 * 16) blocks = 256 * 16;
@@ -320,6 +357,19 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col
         trw::seed_window(seed, sw.w);
         biased_glibc_seq_kernel<<<1, 64, 0, stream>>>(row_ptr, col_idx, targets, n_nodes, nnz, n_walkers,
                                                      walk_length, sw, th, out, status);
+    } else if (pl.narrow && pl.hash) {
+        // persistent lanes: walkers are dealt out by a device counter (status[kStNextWalker])
+        int64_t blocks = (n_walkers + kBlock - 1) / kBlock;
+        const int64_t resident = (int64_t)device_cu_count() * 8;
+        if (blocks > resident) blocks = resident;
+        if (g_prof.count)
+            biased_hash_kernel<true><<<(unsigned)blocks, kBlock, 0, stream>>>(
+                row32, col32, table, pl.hash_mask, targets, n_nodes, n_walkers, walker_base, walk_length,
+                (uint32_t)seed, bp, use_pos ? 1 : 0, stage, status);
+        else
+            biased_hash_kernel<false><<<(unsigned)blocks, kBlock, 0, stream>>>(
+                row32, col32, table, pl.hash_mask, targets, n_nodes, n_walkers, walker_base, walk_length,
+                (uint32_t)seed, bp, use_pos ? 1 : 0, stage, status);
     } else if (pl.narrow) {
 #define TRW_LAUNCH_BIASED(POS, COUNT)                                                                          \
     biased_walker_kernel<POS, COUNT><<<walker_grid, kBlock, 0, stream>>>(                                      \

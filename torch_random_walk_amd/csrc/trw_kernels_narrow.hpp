@@ -70,13 +70,16 @@ csr_shadow_kernel(const int64_t *__restrict__ row_ptr, const int64_t *__restrict
 
 // The row of `node` in the shadow.  row32 is clamped to [0, nnz]; a non-monotone
 // pair (already reported by csr_shadow_kernel) reads as an empty row.
+// Both offsets come back from ONE 8-byte gather (4-byte aligned global_load_dwordx2):
+// a divergent load costs the memory pipeline per lane-request, not per byte.
+typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+
 __device__ __forceinline__ void load_row32(const uint32_t *__restrict__ row32, uint32_t node, uint32_t &start,
                                            uint32_t &deg)
 {
-    const uint32_t a = row32[node];
-    const uint32_t b = row32[node + 1];
-    start = a;
-    deg = b >= a ? b - a : 0u;
+    const u32x2_a4 ab = *reinterpret_cast<const u32x2_a4 *>(row32 + node);
+    start = ab.x;
+    deg = ab.y >= ab.x ? ab.y - ab.x : 0u;
 }
 
 // ---------------------------------------------------------------------------
@@ -410,6 +413,320 @@ biased_walker_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restr
     if (kCount) {  // whole waves reach this point together
         const uint64_t a = wave_sum(n_trials), b = wave_sum(n_fetch), c = wave_sum(n_tests), d = wave_sum(n_probes);
         if ((threadIdx.x & 63) == 0) {
+            atomicAdd((unsigned long long *)&status[4], (unsigned long long)a);
+            atomicAdd((unsigned long long *)&status[5], (unsigned long long)b);
+            atomicAdd((unsigned long long *)&status[6], (unsigned long long)c);
+            atomicAdd((unsigned long long *)&status[7], (unsigned long long)d);
+        }
+    }
+}
+
+
+// ===========================================================================
+// Biased walk, large batches: edge hash table + per-lane state machine
+// ===========================================================================
+// Profiles of biased_walker_kernel (profiles/r01_*): ~40 dependent gathers per
+// step (two bisections of ~10 probes each dominate), VALU lanes 19 % busy because
+// a wave runs every branch of the trial for whichever lanes need it, and the
+// whole wave idles behind its slowest lane.  This path removes all three:
+//   * edge_table_build_kernel hashes every edge (u,v) once per call into an
+//     open-addressing table {u, v, first offset of v in u's row, multiplicity}.
+//     "is x a neighbour of t" and "where does t sit in prev's row" become ONE
+//     16-byte gather each (expected 1.2 probes at load factor <= 0.5) instead of
+//     a bisection.  It is an exact set, so every answer is the reference's.
+//   * biased_hash_kernel runs each lane as a small state machine that issues at
+//     most ONE 16-byte gather per loop iteration, whatever it is for (row
+//     offsets, hash slot, candidate entry): all lanes of a wave keep a request
+//     in flight every iteration instead of taking turns through nested loops.
+//   * lanes that finish a walk fetch the next walker index from a device
+//     counter, so no lane waits for the slowest walk of its wave.
+// Results are identical to biased_walker_kernel (same stream, same decisions).
+
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+constexpr int kStNextWalker = 10;  // status slot: next unassigned walker (dynamic distribution)
+
+__device__ __forceinline__ uint32_t edge_hash(uint32_t u, uint32_t v)
+{
+    uint32_t h = u * 0x9E3779B1u ^ (v * 0x85EBCA77u + 0x165667B1u);
+    h ^= h >> 16;
+    h *= 0x7FEB352Du;
+    h ^= h >> 15;
+    h *= 0x846CA68Bu;
+    h ^= h >> 16;
+    return h;
+}
+
+// table: `mask`+1 slots of {u, v, lo, cnt-1}, all bytes 0xFF when empty.
+__global__ void __launch_bounds__(kBlock)
+edge_table_build_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32, int64_t n_nodes,
+                        int64_t nnz, uint32_t *__restrict__ table, uint32_t mask)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < nnz; e += stride) {
+        // the row that holds entry e: last u with row32[u] <= e (neighbouring lanes walk the same path)
+        uint32_t lo = 0, n = (uint32_t)n_nodes;
+        while (n > 1) {
+            const uint32_t half = n >> 1;
+            if (row32[lo + half] <= (uint32_t)e) {
+                lo += half;
+                n -= half;
+            } else {
+                n = half;
+            }
+        }
+        const uint32_t u = lo;
+        const uint32_t v = col32[e];
+        const uint32_t off = (uint32_t)e - row32[u];
+        const unsigned long long key = ((unsigned long long)v << 32) | u;
+        uint32_t slot = edge_hash(u, v) & mask;
+        while (true) {
+            unsigned long long *kp = (unsigned long long *)(table + 4 * (size_t)slot);
+            const unsigned long long old = atomicCAS(kp, ~0ull, key);
+            if (old == ~0ull || old == key) {
+                atomicMin(table + 4 * (size_t)slot + 2, off);
+                atomicAdd(table + 4 * (size_t)slot + 3, 1u);  // 0xFFFFFFFF + k = k - 1
+                break;
+            }
+            slot = (slot + 1) & mask;
+        }
+    }
+}
+
+enum : uint32_t { LS_IDLE = 0, LS_START, LS_ROW, LS_POS, LS_TRIAL, LS_CAND, LS_MEMBER };
+
+template <bool kCount>
+__global__ void __launch_bounds__(kBlock)
+biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32,
+                   const uint32_t *__restrict__ table, uint32_t mask, const int64_t *__restrict__ targets,
+                   int64_t n_nodes, int64_t n_walkers, int64_t walker_base, int32_t L, uint32_t seed,
+                   BiasedParams bp, int32_t want_pos, uint32_t *__restrict__ stage, int64_t *__restrict__ status)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        status[2] = TRW_RNG_WALKER;
+        status[3] = 2;
+    }
+    // offsets of t inside prev's row are contiguous only when rows are sorted
+    const bool use_pos = want_pos && status[kStDescents] == status[kStBoundary];
+    const int lane = threadIdx.x & 63;
+
+    uint32_t st = 0;
+    uint32_t n_trials = 0, n_fetch = 0, n_tests = 0, n_probes = 0;
+
+    uint32_t state = LS_START;
+    int64_t walker = 0;
+    uint64_t gw = 0;
+    int32_t s = 0;
+    uint32_t t = 0, prev = 0, t_start = 0, t_deg = 0, p_start = 0, p_deg = 0;
+    uint32_t pos_lo = 0, pos_cnt = 0;
+    FastMod fm;
+    fm.d = 1;
+    fm.z = 0;
+    uint32_t blk[4] = {0, 0, 0, 0};
+    uint32_t bi = 0;
+    bool odd = false;
+    uint32_t slot = 0, x = 0, ru = 0, rejected = 0;
+    const uint32_t *addr = row32;
+    uint32_t *sp = stage;
+
+    // after a candidate has been accepted: emit it and move on to the next step
+    auto accept_candidate = [&](uint32_t cand, bool row_known) {
+        *sp = cand;
+        sp += n_walkers;
+        ++s;
+        rejected = 0;
+        if (s > L) {
+            state = LS_START;
+            return;
+        }
+        if (row_known && t_deg != 0) {  // cand == t: its row is the one we came through two steps ago
+            const uint32_t ts = t_start, td = t_deg;
+            t_start = p_start;
+            t_deg = p_deg;
+            p_start = ts;
+            p_deg = td;
+            const uint32_t tt = t;
+            t = prev;
+            prev = tt;
+            fm.init(p_deg);
+            if (use_pos) {
+                slot = edge_hash(prev, t) & mask;
+                addr = table + 4 * (size_t)slot;
+                state = LS_POS;
+            } else {
+                state = LS_TRIAL;
+            }
+        } else {
+            t = prev;
+            t_start = p_start;
+            t_deg = p_deg;
+            prev = cand;
+            addr = row32 + prev;
+            state = LS_ROW;
+        }
+    };
+
+    while (true) {
+        // ---- hand out walkers to the lanes that need one (wave-level, one atomic per wave) ----
+        const unsigned long long need = __ballot(state == LS_START);
+        if (need) {
+            long long base = 0;
+            if (lane == (int)__ffsll((long long)need) - 1)
+                base = (long long)atomicAdd((unsigned long long *)&status[kStNextWalker],
+                                            (unsigned long long)__popcll(need));
+            base = __shfl(base, (int)__ffsll((long long)need) - 1);
+            if (state == LS_START) {
+                walker = base + __popcll(need & ((1ull << lane) - 1ull));
+                if (walker >= n_walkers) {
+                    state = LS_IDLE;
+                } else {
+                    const int64_t tg = targets[walker];
+                    stage[walker] = (uint32_t)tg;  // column 0
+                    sp = stage + n_walkers + walker;
+                    if ((uint64_t)tg >= (uint64_t)n_nodes) {
+                        st |= TRW_ST_NODE_RANGE;  // transpose_rows_kernel fills the row with the bad id
+                    } else {
+                        gw = (uint64_t)walker_base + (uint64_t)walker;
+                        bi = 0;
+                        odd = false;
+                        walker_block(gw, 0, seed, blk);
+                        s = 1;
+                        rejected = 0;
+                        prev = (uint32_t)tg;  // step 1 leaves the start node
+                        t = prev;
+                        addr = row32 + prev;
+                        state = LS_ROW;
+                    }
+                }
+            }
+        }
+        if (__ballot(state != LS_IDLE) == 0) break;
+
+        // ---- the one gather of this iteration ----
+        u32x4_a4 g = {0u, 0u, 0u, 0u};
+        const bool loads = state == LS_ROW || state == LS_POS || state == LS_CAND || state == LS_MEMBER;
+        if (loads) g = *reinterpret_cast<const u32x4_a4 *>(addr);
+
+        // ---- consume it ----
+        if (state == LS_ROW) {  // g = row32[prev], row32[prev+1], ...
+            p_start = g.x;
+            p_deg = g.y >= g.x ? g.y - g.x : 0u;
+            if (p_deg == 0) {  // dead end: reported, the walker stays (the reference divides by zero)
+                st |= TRW_ST_DEGREE0;
+                accept_candidate(prev, false);
+            } else if (s == 1) {  // first step: plain uniform neighbour, draw 0 (rw_cpu.cpp:159)
+                x = p_start + (blk[0] >> 1) % p_deg;
+                addr = col32 + x;
+                ru = 0;
+                state = LS_CAND;
+            } else {
+                fm.init(p_deg);
+                if (use_pos) {
+                    slot = edge_hash(prev, t) & mask;
+                    addr = table + 4 * (size_t)slot;
+                    state = LS_POS;
+                } else {
+                    state = LS_TRIAL;
+                }
+            }
+        } else if (state == LS_POS) {  // g = {u, v, lo, cnt-1} of one slot
+            if (kCount) ++n_probes;
+            if (g.x == 0xFFFFFFFFu) {
+                pos_lo = 0;
+                pos_cnt = 0;
+                state = LS_TRIAL;
+            } else if (g.x == prev && g.y == t) {
+                pos_lo = g.z;
+                pos_cnt = g.w + 1u;
+                state = LS_TRIAL;
+            } else {
+                slot = (slot + 1) & mask;
+                addr = table + 4 * (size_t)slot;
+            }
+        } else if (state == LS_CAND) {  // g.x = the candidate node
+            const uint32_t cand = g.x;
+            bool rejected_now = false;
+            if (s == 1) {
+                accept_candidate(cand, false);
+            } else {
+                if (kCount) ++n_fetch;
+                if (cand == t) {
+                    if (ru < bp.t0) accept_candidate(cand, true);
+                    else rejected_now = true;
+                } else if (ru < bp.lo) {
+                    accept_candidate(cand, false);
+                } else if (ru >= bp.hi) {
+                    rejected_now = true;
+                } else {
+                    if (kCount) ++n_tests;
+                    x = cand;
+                    slot = edge_hash(t, cand) & mask;
+                    addr = table + 4 * (size_t)slot;
+                    state = LS_MEMBER;
+                }
+            }
+            if (rejected_now) {
+                state = LS_TRIAL;
+                if (++rejected >= kTrialCap) {
+                    st |= (uint32_t)kStTrialCap;
+                    accept_candidate(cand, false);
+                }
+            }
+        } else if (state == LS_MEMBER) {  // is x in t's row?
+            if (kCount) ++n_probes;
+            bool decided = true, member = false;
+            if (g.x == 0xFFFFFFFFu) member = false;
+            else if (g.x == t && g.y == x) member = true;
+            else decided = false;
+            if (!decided) {
+                slot = (slot + 1) & mask;
+                addr = table + 4 * (size_t)slot;
+            } else if (ru < (member ? bp.t1 : bp.t2)) {
+                accept_candidate(x, false);
+            } else if (++rejected >= kTrialCap) {
+                st |= (uint32_t)kStTrialCap;
+                accept_candidate(x, false);
+            } else {
+                state = LS_TRIAL;
+            }
+        }
+
+        // ---- one rejection trial for every lane that is between gathers ----
+        if (state == LS_TRIAL) {
+            uint32_t rc;
+            if (!odd) {
+                rc = blk[1] >> 1;
+                ru = blk[2] >> 1;
+            } else {
+                rc = blk[3] >> 1;
+                walker_block(gw, ++bi, seed, blk);
+                ru = blk[0] >> 1;
+            }
+            odd = !odd;
+            if (kCount) ++n_trials;
+            const uint32_t idx = fm.mod(rc);
+            if (use_pos && ru >= bp.hi) {
+                // no candidate but t itself can pass this draw; t sits at offsets [pos_lo, pos_lo+pos_cnt)
+                if (ru < bp.t0 && idx - pos_lo < pos_cnt) {
+                    accept_candidate(t, true);
+                } else if (++rejected >= kTrialCap) {
+                    st |= (uint32_t)kStTrialCap;
+                    addr = col32 + p_start + idx;  // take whatever this trial drew
+                    ru = 0;
+                    rejected = 0;
+                    state = LS_CAND;
+                }
+            } else {
+                addr = col32 + p_start + idx;
+                state = LS_CAND;
+            }
+        }
+    }
+
+    if (st) atomicOr((unsigned long long *)&status[0], (unsigned long long)st);
+    if (kCount) {
+        const uint64_t a = wave_sum(n_trials), b = wave_sum(n_fetch), c = wave_sum(n_tests), d = wave_sum(n_probes);
+        if (lane == 0) {
             atomicAdd((unsigned long long *)&status[4], (unsigned long long)a);
             atomicAdd((unsigned long long *)&status[5], (unsigned long long)b);
             atomicAdd((unsigned long long *)&status[6], (unsigned long long)c);
