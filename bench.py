@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--graph-seed", type=int, default=1)
     ap.add_argument("--no-gather", action="store_true", help="N>1: leave the row blocks on their ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo is a dry-run aid for the N>1 control flow on a single-GPU box (all ranks share "
+                         "cuda:0 and the gather is staged through host memory); its numbers mean nothing")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     args = ap.parse_args()
 
@@ -71,11 +74,17 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                      % (args.gpus, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    dry = args.backend == "gloo"
+    if dry:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from torch_random_walk_amd import _native, graphs, rw
     from torch_random_walk_amd.dist import shard_bounds  # noqa: F401  (the partition rule this bench follows)
@@ -103,38 +112,52 @@ def main():
     gather = (world > 1) and not args.no_gather
     full = None
     if gather and rank == 0:
-        full = torch.empty((world * B, L + 1), dtype=torch.int64, device=dev)
+        full = torch.empty((world * B, L + 1), dtype=torch.int64, device="cpu" if dry else dev)
 
-    def one_step():
-        walks = rw.walk_ex(row_ptr, col_idx, targets, p, q, L, args.seed, walker_base=walker_base,
-                           rng_mode=mode, check=False)
-        if gather:
-            if rank == 0:
-                dist.gather(walks, list(full.split(B, dim=0)), dst=0)
-            else:
-                dist.gather(walks, None, dst=0)
-        return walks
+    def walk_once():
+        return rw.walk_ex(row_ptr, col_idx, targets, p, q, L, args.seed, walker_base=walker_base,
+                          rng_mode=mode, check=False)
+
+    def gather_async(walks):
+        """The one collective of the path: every rank's [B, L+1] block to rank 0 (RCCL gather)."""
+        if dry:
+            walks = walks.cpu()
+        if rank == 0:
+            return dist.gather(walks, list(full.split(B, dim=0)), dst=0, async_op=True)
+        return dist.gather(walks, None, dst=0, async_op=True)
 
     lib = _native.cabi()
     for _ in range(args.warmup):
-        walks = one_step()
+        walks = walk_once()
+        if gather:
+            gather_async(walks).wait()
     torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps between barriers -------------------------------------
+    # N > 1: the gather of step k rides RCCL's stream while step k+1 walks (the blocks of
+    # successive steps are independent); every gather has completed before the closing barrier.
     lib.trw_profile_enable(1)
     kernel_ms, prepare_ms, finish_ms = [], [], []
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    pending = None
     for _ in range(args.steps):
-        walks = one_step()
+        walks = walk_once()
+        if gather:
+            work = gather_async(walks)
+            if pending is not None:
+                pending.wait()
+            pending = work
         a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         # reading the events of step k waits for that step's kernels; the next step is not queued yet
         if lib.trw_profile_last(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) == 0:
             prepare_ms.append(a.value)
             kernel_ms.append(b.value)
             finish_ms.append(c.value)
+    if pending is not None:
+        pending.wait()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -142,7 +165,7 @@ def main():
     elapsed = time.perf_counter() - t0
     lib.trw_profile_enable(0)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dry else dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -151,6 +174,11 @@ def main():
     chk = rw.walk_ex(row_ptr, col_idx, targets[:1024], p, q, L, args.seed, walker_base=walker_base,
                      rng_mode=mode, check=True)
     assert torch.equal(chk, walks[:1024]), "timed output differs from a checked re-run"
+    if gather and rank == 0:
+        # the gathered blocks are exactly what each rank's global walker indices produce
+        for r in range(world):
+            blk = rw.walk_ex(row_ptr, col_idx, targets[:256], p, q, L, args.seed, walker_base=r * B, rng_mode=mode)
+            assert torch.equal(blk.to(full.device), full[r * B: r * B + 256]), "gathered block %d is wrong" % r
 
     # ---- algorithmic bytes of one launch ----------------------------------------
     counters = None
@@ -236,7 +264,8 @@ def main():
                 "walkers_per_gpu": B, "global_walkers": world * B,
                 "rng": "glibc-indexed (csrc/cpu-exact)" if uniform else "per-walker philox4x32-10",
                 "partition": "start nodes block-sharded, CSR replicated",
-                "collective": "one RCCL gather to rank 0 inside the timed step" if gather else "none",
+                "collective": ("one RCCL gather to rank 0 per step, inside the timed region, overlapped with the "
+                               "next step's walk") if gather else "none",
             },
             "roofline": {
                 "bound": "hbm",

@@ -12,7 +12,8 @@ out = sys.argv[1]
 
 def short(name):
     for k in ("uniform_glibc_kernel", "uniform_walker_kernel", "biased_walker_kernel", "glibc_windows_kernel",
-              "csr_rows_sorted_kernel", "biased_glibc_seq_kernel", "transpose_rows_kernel", "csr_shadow_kernel"):
+              "csr_rows_sorted_kernel", "biased_glibc_seq_kernel", "transpose_rows_kernel", "csr_shadow_kernel",
+              "biased_hash_kernel", "edge_table_build_kernel"):
         if k in name:
             tail = name[name.index(k):]
             return tail.split("(")[0][:44]
@@ -44,7 +45,7 @@ for path in sorted(glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collecti
     with open(path) as f:
         for row in csv.DictReader(f):
             k = short(row["Kernel_Name"])
-            if not any(t in k for t in ("walk", "uniform", "transpose", "csr_", "glibc")):
+            if not any(t in k for t in ("walk", "uniform", "transpose", "csr_", "glibc", "hash", "edge_table")):
                 continue
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k, cs in acc.items():

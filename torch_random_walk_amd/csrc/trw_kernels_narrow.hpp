@@ -90,7 +90,8 @@ __device__ __forceinline__ void load_row32(const uint32_t *__restrict__ row32, u
 // window, loop unrolled by the generator order).  Column k = g*(L+1)+s of the
 // lane goes to stage[k*nlanes + l]: the 64 lanes of a wave store 256 contiguous
 // bytes.  A step is two dependent gathers: row32[v],row32[v+1] then col32[...].
-__global__ void __launch_bounds__(kBlock)
+template <int kMinWaves>  // register budget: 8 waves/SIMD caps the kernel at 64 VGPRs
+__global__ void __launch_bounds__(kBlock, kMinWaves)
 uniform_glibc_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32,
                      const int64_t *__restrict__ targets, int64_t n_nodes, int64_t n_walkers, int32_t L, int32_t G,
                      int64_t nlanes, const uint32_t *__restrict__ win, uint32_t *__restrict__ stage,

@@ -77,13 +77,24 @@ __device__ __forceinline__ void load_row(const int64_t *__restrict__ row_ptr, in
     }
 }
 
+__device__ __forceinline__ void mulhilo32(uint32_t a, uint32_t b, uint32_t &hi, uint32_t &lo)
+{
+    unsigned long long prod, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(prod), "=s"(carry) : "v"(a), "v"(b));
+    hi = (uint32_t)(prod >> 32);
+    lo = (uint32_t)prod;
+}
+
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t (&o)[4])
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one v_mad_u64_u32 yields both halves of a 32x32 product; hipcc would issue a
+        // v_mul_hi_u32 and a v_mul_lo_u32 (both quarter rate) for the same thing
+        uint32_t hi0, lo0, hi1, lo1;
+        mulhilo32(0xD2511F53u, c0, hi0, lo0);
+        mulhilo32(0xCD9E8D57u, c2, hi1, lo1);
         const uint32_t n0 = hi1 ^ c1 ^ k0;
         const uint32_t n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
