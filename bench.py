@@ -196,6 +196,9 @@ def main():
         assert rc == 0, lib.trw_last_error()
         c = (ctypes.c_uint64 * 4)()
         assert lib.trw_walk_counters(ws.data_ptr(), stream, c) == 0
+        stw = (ctypes.c_int64 * 4)()
+        assert lib.trw_walk_status(ws.data_ptr(), stream, stw) == 0
+        biased_kernel = {0: "biased_walker_wide_kernel", 1: "biased_walker_kernel", 2: "biased_hash_kernel"}[int(stw[3])]
         lib.trw_profile_enable(0)
         assert torch.equal(out, walks), "counting variant of the kernel produced different walks"
         trials, fetches, tests, probes = (int(x) for x in c)
@@ -269,7 +272,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "uniform_glibc_kernel" if uniform else "biased_walker_kernel",
+                "kernel": "uniform_glibc_kernel" if uniform else biased_kernel,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
