@@ -300,8 +300,8 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col
     if (pl.narrow && pl.hash && mode == TRW_RNG_WALKER) {
         e = hipMemsetAsync(table, 0xFF, ((size_t)pl.hash_mask + 1) * 16, stream);
         if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(edge table)");
-        edge_table_build_kernel<<<stream_grid(nnz), kBlock, 0, stream>>>(row32, col32, n_nodes, nnz, table,
-                                                                       pl.hash_mask);
+        edge_table_build_kernel<<<stream_grid((nnz + 7) / 8), kBlock, 0, stream>>>(row32, col32, n_nodes, nnz, table,
+                                                                                 pl.hash_mask, status);
     }
     const unsigned lane_grid = (unsigned)((pl.nlanes + kBlock - 1) / kBlock);
     if (uniform && mode == TRW_RNG_GLIBC) {

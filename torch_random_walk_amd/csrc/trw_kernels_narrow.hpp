@@ -459,42 +459,73 @@ __device__ __forceinline__ uint32_t edge_hash(uint32_t u, uint32_t v)
 }
 
 // table: `mask`+1 slots of {u, v, lo, cnt-1}, all bytes 0xFF when empty.
+// Each thread owns 8 consecutive entries: one bisection of row32 finds the row of the first,
+// the others follow by walking row32 forward.  With sorted rows (the shadow pass counted no
+// descent inside a row) equal neighbours are adjacent, so the first entry of a run claims the
+// slot with ONE compare-and-swap and stores offset and multiplicity plainly; otherwise every
+// entry goes through CAS + min + add.
 __global__ void __launch_bounds__(kBlock)
 edge_table_build_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32, int64_t n_nodes,
-                        int64_t nnz, uint32_t *__restrict__ table, uint32_t mask)
+                        int64_t nnz, uint32_t *__restrict__ table, uint32_t mask,
+                        const int64_t *__restrict__ status)
 {
+    constexpr int kPer = 8;
+    const bool sorted = status[kStDescents] == status[kStBoundary];
+    const int64_t chunks = (nnz + kPer - 1) / kPer;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < nnz; e += stride) {
-        // the row that holds entry e: last u with row32[u] <= e (neighbouring lanes walk the same path)
-        uint32_t lo = 0, n = (uint32_t)n_nodes;
+    for (int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x; c < chunks; c += stride) {
+        const uint32_t e0 = (uint32_t)(c * kPer);
+        // the row that holds entry e0: last u with row32[u] <= e0
+        uint32_t u = 0, n = (uint32_t)n_nodes;
         while (n > 1) {
             const uint32_t half = n >> 1;
-            if (row32[lo + half] <= (uint32_t)e) {
-                lo += half;
+            if (row32[u + half] <= e0) {
+                u += half;
                 n -= half;
             } else {
                 n = half;
             }
         }
-        const uint32_t u = lo;
-        const uint32_t v = col32[e];
-        const uint32_t off = (uint32_t)e - row32[u];
-        const unsigned long long key = ((unsigned long long)v << 32) | u;
-        uint32_t slot = edge_hash(u, v) & mask;
-        while (true) {
-            unsigned long long *kp = (unsigned long long *)(table + 4 * (size_t)slot);
-            const unsigned long long old = atomicCAS(kp, ~0ull, key);
-            if (old == ~0ull || old == key) {
-                atomicMin(table + 4 * (size_t)slot + 2, off);
-                atomicAdd(table + 4 * (size_t)slot + 3, 1u);  // 0xFFFFFFFF + k = k - 1
-                break;
+        uint32_t row_lo = row32[u], row_hi = row32[u + 1];
+        for (int k = 0; k < kPer; ++k) {
+            const uint32_t e = e0 + k;
+            if (e >= (uint32_t)nnz) break;
+            while (e >= row_hi && u + 1 < (uint32_t)n_nodes) {  // next non-empty row
+                ++u;
+                row_lo = row_hi;
+                row_hi = row32[u + 1];
             }
-            slot = (slot + 1) & mask;
+            const uint32_t v = col32[e];
+            uint32_t cnt = 1;
+            if (sorted) {
+                if (e > row_lo && col32[e - 1] == v) continue;  // not the first of its run
+                while (e + cnt < row_hi && col32[e + cnt] == v) ++cnt;
+            }
+            const unsigned long long key = ((unsigned long long)v << 32) | u;
+            uint32_t slot = edge_hash(u, v) & mask;
+            while (true) {
+                uint32_t *ent = table + 4 * (size_t)slot;
+                const unsigned long long old = atomicCAS((unsigned long long *)ent, ~0ull, key);
+                if (sorted) {
+                    if (old == ~0ull) {
+                        ent[2] = e - row_lo;
+                        ent[3] = cnt - 1u;
+                        break;
+                    }
+                } else if (old == ~0ull || old == key) {
+                    atomicMin(ent + 2, e - row_lo);
+                    atomicAdd(ent + 3, 1u);  // 0xFFFFFFFF + k = k - 1
+                    break;
+                }
+                slot = (slot + 1) & mask;
+            }
         }
     }
 }
 
 enum : uint32_t { LS_IDLE = 0, LS_START, LS_ROW, LS_POS, LS_TRIAL, LS_CAND, LS_MEMBER };
+
+constexpr int kRing = 16;  // draws buffered per lane in LDS (4 Philox blocks)
 
 template <bool kCount>
 __global__ void __launch_bounds__(kBlock)
@@ -503,6 +534,11 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                    int64_t n_nodes, int64_t n_walkers, int64_t walker_base, int32_t L, uint32_t seed,
                    BiasedParams bp, int32_t want_pos, uint32_t *__restrict__ stage, int64_t *__restrict__ status)
 {
+    // Per-lane ring of upcoming draws, draw d of the lane's walker at ring[d % kRing][tid] (slot-major: a
+    // lane always hits its own bank).  The ring is topped up for ALL lanes of the wave at once whenever one
+    // lane runs dry, so the Philox rounds execute with (nearly) every lane active instead of for the few
+    // lanes that happen to need a block in a given iteration.
+    __shared__ uint32_t ring[kRing * kBlock];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         status[2] = TRW_RNG_WALKER;
         status[3] = 2;
@@ -510,6 +546,7 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
     // offsets of t inside prev's row are contiguous only when rows are sorted
     const bool use_pos = want_pos && status[kStDescents] == status[kStBoundary];
     const int lane = threadIdx.x & 63;
+    uint32_t *my_ring = ring + threadIdx.x;
 
     uint32_t st = 0;
     uint32_t n_trials = 0, n_fetch = 0, n_tests = 0, n_probes = 0;
@@ -523,59 +560,21 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
     FastMod fm;
     fm.d = 1;
     fm.z = 0;
-    uint32_t blk[4] = {0, 0, 0, 0};
-    uint32_t bi = 0;
-    bool odd = false;
-    uint32_t slot = 0, x = 0, ru = 0, rejected = 0;
+    uint32_t d_cons = 0, d_prod = 0;  // draws consumed / produced for the current walker
+    uint32_t slot = 0, ku = 0, kv = 0, ru = 0, rejected = 0;
     const uint32_t *addr = row32;
     uint32_t *sp = stage;
 
-    // after a candidate has been accepted: emit it and move on to the next step
-    auto accept_candidate = [&](uint32_t cand, bool row_known) {
-        *sp = cand;
-        sp += n_walkers;
-        ++s;
-        rejected = 0;
-        if (s > L) {
-            state = LS_START;
-            return;
-        }
-        if (row_known && t_deg != 0) {  // cand == t: its row is the one we came through two steps ago
-            const uint32_t ts = t_start, td = t_deg;
-            t_start = p_start;
-            t_deg = p_deg;
-            p_start = ts;
-            p_deg = td;
-            const uint32_t tt = t;
-            t = prev;
-            prev = tt;
-            fm.init(p_deg);
-            if (use_pos) {
-                slot = edge_hash(prev, t) & mask;
-                addr = table + 4 * (size_t)slot;
-                state = LS_POS;
-            } else {
-                state = LS_TRIAL;
-            }
-        } else {
-            t = prev;
-            t_start = p_start;
-            t_deg = p_deg;
-            prev = cand;
-            addr = row32 + prev;
-            state = LS_ROW;
-        }
-    };
-
     while (true) {
-        // ---- hand out walkers to the lanes that need one (wave-level, one atomic per wave) ----
+        // ---- hand out walkers to the lanes that need one (one atomic per wave) ----
         const unsigned long long need = __ballot(state == LS_START);
         if (need) {
+            const int leader = (int)__ffsll((long long)need) - 1;
             long long base = 0;
-            if (lane == (int)__ffsll((long long)need) - 1)
+            if (lane == leader)
                 base = (long long)atomicAdd((unsigned long long *)&status[kStNextWalker],
                                             (unsigned long long)__popcll(need));
-            base = __shfl(base, (int)__ffsll((long long)need) - 1);
+            base = __shfl(base, leader);
             if (state == LS_START) {
                 walker = base + __popcll(need & ((1ull << lane) - 1ull));
                 if (walker >= n_walkers) {
@@ -588,9 +587,8 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                         st |= TRW_ST_NODE_RANGE;  // transpose_rows_kernel fills the row with the bad id
                     } else {
                         gw = (uint64_t)walker_base + (uint64_t)walker;
-                        bi = 0;
-                        odd = false;
-                        walker_block(gw, 0, seed, blk);
+                        d_cons = 0;
+                        d_prod = 0;
                         s = 1;
                         rejected = 0;
                         prev = (uint32_t)tg;  // step 1 leaves the start node
@@ -605,111 +603,108 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
 
         // ---- the one gather of this iteration ----
         u32x4_a4 g = {0u, 0u, 0u, 0u};
-        const bool loads = state == LS_ROW || state == LS_POS || state == LS_CAND || state == LS_MEMBER;
-        if (loads) g = *reinterpret_cast<const u32x4_a4 *>(addr);
+        if (state == LS_ROW || state == LS_POS || state == LS_CAND || state == LS_MEMBER)
+            g = *reinterpret_cast<const u32x4_a4 *>(addr);
 
-        // ---- consume it ----
+        // ---- top up the draw rings when some lane is about to run dry ----
+        const bool live = state != LS_IDLE && state != LS_START;
+        if (__ballot(live && d_prod - d_cons < 2u)) {
+            while (__ballot(live && d_prod - d_cons <= (uint32_t)(kRing - 4))) {
+                if (live && d_prod - d_cons <= (uint32_t)(kRing - 4)) {
+                    uint32_t blk[4];
+                    walker_block(gw, d_prod >> 2, seed, blk);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) my_ring[((d_prod + k) & (kRing - 1)) * kBlock] = blk[k];
+                    d_prod += 4;
+                }
+            }
+        }
+
+        // ---- consume the gather: every state reduces to "accept cand", "reject", "probe (ku,kv)" or nothing ----
+        bool ev_accept = false, ev_known = false, ev_reject = false, ev_probe = false;
+        uint32_t cand = 0, probe_state = LS_POS;
         if (state == LS_ROW) {  // g = row32[prev], row32[prev+1], ...
             p_start = g.x;
             p_deg = g.y >= g.x ? g.y - g.x : 0u;
             if (p_deg == 0) {  // dead end: reported, the walker stays (the reference divides by zero)
                 st |= TRW_ST_DEGREE0;
-                accept_candidate(prev, false);
+                cand = prev;
+                ev_accept = true;
             } else if (s == 1) {  // first step: plain uniform neighbour, draw 0 (rw_cpu.cpp:159)
-                x = p_start + (blk[0] >> 1) % p_deg;
-                addr = col32 + x;
+                const uint32_t r0 = my_ring[0] >> 1;
+                d_cons = 1;
+                addr = col32 + p_start + r0 % p_deg;
                 ru = 0;
                 state = LS_CAND;
             } else {
                 fm.init(p_deg);
                 if (use_pos) {
-                    slot = edge_hash(prev, t) & mask;
-                    addr = table + 4 * (size_t)slot;
-                    state = LS_POS;
+                    ku = prev;
+                    kv = t;
+                    ev_probe = true;
                 } else {
                     state = LS_TRIAL;
                 }
             }
-        } else if (state == LS_POS) {  // g = {u, v, lo, cnt-1} of one slot
+        } else if (state == LS_POS || state == LS_MEMBER) {  // g = {u, v, lo, cnt-1} of one slot
             if (kCount) ++n_probes;
-            if (g.x == 0xFFFFFFFFu) {
-                pos_lo = 0;
-                pos_cnt = 0;
-                state = LS_TRIAL;
-            } else if (g.x == prev && g.y == t) {
-                pos_lo = g.z;
-                pos_cnt = g.w + 1u;
-                state = LS_TRIAL;
-            } else {
+            const bool empty = g.x == 0xFFFFFFFFu;
+            const bool match = g.x == ku && g.y == kv;
+            if (!empty && !match) {
                 slot = (slot + 1) & mask;
                 addr = table + 4 * (size_t)slot;
+            } else if (state == LS_POS) {  // where t sits in prev's row
+                pos_lo = match ? g.z : 0u;
+                pos_cnt = match ? g.w + 1u : 0u;
+                state = LS_TRIAL;
+            } else {  // is x a neighbour of t?
+                cand = kv;
+                if (ru < (match ? bp.t1 : bp.t2)) ev_accept = true;
+                else ev_reject = true;
             }
         } else if (state == LS_CAND) {  // g.x = the candidate node
-            const uint32_t cand = g.x;
-            bool rejected_now = false;
+            cand = g.x;
             if (s == 1) {
-                accept_candidate(cand, false);
+                ev_accept = true;
             } else {
                 if (kCount) ++n_fetch;
                 if (cand == t) {
-                    if (ru < bp.t0) accept_candidate(cand, true);
-                    else rejected_now = true;
+                    if (ru < bp.t0) ev_accept = ev_known = true;
+                    else ev_reject = true;
                 } else if (ru < bp.lo) {
-                    accept_candidate(cand, false);
+                    ev_accept = true;
                 } else if (ru >= bp.hi) {
-                    rejected_now = true;
+                    ev_reject = true;
                 } else {
                     if (kCount) ++n_tests;
-                    x = cand;
-                    slot = edge_hash(t, cand) & mask;
-                    addr = table + 4 * (size_t)slot;
-                    state = LS_MEMBER;
+                    ku = t;
+                    kv = cand;
+                    ev_probe = true;
+                    probe_state = LS_MEMBER;
                 }
             }
-            if (rejected_now) {
-                state = LS_TRIAL;
-                if (++rejected >= kTrialCap) {
-                    st |= (uint32_t)kStTrialCap;
-                    accept_candidate(cand, false);
-                }
-            }
-        } else if (state == LS_MEMBER) {  // is x in t's row?
-            if (kCount) ++n_probes;
-            bool decided = true, member = false;
-            if (g.x == 0xFFFFFFFFu) member = false;
-            else if (g.x == t && g.y == x) member = true;
-            else decided = false;
-            if (!decided) {
-                slot = (slot + 1) & mask;
-                addr = table + 4 * (size_t)slot;
-            } else if (ru < (member ? bp.t1 : bp.t2)) {
-                accept_candidate(x, false);
-            } else if (++rejected >= kTrialCap) {
+        }
+        if (ev_reject) {
+            state = LS_TRIAL;
+            if (++rejected >= kTrialCap) {
                 st |= (uint32_t)kStTrialCap;
-                accept_candidate(x, false);
-            } else {
-                state = LS_TRIAL;
+                ev_accept = true;
+                ev_known = false;
             }
         }
 
         // ---- one rejection trial for every lane that is between gathers ----
-        if (state == LS_TRIAL) {
-            uint32_t rc;
-            if (!odd) {
-                rc = blk[1] >> 1;
-                ru = blk[2] >> 1;
-            } else {
-                rc = blk[3] >> 1;
-                walker_block(gw, ++bi, seed, blk);
-                ru = blk[0] >> 1;
-            }
-            odd = !odd;
+        if (state == LS_TRIAL && !ev_accept && d_prod - d_cons >= 2u) {
+            const uint32_t rc = my_ring[(d_cons & (kRing - 1)) * kBlock] >> 1;
+            ru = my_ring[((d_cons + 1) & (kRing - 1)) * kBlock] >> 1;
+            d_cons += 2;
             if (kCount) ++n_trials;
             const uint32_t idx = fm.mod(rc);
             if (use_pos && ru >= bp.hi) {
                 // no candidate but t itself can pass this draw; t sits at offsets [pos_lo, pos_lo+pos_cnt)
                 if (ru < bp.t0 && idx - pos_lo < pos_cnt) {
-                    accept_candidate(t, true);
+                    cand = t;
+                    ev_accept = ev_known = true;
                 } else if (++rejected >= kTrialCap) {
                     st |= (uint32_t)kStTrialCap;
                     addr = col32 + p_start + idx;  // take whatever this trial drew
@@ -721,6 +716,48 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                 addr = col32 + p_start + idx;
                 state = LS_CAND;
             }
+        }
+
+        // ---- emit an accepted candidate and move to the next step ----
+        if (ev_accept) {
+            *sp = cand;
+            sp += n_walkers;
+            ++s;
+            rejected = 0;
+            if (s > L) {
+                state = LS_START;
+            } else if (ev_known && t_deg != 0) {  // cand == t: its row is the one we came through
+                const uint32_t ts = t_start, td = t_deg, tt = t;
+                t_start = p_start;
+                t_deg = p_deg;
+                p_start = ts;
+                p_deg = td;
+                t = prev;
+                prev = tt;
+                fm.init(p_deg);
+                if (use_pos) {
+                    ku = prev;
+                    kv = t;
+                    ev_probe = true;
+                    probe_state = LS_POS;
+                } else {
+                    state = LS_TRIAL;
+                }
+            } else {
+                t = prev;
+                t_start = p_start;
+                t_deg = p_deg;
+                prev = cand;
+                addr = row32 + prev;
+                state = LS_ROW;
+            }
+        }
+
+        // ---- start a table probe ----
+        if (ev_probe) {
+            slot = edge_hash(ku, kv) & mask;
+            addr = table + 4 * (size_t)slot;
+            state = probe_state;
         }
     }
 
