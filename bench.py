@@ -226,6 +226,7 @@ def main():
 
     # ---- CPU baseline: the reference's algorithm on a bounded sample (rank 0, N = 1 only) ------
     cpu = None
+    reference_accounting = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
         rp_h, ci_h = row_ptr.cpu().numpy(), col_idx.cpu().numpy()
@@ -242,6 +243,29 @@ def main():
                    sample="first %d start nodes of a seeded permutation of the batch, %d steps, %.1f s, "
                           "oracle libc srand/rand single thread (the reference's csrc/cpu algorithm; its "
                           "multi-threaded run is slower and non-deterministic, SURVEY 0.2)" % (sample, sample * L, dt))
+        if not uniform:
+            # SURVEY 8(d) accounting: what the REFERENCE's loop reads for the same walks (a candidate on every
+            # trial, is_neighbor on every candidate != t), from the oracle's counters on walkers 0..m-1 -- the
+            # same walks the GPU produced for those rows -- scaled to the batch.
+            m = min(B, 2000)
+            ref_w, cnt = O.walk(rp_h, ci_h, targets.cpu()[:m].numpy(), p, q, L, args.seed, rng_mode=O.RNG_WALKER,
+                                walker_base=walker_base, return_counters=True)
+            assert (ref_w == walks[:m].cpu().numpy()).all(), "GPU rows differ from the oracle"
+            scale = B / m
+            deg_h = (rp_h[1:] - rp_h[:-1])
+            import numpy as np
+            t_nodes = ref_w[:, :-2].reshape(-1)            # the `t` of every step >= 2
+            log2deg = np.ceil(np.log2(np.maximum(deg_h[t_nodes], 2))).mean()
+            trials_r, member_r, scan_r = cnt["trials_total"] * scale, cnt["membership_tests"] * scale, \
+                cnt["scan_entries_total"] * scale
+            base_r = B * 16 + B * 32 + 8 * B * (L - 1) + 24 * trials_r + 16 * member_r
+            reference_accounting = dict(
+                sample_walkers=m,
+                trials=trials_r, membership_tests=member_r, linear_scan_entries=scan_r,
+                bytes_linear_scan=base_r + 8 * scan_r,
+                bytes_binary_search=base_r + 8 * member_r * float(log2deg),
+                note="SURVEY 8(d) formula with the reference's access pattern; NOT used for roofline.achieved, "
+                     "which counts only what this kernel's algorithm has to read")
 
     if rank == 0:
         total_steps = world * B * L * args.steps
@@ -285,6 +309,7 @@ def main():
                 "finish_ms": sum(finish_ms) / max(1, len(finish_ms)),
                 "kernel_steps_per_s": steps_per_launch / (k_ms * 1e-3) if k_ms > 0 else None,
                 "counters": counters,
+                "reference_accounting": reference_accounting,
             },
             "cpu_baseline": cpu,
             "graph_build_s": t_graph,

@@ -16,7 +16,8 @@ def pytest_configure(config):
 def _native_built():
     """Build the native pieces if they are absent (hipcc cross-compiles without a GPU).
     On the GPU box the prebuilt .so files travel with the snapshot and are used as they are."""
-    from torch_random_walk_amd import _build
+    import __graft_entry__
+    _build = __graft_entry__._load_builder()
     if not (os.path.exists(_build.HIP_LIB) and os.path.exists(_build.EXT_LIB)):
         _build.build_all()
     from oracle import oracle

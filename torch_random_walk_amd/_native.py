@@ -9,7 +9,7 @@ HIP_LIB_PATH = os.path.join(_HERE, "libtrw_hip.so")
 
 if not os.path.exists(HIP_LIB_PATH):
     raise ImportError(
-        "torch_random_walk_amd: %s is missing. Build it with `python -m torch_random_walk_amd._build` "
+        "torch_random_walk_amd: %s is missing. Build it with `python torch_random_walk_amd/_build.py` "
         "(hipcc --offload-arch=gfx950). There is no CPU fallback." % HIP_LIB_PATH)
 
 try:
@@ -17,7 +17,7 @@ try:
 except ImportError as e:  # pragma: no cover - exercised only on a broken build
     raise ImportError(
         "torch_random_walk_amd: the torch_rw_native extension failed to load (%s). Rebuild with "
-        "`python -m torch_random_walk_amd._build --force`. There is no CPU fallback." % e) from e
+        "`python torch_random_walk_amd/_build.py --force`. There is no CPU fallback." % e) from e
 
 RNG_AUTO = int(ext.RNG_AUTO)
 RNG_GLIBC = int(ext.RNG_GLIBC)
