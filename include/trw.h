@@ -116,6 +116,34 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes,
                      void *workspace, size_t workspace_bytes,
                      void *hip_stream);
 
+/*
+ * The triples (knowledge-graph) walk.  Replaces the reference's
+ *     torch::Tensor triples::walk_triples_gpu(triples_indexed, relation_tail_index, target_nodes,
+ *                                             walk_length, padding_idx, restart, seed)
+ * (csrc/cuda/rw_cuda_triples.h:4-13, called from csrc/rw_init.cpp:57-65) and produces what
+ * triples::walk_triples_cpu (csrc/cpu/rw_cpu_triples.cpp:105-127) produces.
+ *
+ *   triples   [n_triples][3]  int64 (head, relation, tail) sorted by head     (reference arg 1)
+ *   rt_index  [n_entities][2] int64 inclusive (first, last) triple per head,
+ *                             (-1,-1) for an entity without out-edges          (reference arg 2)
+ *   targets   [n_walkers]     int64 start entities                             (reference arg 3)
+ *   padding_idx               emitted once a walk can go no further            (reference arg 5)
+ *   out       [n_walkers][2*walk_length+1] int64: start, then (relation, tail) per hop
+ * The reference's `restart` argument is accepted by its Python surface and never read
+ * (rw_cpu_triples.cpp:48-55); it has no counterpart here.  rng_mode as for the CSR walk:
+ * TRW_RNG_GLIBC replays the reference's serial stream with one lane (walker_base == 0),
+ * TRW_RNG_WALKER uses the per-walker stream (draw k = the k-th draw the walker consumes; hops
+ * from single-edge entities and padding consume none, csrc/cpu/cpu_utils.cpp:4-5), TRW_RNG_AUTO
+ * picks GLIBC for walker_base == 0 && n_walkers <= 32768 && n_walkers*walk_length <= 2^18.
+ */
+size_t trw_walk_triples_workspace_bytes(int64_t n_triples, int64_t n_entities, int64_t n_walkers,
+                                        int32_t walk_length, int64_t padding_idx, int32_t rng_mode);
+int trw_walk_triples_hip(const int64_t *triples, int64_t n_triples,
+                         const int64_t *rt_index, int64_t n_entities,
+                         const int64_t *targets, int64_t n_walkers, int64_t walker_base,
+                         int32_t walk_length, int64_t padding_idx, int32_t seed, int32_t rng_mode,
+                         int64_t *out, void *workspace, size_t workspace_bytes, void *hip_stream);
+
 /* Synchronises `hip_stream` and copies the status block of the last walk that
  * used `workspace` to the host: status[0] = OR of TRW_ST_* bits,
  * status[1] = 1 if some CSR row was found unsorted (biased walks only; the

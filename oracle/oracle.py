@@ -79,6 +79,10 @@ def lib():
             ctypes.c_double, ctypes.c_double, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
             i64p, ctypes.POINTER(Counters), i64p]
         L.trw_oracle_walk_csr.restype = ctypes.c_int
+        L.trw_oracle_walk_triples.argtypes = [
+            i64p, ctypes.c_int64, i64p, ctypes.c_int64, i64p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
+            ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, i64p, ctypes.POINTER(ctypes.c_uint64)]
+        L.trw_oracle_walk_triples.restype = ctypes.c_int
         _lib = L
     return _lib
 
@@ -181,3 +185,28 @@ def walk_timed(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, rng_mode
     if rc != 0:
         raise OracleError(rc)
     return out, dt
+
+
+def walk_triples(triples_indexed, relation_tail_index, target_nodes, walk_length, padding_idx, seed,
+                 rng_mode=RNG_GLIBC_SEQ, walker_base=0, return_draws=False, timed=False):
+    """The reference's ``triples::walk_triples_cpu`` restated: ``[N, 2*walk_length+1]`` int64."""
+    import time
+    tr = np.ascontiguousarray(np.asarray(triples_indexed), dtype=np.int64).reshape(-1, 3)
+    ix = np.ascontiguousarray(np.asarray(relation_tail_index), dtype=np.int64).reshape(-1, 2)
+    tg, tg_p = _i64(target_nodes)
+    n = int(tg.shape[0])
+    out = np.empty((n, 2 * int(walk_length) + 1), dtype=np.int64)
+    draws = ctypes.c_uint64(0)
+    p64 = ctypes.POINTER(ctypes.c_int64)
+    t0 = time.perf_counter()
+    rc = lib().trw_oracle_walk_triples(tr.ctypes.data_as(p64), tr.shape[0], ix.ctypes.data_as(p64), ix.shape[0],
+                                       tg_p, n, int(walker_base), int(walk_length), int(padding_idx), int(seed),
+                                       int(rng_mode), out.ctypes.data_as(p64), ctypes.byref(draws))
+    dt = time.perf_counter() - t0
+    if rc != 0:
+        raise OracleError(rc)
+    if timed:
+        return out, dt
+    if return_draws:
+        return out, int(draws.value)
+    return out

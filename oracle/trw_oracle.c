@@ -374,3 +374,63 @@ int trw_oracle_walk_csr(const int64_t *row_ptr, int64_t n_nodes,
     if (counters) *counters = cnt;
     return g.err;
 }
+
+/* ------------------------------------------------------------------------ */
+/* Triples (knowledge-graph) walk                                             */
+/* ------------------------------------------------------------------------ */
+
+int trw_oracle_walk_triples(const int64_t *triples, int64_t n_triples,
+                            const int64_t *rt_index, int64_t n_entities,
+                            const int64_t *targets, int64_t n_walkers,
+                            int64_t walker_base, int32_t walk_length,
+                            int64_t padding_idx, int32_t seed, int32_t rng_mode,
+                            int64_t *out, uint64_t *draws_total)
+{
+    if ((!triples && n_triples) || (!rt_index && n_entities) || (!targets && n_walkers) || (!out && n_walkers))
+        return TRW_ORACLE_E_ARG;
+    if (n_triples < 0 || n_entities < 0 || n_walkers < 0 || walker_base < 0 || walk_length < 1) return TRW_ORACLE_E_ARG;
+    if (rng_mode != TRW_ORACLE_RNG_GLIBC_SEQ && rng_mode != TRW_ORACLE_RNG_LIBC && rng_mode != TRW_ORACLE_RNG_WALKER)
+        return TRW_ORACLE_E_ARG;
+    if (rng_mode != TRW_ORACLE_RNG_WALKER && walker_base != 0) return TRW_ORACLE_E_ARG;
+
+    rng_t rng;
+    memset(&rng, 0, sizeof rng);
+    rng.mode = rng_mode;
+    rng.seed = seed;
+    if (rng_mode == TRW_ORACLE_RNG_LIBC) srand((unsigned)seed); /* rw_cpu_triples.cpp:57 */
+    else if (rng_mode == TRW_ORACLE_RNG_GLIBC_SEQ) glibc_init(&rng.gl, seed);
+
+    int err = 0;
+    const int64_t walk_size = 2 * (int64_t)walk_length + 1; /* rw_cpu_triples.cpp:119 */
+    for (int64_t i = 0; i < n_walkers && !err; ++i) {
+        int64_t *walk = out + i * walk_size;
+        rng_begin_walker(&rng, (uint64_t)walker_base + (uint64_t)i, walk_length);
+        const int64_t target_node = targets[i];
+        walk[0] = target_node;
+        int64_t previous_node = target_node;
+        for (int64_t s = 1; s < walk_size; s += 2) { /* rw_cpu_triples.cpp:91 */
+            int64_t relation = padding_idx, tail = padding_idx;
+            if (previous_node != padding_idx) { /* :20 */
+                if (previous_node < 0 || previous_node >= n_entities) { err = TRW_ORACLE_E_RANGE; break; }
+                const int64_t start_index = rt_index[2 * previous_node];
+                const int64_t end_index = rt_index[2 * previous_node + 1];
+                if (!(start_index == -1 || end_index == -1)) { /* :26 */
+                    int64_t e = start_index; /* sample_int, cpu_utils.cpp:3-10 */
+                    if (start_index != end_index) {
+                        const int64_t span = (end_index + 1) - start_index;
+                        if (span <= 0) { err = TRW_ORACLE_E_ARG; break; }
+                        e = start_index + ((int64_t)rng_next(&rng) % span);
+                    }
+                    if (e < 0 || e >= n_triples) { err = TRW_ORACLE_E_RANGE; break; }
+                    relation = triples[3 * e + 1];
+                    tail = triples[3 * e + 2];
+                }
+            }
+            walk[s] = relation;
+            walk[s + 1] = tail;
+            previous_node = tail;
+        }
+    }
+    if (draws_total) *draws_total = rng.ndraws;
+    return err;
+}

@@ -107,6 +107,28 @@ int trw_oracle_walk_csr(const int64_t *row_ptr, int64_t n_nodes,
                         trw_oracle_counters *counters,
                         int64_t *draws_per_walker);
 
+/*
+ * triples::walk_triples_cpu restated (csrc/cpu/rw_cpu_triples.cpp:105-127 ->
+ * uniform_walk_triples :48-103, triples::sample_neighbor :11-46, sample_int
+ * csrc/cpu/cpu_utils.cpp:3-10).
+ *
+ *   triples   [n_triples][3] int64 (head, relation, tail), sorted by head
+ *   rt_index  [n_entities][2] int64 inclusive (first, last) triple of each
+ *             head, (-1,-1) for entities without out-edges
+ *   out       [n_walkers][2*walk_length+1]: start, then (relation, tail) per hop
+ * A hop from the padding id, or from an entity without out-edges, yields
+ * (padding, padding) and consumes no draw; a single-edge entity consumes no
+ * draw either (sample_int returns early when start == end).
+ * rng_mode: GLIBC_SEQ / LIBC (serial stream, walker_base must be 0) or WALKER
+ * (draw k = the k-th draw this walker actually consumes).
+ */
+int trw_oracle_walk_triples(const int64_t *triples, int64_t n_triples,
+                            const int64_t *rt_index, int64_t n_entities,
+                            const int64_t *targets, int64_t n_walkers,
+                            int64_t walker_base, int32_t walk_length,
+                            int64_t padding_idx, int32_t seed, int32_t rng_mode,
+                            int64_t *out, uint64_t *draws_total);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,7 +1,7 @@
 // torch_rw_native -- the PyTorch-ROCm face of libtrw_hip.so.
 //
-// Plays the role of the reference's pybind dispatcher (csrc/rw_init.cpp:11-25,
-// m.def("walk") at :134) for the CSR walk path only: same module name, same
+// Plays the role of the reference's pybind dispatcher (csrc/rw_init.cpp:11-25 and :47-75,
+// m.def("walk") / m.def("walk_triples") at :134/:136) for the walk paths built so far: same module name, same
 // function name, same seven positional arguments.  Everything below the
 // argument checks is the C ABI of include/trw.h; torch is used for device
 // memory (output + scratch through the caching allocator), the device guard and
@@ -108,6 +108,69 @@ torch::Tensor walk(const torch::Tensor &row_ptr, const torch::Tensor &column_idx
     return walk_ex(row_ptr, column_idx, target_nodes, p, q, walk_length, seed, 0, g_rng_mode.load(), g_check.load());
 }
 
+// walk_triples: reference dispatcher csrc/rw_init.cpp:47-75, same argument order.
+torch::Tensor walk_triples_ex(const torch::Tensor &triples_indexed, const torch::Tensor &relation_tail_index,
+                              const torch::Tensor &target_nodes, int64_t walk_length, int64_t padding_idx,
+                              bool restart, int64_t seed, int64_t walker_base, int64_t rng_mode, bool check)
+{
+    (void)restart;  // accepted and never read by the reference either (rw_cpu_triples.cpp:48-55)
+    check_index_tensor(target_nodes, "target_nodes");
+    for (const auto *t : {&triples_indexed, &relation_tail_index}) {
+        TORCH_CHECK(t->is_cuda(), "triples_indexed and relation_tail_index must be CUDA tensors (torch_rw_native here "
+                                  "is the MI355X HIP build; it has no CPU walker)");
+        TORCH_CHECK(t->scalar_type() == torch::kInt64, "expected scalar type Long but found ",
+                    c10::toString(t->scalar_type()));
+        TORCH_CHECK(t->dim() == 2, "triples_indexed / relation_tail_index must be 2-dimensional");
+    }
+    TORCH_CHECK(triples_indexed.size(1) == 3, "triples_indexed must be [T, 3] (head, relation, tail)");
+    TORCH_CHECK(relation_tail_index.size(1) == 2, "relation_tail_index must be [num_entities, 2]");
+    TORCH_CHECK(triples_indexed.device() == target_nodes.device() && relation_tail_index.device() == target_nodes.device(),
+                "triples_indexed, relation_tail_index and target_nodes must be on the same device");
+    TORCH_CHECK(walk_length >= 1, "walk_length must be >= 1, got ", walk_length);
+    TORCH_CHECK(walk_length < (int64_t(1) << 30) && seed >= INT32_MIN && seed <= INT32_MAX,
+                "walk_length/seed must fit the reference's int arguments");
+
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(target_nodes.device());
+    const auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(target_nodes.device().index());
+    const auto tr = triples_indexed.contiguous();
+    const auto ix = relation_tail_index.contiguous();
+    const auto tg = target_nodes.contiguous();
+    const int64_t n_triples = tr.size(0), n_entities = ix.size(0), n_walkers = tg.numel();
+
+    // rw_cuda_triples.cu: a fresh [N, 2L+1] int64 tensor on the inputs' device
+    auto walks = torch::empty({n_walkers, 2 * walk_length + 1}, tg.options());
+    const size_t ws_bytes = trw_walk_triples_workspace_bytes(n_triples, n_entities, n_walkers, (int32_t)walk_length,
+                                                             padding_idx, (int32_t)rng_mode);
+    auto workspace = torch::empty({(int64_t)ws_bytes}, tg.options().dtype(torch::kUInt8));
+    int rc;
+    {
+        pybind11::gil_scoped_release nogil;
+        rc = trw_walk_triples_hip(tr.data_ptr<int64_t>(), n_triples, ix.data_ptr<int64_t>(), n_entities,
+                                  tg.data_ptr<int64_t>(), n_walkers, walker_base, (int32_t)walk_length, padding_idx,
+                                  (int32_t)seed, (int32_t)rng_mode, walks.data_ptr<int64_t>(), workspace.data_ptr(),
+                                  ws_bytes, (void *)stream.stream());
+    }
+    TORCH_CHECK(rc == TRW_OK, "torch_rw walk_triples failed (", rc, "): ", trw_last_error());
+    if (check) {
+        int64_t status[4] = {0, 0, 0, 0};
+        {
+            pybind11::gil_scoped_release nogil;
+            rc = trw_walk_status(workspace.data_ptr(), (void *)stream.stream(), status);
+        }
+        TORCH_CHECK(rc == TRW_OK, "torch_rw status read failed (", rc, "): ", trw_last_error());
+        TORCH_CHECK(status[0] == 0, "torch_rw walk_triples: ", status_text(status[0]), "status bits ", status[0]);
+    }
+    return walks;
+}
+
+torch::Tensor walk_triples(const torch::Tensor &triples_indexed, const torch::Tensor &relation_tail_index,
+                           const torch::Tensor &target_nodes, const int walk_length, const int64_t padding_idx,
+                           const bool restart, const int seed)
+{
+    return walk_triples_ex(triples_indexed, relation_tail_index, target_nodes, walk_length, padding_idx, restart, seed,
+                           0, g_rng_mode.load(), g_check.load());
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
@@ -119,6 +182,14 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           pybind11::arg("row_ptr"), pybind11::arg("col_idx"), pybind11::arg("target_nodes"), pybind11::arg("p"),
           pybind11::arg("q"), pybind11::arg("walk_length"), pybind11::arg("seed"), pybind11::arg("walker_base") = 0,
           pybind11::arg("rng_mode") = (int64_t)TRW_RNG_AUTO, pybind11::arg("check") = true);
+    m.def("walk_triples", &walk_triples, "walk_triples", pybind11::arg("triples_indexed"),
+          pybind11::arg("relation_tail_index"), pybind11::arg("target_nodes"), pybind11::arg("walk_length"),
+          pybind11::arg("padding_idx"), pybind11::arg("restart"), pybind11::arg("seed"));
+    m.def("walk_triples_ex", &walk_triples_ex, "walk_triples with a global walker base, RNG mode and status check",
+          pybind11::arg("triples_indexed"), pybind11::arg("relation_tail_index"), pybind11::arg("target_nodes"),
+          pybind11::arg("walk_length"), pybind11::arg("padding_idx"), pybind11::arg("restart"), pybind11::arg("seed"),
+          pybind11::arg("walker_base") = 0, pybind11::arg("rng_mode") = (int64_t)TRW_RNG_AUTO,
+          pybind11::arg("check") = true);
     m.def("set_rng_mode", [](int64_t mode) {
         TORCH_CHECK(mode == TRW_RNG_AUTO || mode == TRW_RNG_GLIBC || mode == TRW_RNG_WALKER, "unknown rng mode ", mode);
         g_rng_mode.store((int)mode);

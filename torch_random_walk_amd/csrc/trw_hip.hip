@@ -28,6 +28,7 @@
 #include "glibc_jump.hpp"
 #include "trw_kernels_wide.hpp"
 #include "trw_kernels_narrow.hpp"
+#include "trw_kernels_triples.hpp"
 
 namespace {
 
@@ -199,6 +200,43 @@ unsigned stream_grid(int64_t items)
     return (unsigned)blocks;
 }
 
+}  // namespace
+
+namespace {
+struct TriplesPlan {
+    bool narrow = false;
+    size_t off_rt32 = 0, off_ix32 = 0, off_stage = 0, total = 0;
+};
+
+TriplesPlan make_triples_plan(int64_t n_triples, int64_t n_entities, int64_t n_walkers, int32_t L,
+                              int64_t padding_idx, int32_t rng_mode)
+{
+    TriplesPlan pl;
+    size_t off = kStatusBytes;
+    const bool fits = n_entities < ((int64_t)1 << 31) && n_triples < ((int64_t)1 << 32) - 64 && padding_idx >= 0 &&
+                      padding_idx < ((int64_t)1 << 31) && env_long("TRW_FORCE_WIDE", 0, 1, 0) == 0;
+    pl.narrow = fits && rng_mode != TRW_RNG_GLIBC && n_walkers > 0 && L >= 1;
+    if (pl.narrow) {
+        pl.off_rt32 = off;
+        off += align_up((size_t)n_triples * 8 + 64, 256);
+        pl.off_ix32 = off;
+        off += align_up((size_t)n_entities * 8 + 64, 256);
+        pl.off_stage = off;
+        off += align_up((size_t)n_walkers * (2 * (size_t)L + 1) * sizeof(uint32_t), 256);
+    }
+    pl.total = off;
+    return pl;
+}
+
+int resolve_triples_mode(int32_t rng_mode, int64_t n_walkers, int64_t walker_base, int32_t L)
+{
+    if (rng_mode == TRW_RNG_GLIBC || rng_mode == TRW_RNG_WALKER) return rng_mode;
+    if (rng_mode != TRW_RNG_AUTO) return -1;
+    // the reference is deterministic up to its parallel_for grain of 32768 walkers
+    // (rw_cpu_triples.cpp:67); the serial replay is one lane, so it is also kept to small jobs
+    return (walker_base == 0 && n_walkers <= 32768 && n_walkers * (int64_t)L <= ((int64_t)1 << 18)) ? TRW_RNG_GLIBC
+                                                                                                    : TRW_RNG_WALKER;
+}
 }  // namespace
 
 extern "C" {
@@ -405,6 +443,82 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col
         const dim3 grid((unsigned)((pl.nlanes + 63) / 64), (unsigned)pl.G);
         transpose_rows_kernel<<<grid, kBlock, 0, stream>>>(stage, targets, n_nodes, n_walkers, walk_length, pl.G,
                                                           pl.nlanes, out);
+    }
+    prof_mark(3, stream);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "kernel launch");
+    return TRW_OK;
+}
+
+// ---- triples (knowledge-graph) walk, reference csrc/cpu/rw_cpu_triples.cpp -----------------------
+
+size_t trw_walk_triples_workspace_bytes(int64_t n_triples, int64_t n_entities, int64_t n_walkers,
+                                        int32_t walk_length, int64_t padding_idx, int32_t rng_mode)
+{
+    if (n_triples < 0 || n_entities < 0) return kStatusBytes;
+    return make_triples_plan(n_triples, n_entities, n_walkers, walk_length, padding_idx, rng_mode).total;
+}
+
+int trw_walk_triples_hip(const int64_t *triples, int64_t n_triples, const int64_t *rt_index, int64_t n_entities,
+                         const int64_t *targets, int64_t n_walkers, int64_t walker_base, int32_t walk_length,
+                         int64_t padding_idx, int32_t seed, int32_t rng_mode, int64_t *out, void *workspace,
+                         size_t workspace_bytes, void *hip_stream)
+{
+    t_last_error.clear();
+    if (n_triples < 0 || n_entities < 0 || n_walkers < 0 || walker_base < 0)
+        return fail(TRW_E_ARG, "negative size argument");
+    if (walk_length < 1) return fail(TRW_E_ARG, "walk_length must be >= 1");
+    if (n_triples > 0 && !triples) return fail(TRW_E_ARG, "triples is null");
+    if (n_entities > 0 && !rt_index) return fail(TRW_E_ARG, "relation_tail_index is null");
+    if (n_walkers > 0 && (!targets || !out)) return fail(TRW_E_ARG, "targets/out is null");
+    if (!workspace || workspace_bytes < (size_t)kStatusBytes)
+        return fail(TRW_E_WORKSPACE, "workspace missing or smaller than the status block");
+    if (((uintptr_t)workspace & 15u) != 0) return fail(TRW_E_WORKSPACE, "workspace must be 16-byte aligned");
+    const int mode = resolve_triples_mode(rng_mode, n_walkers, walker_base, walk_length);
+    if (mode < 0) return fail(TRW_E_RNG_MODE, "unknown rng_mode");
+    if (mode == TRW_RNG_GLIBC && walker_base != 0)
+        return fail(TRW_E_RNG_MODE, "TRW_RNG_GLIBC triples walks replay one serial stream: walker_base must be 0");
+
+    hipStream_t stream = (hipStream_t)hip_stream;
+    int64_t *status = (int64_t *)workspace;
+    hipError_t e = hipMemsetAsync(status, 0, kStatusBytes, stream);
+    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(status)");
+    if (n_walkers == 0) return TRW_OK;
+
+    const TriplesPlan pl = make_triples_plan(n_triples, n_entities, n_walkers, walk_length, padding_idx, mode);
+    if (workspace_bytes < pl.total) return fail(TRW_E_WORKSPACE, "workspace too small for this call shape");
+    char *ws = (char *)workspace;
+    const unsigned walker_grid = (unsigned)((n_walkers + kBlock - 1) / kBlock);
+
+    prof_mark(0, stream);
+    if (pl.narrow)
+        triples_shadow_kernel<<<stream_grid(n_triples > n_entities ? n_triples : n_entities), kBlock, 0, stream>>>(
+            triples, n_triples, rt_index, n_entities, padding_idx, (u32x2_a8 *)(ws + pl.off_rt32),
+            (u32x2_a8 *)(ws + pl.off_ix32), status);
+    prof_mark(1, stream);
+    if (mode == TRW_RNG_GLIBC) {
+        SeedWindow sw;
+        trw::seed_window(seed, sw.w);
+        triples_glibc_seq_kernel<<<1, 64, 0, stream>>>(triples, n_triples, rt_index, targets, n_entities, n_walkers,
+                                                      walk_length, padding_idx, sw, out, status);
+    } else if (pl.narrow) {
+        triples_walker_kernel<<<walker_grid, kBlock, 0, stream>>>(
+            (const u32x2_a8 *)(ws + pl.off_rt32), (const u32x2_a8 *)(ws + pl.off_ix32), targets, n_entities,
+            n_walkers, walker_base, walk_length, (uint32_t)padding_idx, (uint32_t)seed,
+            (uint32_t *)(ws + pl.off_stage), status);
+    } else {
+        triples_walker_wide_kernel<<<walker_grid, kBlock, 0, stream>>>(triples, n_triples, rt_index, targets,
+                                                                      n_entities, n_walkers, walker_base, walk_length,
+                                                                      padding_idx, (uint32_t)seed, out, status);
+    }
+    prof_mark(2, stream);
+    if (pl.narrow && mode == TRW_RNG_WALKER) {
+        const dim3 grid((unsigned)((n_walkers + 63) / 64), 1u);
+        // the start node is the only column that may be anything: a row whose start is neither an
+        // entity nor the padding id is filled with it (and was reported)
+        transpose_rows_kernel<<<grid, kBlock, 0, stream>>>((const uint32_t *)(ws + pl.off_stage), targets,
+                                                          padding_idx >= n_entities ? padding_idx + 1 : n_entities,
+                                                          n_walkers, 2 * walk_length, 1, n_walkers, out);
     }
     prof_mark(3, stream);
     e = hipGetLastError();

@@ -84,3 +84,26 @@ def walks_follow_edges(row_ptr, col_idx, walks):
         pos = torch.searchsorted(keys, q).clamp_(max=keys.numel() - 1)
         ok = ok and bool((keys[pos] == q).all())
     return ok
+
+
+def synthetic_kg(n_entities, n_triples, n_relations, seed=1, device="cpu", skew=(0.57, 0.19, 0.19, 0.05)):
+    """Synthetic knowledge graph (BASELINE config 5 recipe): heads R-MAT-skewed, tails
+    from the same generator's column bits, relations uniform.  Entity ids are 0..n_entities-1, relation
+    ids n_entities..n_entities+n_relations-1 (the reference's tests number them after the entities,
+    tests/test_rw_triples.py:14-24) and the padding id is n_entities+n_relations.
+    Returns ``(triples [T,3] int64 unsorted, entities [n] int64, padding_idx)``.
+    """
+    scale = max(1, (n_entities - 1).bit_length())
+    a, b, c, _ = skew
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    h = torch.zeros(n_triples, dtype=torch.int64, device=device)
+    t = torch.zeros(n_triples, dtype=torch.int64, device=device)
+    for _ in range(scale):
+        u = torch.rand(n_triples, generator=g, device=device)
+        h = (h << 1) | (u >= a + b).to(torch.int64)
+        t = (t << 1) | (((u >= a) & (u < a + b)) | (u >= a + b + c)).to(torch.int64)
+    rel = torch.randint(0, n_relations, (n_triples,), generator=g, device=device, dtype=torch.int64) + n_entities
+    triples = torch.stack([h % n_entities, rel, t % n_entities], dim=1).contiguous()
+    entities = torch.arange(n_entities, dtype=torch.int64, device=device)
+    return triples, entities, n_entities + n_relations

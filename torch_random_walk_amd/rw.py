@@ -41,3 +41,22 @@ def get_rng_mode():
 def set_check(on):
     """Whether ``walk`` synchronises and raises on device-side data faults (default True)."""
     torch_rw_native.set_check(bool(on))
+
+
+def walk_triples(triples_indexed, relation_tail_index, target_nodes, walk_length, padding_idx, seed, restart=True):
+    """Knowledge-graph walks that emit (relation, tail) per hop: ``[N, 2*walk_length+1]`` int64.
+
+    Same surface as the reference (torch_rw/rw.py:18-26, which reorders the arguments for the native
+    call exactly like this): ``triples_indexed`` is ``[T, 3]`` (head, relation, tail) sorted by head and
+    ``relation_tail_index`` ``[num_entities, 2]`` from ``utils.build_relation_tail_index``.  ``restart`` is
+    accepted and unused, as in the reference (csrc/cpu/rw_cpu_triples.cpp:48-55).
+    """
+    return torch_rw_native.walk_triples(triples_indexed, relation_tail_index, target_nodes, walk_length,
+                                        padding_idx, restart, seed)
+
+
+def walk_triples_ex(triples_indexed, relation_tail_index, target_nodes, walk_length, padding_idx, seed,
+                    restart=True, walker_base=0, rng_mode=RNG_AUTO, check=True):
+    """``walk_triples`` with an explicit global walker base and RNG mode (see ``walk_ex``)."""
+    return torch_rw_native.walk_triples_ex(triples_indexed, relation_tail_index, target_nodes, walk_length,
+                                           padding_idx, restart, seed, walker_base, rng_mode, check)

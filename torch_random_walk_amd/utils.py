@@ -23,3 +23,34 @@ def nodes_tensor(graph):
     """``[0 .. n)`` as an int64 tensor (torch_rw/utils.py:11-18: the index of every
     node in ``graph.nodes()`` order, which is its position)."""
     return torch.arange(graph.number_of_nodes(), dtype=torch.int64)
+
+
+def build_relation_tail_index(triples_indexed_tensor, all_entities_tensor):
+    """Sort the triples by head and index them: returns ``(relation_tail_index, triples_sorted)``.
+
+    Reference: torch_rw/utils.py:91-120 -- a pandas sort by head followed by a per-triple Python loop that
+    records, for every entity id, the inclusive (first, last) position of its triples, ``(-1, -1)`` when
+    it heads none.  This is the same result from one stable sort and two scatters (the order of
+    triples that share a head is their input order, which is what the reference's golden walks
+    assume, tests/test_rw_triples.py:70-79); works on any device.
+    """
+    triples = triples_indexed_tensor.to(torch.int64)
+    num_nodes = int(all_entities_tensor.numel())
+    heads = triples[:, 0].contiguous()
+    order = torch.sort(heads, stable=True).indices
+    triples_sorted = triples[order].contiguous()
+    heads = triples_sorted[:, 0]
+    num_edges = int(heads.numel())
+    index = torch.full((num_nodes, 2), -1, dtype=torch.int64, device=triples.device)
+    if num_edges == 0:
+        return index, triples_sorted
+    pos = torch.arange(num_edges, dtype=torch.int64, device=triples.device)
+    is_first = torch.ones(num_edges, dtype=torch.bool, device=triples.device)
+    is_first[1:] = heads[1:] != heads[:-1]
+    is_last = torch.ones(num_edges, dtype=torch.bool, device=triples.device)
+    is_last[:-1] = heads[1:] != heads[:-1]
+    index[heads[is_first], 0] = pos[is_first]
+    index[heads[is_last], 1] = pos[is_last]
+    if num_edges == 1:
+        index[heads[0], 1] = -1  # the reference's loop never closes the range of a lone triple (utils.py:106-118)
+    return index, triples_sorted

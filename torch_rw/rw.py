@@ -1,2 +1,3 @@
 from torch_random_walk_amd.rw import *  # noqa: F401,F403
 from torch_random_walk_amd.rw import walk, walk_ex, set_rng_mode, get_rng_mode, set_check  # noqa: F401
+from torch_random_walk_amd.rw import walk_triples, walk_triples_ex  # noqa: F401
