@@ -16,6 +16,7 @@ Workloads (BASELINE.json `configs`):
                                the graph the north-star target is quoted on)
   rmat10m_uniform  same graph, p=q=1 (reference-exact glibc draws)
   er100k_uniform   configs[1]  Erdos-Renyi 100k nodes / 1M edges, p=q=1, L=80, 10 walks per node
+  kg5m_triples     configs[4]  synthetic KG, 5M triples / 1M entities / 1000 relations, walk_triples, L=80
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the walk
 kernel), its duration measured with HIP events on the launch stream through the
@@ -40,6 +41,10 @@ WORKLOADS = {
     "rmat10m_biased": dict(graph="rmat", nodes=10_000_000, edges=100_000_000, p=0.25, q=4.0, walks_per_node=1),
     "rmat10m_uniform": dict(graph="rmat", nodes=10_000_000, edges=100_000_000, p=1.0, q=1.0, walks_per_node=1),
     "er100k_uniform": dict(graph="er", nodes=100_000, edges=1_000_000, p=1.0, q=1.0, walks_per_node=10),
+    # BASELINE configs[4]: knowledge-graph triples path (the reference's triples walk is uniform only,
+    # torch_rw/rw.py:18 / rw_cpu_triples.cpp:105-127 -- there is no biased triples walk to reproduce)
+    "kg5m_triples": dict(graph="kg", nodes=1_000_000, edges=5_000_000, relations=1000, p=1.0, q=1.0,
+                         walks_per_node=1),
     # small variants for quick checks / CI on the GPU box
     "rmat1m_biased": dict(graph="rmat", nodes=1_000_000, edges=10_000_000, p=0.25, q=4.0, walks_per_node=1),
     "rmat1m_uniform": dict(graph="rmat", nodes=1_000_000, edges=10_000_000, p=1.0, q=1.0, walks_per_node=1),
@@ -94,39 +99,53 @@ def main():
     p, q = cfg["p"], cfg["q"]
     uniform = (p == 1.0 and q == 1.0)
     n = cfg["nodes"]
+    kg = cfg["graph"] == "kg"
+    lib = _native.cabi()
 
     # ---- synthetic graph, generated on the device from a seed (identical on every rank) ----
     t0 = time.time()
-    if cfg["graph"] == "rmat":
+    if kg:
+        from torch_random_walk_amd import utils as trw_utils
+        triples, entities, pad = graphs.synthetic_kg(n, cfg["edges"], cfg["relations"], seed=args.graph_seed, device=dev)
+        rt_index, triples = trw_utils.build_relation_tail_index(triples, entities)
+        nnz = int(triples.shape[0])
+        cols = 2 * L + 1
+    elif cfg["graph"] == "rmat":
         row_ptr, col_idx = graphs.rmat(n, cfg["edges"], seed=args.graph_seed, device=dev)
     else:
         row_ptr, col_idx = graphs.erdos_renyi(n, cfg["edges"], seed=args.graph_seed, device=dev)
-    nnz = int(col_idx.numel())
+    if not kg:
+        nnz = int(col_idx.numel())
+        cols = L + 1
     targets = torch.arange(n, device=dev, dtype=torch.int64).repeat(cfg["walks_per_node"])
     B = int(targets.numel())          # walkers per GPU (fixed: weak scaling)
     walker_base = rank * B            # global walker index of this rank's first walker
     torch.cuda.synchronize()
     t_graph = time.time() - t0
 
-    mode = rw.RNG_GLIBC if uniform else rw.RNG_WALKER
+    mode = rw.RNG_WALKER if (kg or not uniform) else rw.RNG_GLIBC
     gather = (world > 1) and not args.no_gather
     full = None
     if gather and rank == 0:
-        full = torch.empty((world * B, L + 1), dtype=torch.int64, device="cpu" if dry else dev)
+        full = torch.empty((world * B, cols), dtype=torch.int64, device="cpu" if dry else dev)
+
+    def walk(tg, base, check):
+        if kg:
+            return rw.walk_triples_ex(triples, rt_index, tg, L, pad, args.seed, walker_base=base, rng_mode=mode,
+                                      check=check)
+        return rw.walk_ex(row_ptr, col_idx, tg, p, q, L, args.seed, walker_base=base, rng_mode=mode, check=check)
 
     def walk_once():
-        return rw.walk_ex(row_ptr, col_idx, targets, p, q, L, args.seed, walker_base=walker_base,
-                          rng_mode=mode, check=False)
+        return walk(targets, walker_base, False)
 
     def gather_async(walks):
-        """The one collective of the path: every rank's [B, L+1] block to rank 0 (RCCL gather)."""
+        """The one collective of the path: every rank's [B, cols] block to rank 0 (RCCL gather)."""
         if dry:
             walks = walks.cpu()
         if rank == 0:
             return dist.gather(walks, list(full.split(B, dim=0)), dst=0, async_op=True)
         return dist.gather(walks, None, dst=0, async_op=True)
 
-    lib = _native.cabi()
     for _ in range(args.warmup):
         walks = walk_once()
         if gather:
@@ -171,19 +190,26 @@ def main():
     elapsed = float(t.item())
 
     # ---- device-side status of the last step (validity of what was timed) -------------------
-    chk = rw.walk_ex(row_ptr, col_idx, targets[:1024], p, q, L, args.seed, walker_base=walker_base,
-                     rng_mode=mode, check=True)
+    chk = walk(targets[:1024], walker_base, True)
     assert torch.equal(chk, walks[:1024]), "timed output differs from a checked re-run"
     if gather and rank == 0:
         # the gathered blocks are exactly what each rank's global walker indices produce
         for r in range(world):
-            blk = rw.walk_ex(row_ptr, col_idx, targets[:256], p, q, L, args.seed, walker_base=r * B, rng_mode=mode)
+            blk = walk(targets[:256], r * B, True)
             assert torch.equal(blk.to(full.device), full[r * B: r * B + 256]), "gathered block %d is wrong" % r
 
     # ---- algorithmic bytes of one launch ----------------------------------------
     counters = None
-    if uniform:
+    if kg:
+        # per LIVE hop (not yet on the padding id / a dead end): 16 B index pair + 16 B (relation, tail);
+        # per hop 16 B stored; per walker 8 B target + 8 B column 0.  Hops after a dead end read nothing.
+        live_hops = int((walks[:, 1::2] != pad).sum())
+        counters = dict(live_hops=live_hops, hops=B * L)
+        alg_bytes = B * 16 + 32 * live_hops + 16 * B * L
+        kernel_name = "triples_walker_kernel"
+    elif uniform:
         alg_bytes = B * (16 + 32 * L)
+        kernel_name = "uniform_glibc_kernel"
     else:
         lib.trw_profile_enable(2)
         nbytes = lib.trw_walk_csr_workspace_bytes(n, nnz, B, L, p, q, mode)
@@ -198,16 +224,16 @@ def main():
         assert lib.trw_walk_counters(ws.data_ptr(), stream, c) == 0
         stw = (ctypes.c_int64 * 4)()
         assert lib.trw_walk_status(ws.data_ptr(), stream, stw) == 0
-        biased_kernel = {0: "biased_walker_wide_kernel", 1: "biased_walker_kernel", 2: "biased_hash_kernel"}[int(stw[3])]
+        kernel_name = {0: "biased_walker_wide_kernel", 1: "biased_walker_kernel", 2: "biased_hash_kernel"}[int(stw[3])]
         lib.trw_profile_enable(0)
         assert torch.equal(out, walks), "counting variant of the kernel produced different walks"
         trials, fetches, tests, probes = (int(x) for x in c)
-        counters = dict(trials=trials, candidate_loads=fetches, membership_tests=tests, bisect_entries=probes)
+        counters = dict(trials=trials, candidate_loads=fetches, membership_tests=tests, table_or_bisect_entries=probes)
         # int64-API-layout bytes the algorithm as run must move (with this kernel's
         # own counts): per walker 8 B target + 8 B column 0 + 32 B first step; per later step
         # 16 B row_ptr pair + 8 B stored column; 8 B per candidate entry actually loaded and per
-        # col_idx entry a bisection reads.  (The reference's own access pattern -- a candidate load
-        # and a linear row scan on every trial -- would count many times more.)
+        # table/col_idx entry a lookup reads.  (The reference's own access pattern -- a candidate load
+        # and a linear row scan on every trial -- counts many times more: roofline.reference_accounting.)
         alg_bytes = B * 16 + B * 32 + (L - 1) * B * (16 + 8) + 8 * fetches + 8 * probes
         del out, ws
 
@@ -229,31 +255,47 @@ def main():
     reference_accounting = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
-        rp_h, ci_h = row_ptr.cpu().numpy(), col_idx.cpu().numpy()
         g = torch.Generator().manual_seed(12345)
         perm = torch.randperm(B, generator=g)
-        probe = 500 if not uniform else 5000
-        tg_h = targets.cpu()[perm[:probe]].numpy()
-        _, dt = O.walk_timed(rp_h, ci_h, tg_h, p, q, L, args.seed, rng_mode=O.RNG_LIBC)
+        tg_cpu = targets.cpu()
+        if kg:
+            ts_h, ix_h = triples.cpu().numpy(), rt_index.cpu().numpy()
+
+            def cpu_run(tg_h):
+                return O.walk_triples(ts_h, ix_h, tg_h, L, pad, args.seed, rng_mode=O.RNG_LIBC, timed=True)[1]
+        else:
+            rp_h, ci_h = row_ptr.cpu().numpy(), col_idx.cpu().numpy()
+
+            def cpu_run(tg_h):
+                return O.walk_timed(rp_h, ci_h, tg_h, p, q, L, args.seed, rng_mode=O.RNG_LIBC)[1]
+        probe = 5000 if (uniform or kg) else 500
+        dt = cpu_run(tg_cpu[perm[:probe]].numpy())
         rate = probe * L / dt
         sample = int(min(B, max(probe, args.cpu_seconds * rate / L)))
-        tg_h = targets.cpu()[perm[:sample]].numpy()
-        _, dt = O.walk_timed(rp_h, ci_h, tg_h, p, q, L, args.seed, rng_mode=O.RNG_LIBC)
+        dt = cpu_run(tg_cpu[perm[:sample]].numpy())
         cpu = dict(value=sample * L / dt, unit="walk-steps/s", cores=1, kind="port",
                    sample="first %d start nodes of a seeded permutation of the batch, %d steps, %.1f s, "
                           "oracle libc srand/rand single thread (the reference's csrc/cpu algorithm; its "
                           "multi-threaded run is slower and non-deterministic, SURVEY 0.2)" % (sample, sample * L, dt))
-        if not uniform:
+        m = min(B, 2000)
+        if kg:
+            ref_w = O.walk_triples(ts_h, ix_h, tg_cpu[:m].numpy(), L, pad, args.seed, rng_mode=O.RNG_WALKER,
+                                   walker_base=walker_base)
+            assert (ref_w == walks[:m].cpu().numpy()).all(), "GPU rows differ from the oracle"
+        elif uniform:
+            ref_w = O.walk(rp_h, ci_h, tg_cpu[:m].numpy(), p, q, L, args.seed, rng_mode=O.RNG_GLIBC_INDEXED,
+                           walker_base=walker_base)
+            assert (ref_w == walks[:m].cpu().numpy()).all(), "GPU rows differ from the oracle"
+        else:
             # SURVEY 8(d) accounting: what the REFERENCE's loop reads for the same walks (a candidate on every
             # trial, is_neighbor on every candidate != t), from the oracle's counters on walkers 0..m-1 -- the
             # same walks the GPU produced for those rows -- scaled to the batch.
-            m = min(B, 2000)
-            ref_w, cnt = O.walk(rp_h, ci_h, targets.cpu()[:m].numpy(), p, q, L, args.seed, rng_mode=O.RNG_WALKER,
+            import numpy as np
+            ref_w, cnt = O.walk(rp_h, ci_h, tg_cpu[:m].numpy(), p, q, L, args.seed, rng_mode=O.RNG_WALKER,
                                 walker_base=walker_base, return_counters=True)
             assert (ref_w == walks[:m].cpu().numpy()).all(), "GPU rows differ from the oracle"
             scale = B / m
             deg_h = (rp_h[1:] - rp_h[:-1])
-            import numpy as np
             t_nodes = ref_w[:, :-2].reshape(-1)            # the `t` of every step >= 2
             log2deg = np.ceil(np.log2(np.maximum(deg_h[t_nodes], 2))).mean()
             trials_r, member_r, scan_r = cnt["trials_total"] * scale, cnt["membership_tests"] * scale, \
@@ -285,18 +327,20 @@ def main():
             "walks_per_s": world * B * args.steps / elapsed,
             "config": {
                 "workload": args.workload,
-                "graph": "%s nodes=%d directed_edges=%d (+ring) nnz=%d graph_seed=%d" % (
+                "graph": ("kg entities=%d triples=%d relations=%d graph_seed=%d" % (n, nnz, cfg["relations"],
+                                                                                      args.graph_seed)) if kg else
+                         "%s nodes=%d directed_edges=%d (+ring) nnz=%d graph_seed=%d" % (
                     cfg["graph"], n, cfg["edges"], nnz, args.graph_seed),
                 "p": p, "q": q, "walk_length": L, "seed": args.seed,
                 "walkers_per_gpu": B, "global_walkers": world * B,
-                "rng": "glibc-indexed (csrc/cpu-exact)" if uniform else "per-walker philox4x32-10",
+                "rng": "per-walker philox4x32-10" if mode == rw.RNG_WALKER else "glibc-indexed (csrc/cpu-exact)",
                 "partition": "start nodes block-sharded, CSR replicated",
                 "collective": ("one RCCL gather to rank 0 per step, inside the timed region, overlapped with the "
                                "next step's walk") if gather else "none",
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "uniform_glibc_kernel" if uniform else biased_kernel,
+                "kernel": kernel_name,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

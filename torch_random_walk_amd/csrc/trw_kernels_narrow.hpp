@@ -178,25 +178,38 @@ __global__ void __launch_bounds__(kBlock)
 transpose_rows_kernel(const uint32_t *__restrict__ stage, const int64_t *__restrict__ targets, int64_t n_nodes,
                       int64_t n_walkers, int32_t L, int32_t G, int64_t nlanes, int64_t *__restrict__ out)
 {
-    __shared__ uint32_t tile[64][65];
+    // tile[r][c]: lane r of the block, column c of the chunk; 66-word rows keep the 8-byte reads of the
+    // store phase aligned and conflict-free (the 2-way conflict of the 4-byte writes is free on CDNA4)
+    __shared__ uint32_t tile[64][66];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t lane0 = (int64_t)blockIdx.x * 64;
     const int32_t g = blockIdx.y;
     const int32_t cols = L + 1;
+    const bool lane_ok = lane0 + lane < nlanes;
     for (int32_t c0 = 0; c0 < cols; c0 += 64) {
         const int32_t nc = cols - c0 < 64 ? cols - c0 : 64;
-        for (int32_t cc = wave; cc < nc; cc += 4) {
-            const int64_t l = lane0 + lane;
-            tile[cc][lane] = l < nlanes ? stage[((int64_t)g * cols + c0 + cc) * nlanes + l] : 0u;
-        }
+        // plane reads: 16 independent 256-byte loads per wave in flight, then into the tile
+        uint32_t v[16];
+        const uint32_t *src = stage + ((int64_t)g * cols + c0 + wave) * nlanes + lane0 + lane;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = (lane_ok && wave + 4 * k < nc) ? src[(int64_t)(4 * k) * nlanes] : 0u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tile[lane][wave + 4 * k] = v[k];
         __syncthreads();
-        for (int32_t r = wave; r < 64; r += 4) {
+        // row writes: a half-wave per walker row, two columns (16 bytes) per lane
+        const int half = lane >> 5, j = lane & 31;
+#pragma unroll 4
+        for (int it = 0; it < 8; ++it) {
+            const int r = wave * 16 + 2 * it + half;
             const int64_t i = (lane0 + r) * G + g;
-            if (lane0 + r < nlanes && i < n_walkers && lane < nc) {
+            if (lane0 + r < nlanes && i < n_walkers && 2 * j < nc) {
                 const int64_t tg = targets[i];
                 const bool dead = (uint64_t)tg >= (uint64_t)n_nodes;  // reported by the walk kernel
-                out[i * cols + c0 + lane] = dead ? tg : (int64_t)tile[lane][r];
+                const uint2 ab = *reinterpret_cast<const uint2 *>(&tile[r][2 * j]);
+                int64_t *dst = out + i * cols + c0 + 2 * j;
+                dst[0] = dead ? tg : (int64_t)ab.x;
+                if (2 * j + 1 < nc) dst[1] = dead ? tg : (int64_t)ab.y;
             }
         }
         __syncthreads();
