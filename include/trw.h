@@ -144,6 +144,35 @@ int trw_walk_triples_hip(const int64_t *triples, int64_t n_triples,
                          int32_t walk_length, int64_t padding_idx, int32_t seed, int32_t rng_mode,
                          int64_t *out, void *workspace, size_t workspace_bytes, void *hip_stream);
 
+/*
+ * The edge-list walk.  Replaces the reference's
+ *     torch::Tensor walk_edge_list_gpu(edge_list_indexed, node_edges_idx, target_nodes, p, q,
+ *                                      walk_length, seed, padding_idx, restart)
+ * (csrc/cuda/rw_cuda_edge_list.h:4-12, called from csrc/rw_init.cpp:39-40) and produces what
+ * walk_edge_list_cpu (csrc/cpu/rw_cpu_edge_list.cpp:240-265) produces.
+ *
+ *   edges            [n_edges][2] int64 (head, tail) sorted by head            (reference arg 1)
+ *   node_edge_index  [n_nodes][2] int64 inclusive (first, last) edge per head,
+ *                                 (-1,-1) for a node without out-edges          (reference arg 2)
+ *   targets          [n_walkers]  int64 start nodes                             (reference arg 3)
+ *   padding_idx, restart          a dead end steps to padding_idx; from padding_idx the walk goes to the
+ *                                 start node (restart != 0) or stays on padding_idx
+ *   out              [n_walkers][walk_length+1] int64
+ * rng_mode as for the CSR walk (hops from single-edge nodes and from padding consume no draw, so
+ * even the uniform walk's stream positions are data dependent): TRW_RNG_GLIBC replays the
+ * reference's serial stream with one lane (walker_base == 0), TRW_RNG_WALKER is the per-walker
+ * stream, TRW_RNG_AUTO picks GLIBC for walker_base == 0, n_walkers within the reference's
+ * parallel_for grain (32768 uniform, 32768/(walk_length+1) biased) and n_walkers*walk_length <= 2^18.
+ */
+size_t trw_walk_edge_list_workspace_bytes(int64_t n_edges, int64_t n_nodes, int64_t n_walkers,
+                                          int32_t walk_length, int64_t padding_idx, int32_t rng_mode);
+int trw_walk_edge_list_hip(const int64_t *edges, int64_t n_edges,
+                           const int64_t *node_edge_index, int64_t n_nodes,
+                           const int64_t *targets, int64_t n_walkers, int64_t walker_base,
+                           double p, double q, int32_t walk_length, int32_t seed,
+                           int64_t padding_idx, int32_t restart, int32_t rng_mode,
+                           int64_t *out, void *workspace, size_t workspace_bytes, void *hip_stream);
+
 /* Synchronises `hip_stream` and copies the status block of the last walk that
  * used `workspace` to the host: status[0] = OR of TRW_ST_* bits,
  * status[1] = 1 if some CSR row was found unsorted (biased walks only; the

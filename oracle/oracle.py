@@ -83,6 +83,11 @@ def lib():
             i64p, ctypes.c_int64, i64p, ctypes.c_int64, i64p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
             ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, i64p, ctypes.POINTER(ctypes.c_uint64)]
         L.trw_oracle_walk_triples.restype = ctypes.c_int
+        L.trw_oracle_walk_edge_list.argtypes = [
+            i64p, ctypes.c_int64, i64p, ctypes.c_int64, i64p, ctypes.c_int64, ctypes.c_int64, ctypes.c_double,
+            ctypes.c_double, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, i64p,
+            ctypes.POINTER(ctypes.c_uint64)]
+        L.trw_oracle_walk_edge_list.restype = ctypes.c_int
         _lib = L
     return _lib
 
@@ -207,6 +212,27 @@ def walk_triples(triples_indexed, relation_tail_index, target_nodes, walk_length
         raise OracleError(rc)
     if timed:
         return out, dt
+    if return_draws:
+        return out, int(draws.value)
+    return out
+
+
+def walk_edge_list(edge_list_indexed, node_edge_index, target_nodes, p, q, walk_length, seed, padding_idx,
+                   restart=True, rng_mode=RNG_GLIBC_SEQ, walker_base=0, return_draws=False):
+    """The reference's ``walk_edge_list_cpu`` restated: ``[N, walk_length+1]`` int64."""
+    ed = np.ascontiguousarray(np.asarray(edge_list_indexed), dtype=np.int64).reshape(-1, 2)
+    ix = np.ascontiguousarray(np.asarray(node_edge_index), dtype=np.int64).reshape(-1, 2)
+    tg, tg_p = _i64(target_nodes)
+    n = int(tg.shape[0])
+    out = np.empty((n, int(walk_length) + 1), dtype=np.int64)
+    draws = ctypes.c_uint64(0)
+    p64 = ctypes.POINTER(ctypes.c_int64)
+    rc = lib().trw_oracle_walk_edge_list(ed.ctypes.data_as(p64), ed.shape[0], ix.ctypes.data_as(p64), ix.shape[0],
+                                         tg_p, n, int(walker_base), float(p), float(q), int(walk_length), int(seed),
+                                         int(padding_idx), 1 if restart else 0, int(rng_mode),
+                                         out.ctypes.data_as(p64), ctypes.byref(draws))
+    if rc != 0:
+        raise OracleError(rc)
     if return_draws:
         return out, int(draws.value)
     return out

@@ -434,3 +434,115 @@ int trw_oracle_walk_triples(const int64_t *triples, int64_t n_triples,
     if (draws_total) *draws_total = rng.ndraws;
     return err;
 }
+
+/* ------------------------------------------------------------------------ */
+/* Edge-list walk                                                             */
+/* ------------------------------------------------------------------------ */
+
+typedef struct {
+    const int64_t *edges, *index;
+    int64_t n_edges, n_nodes, padding;
+    int err;
+} elist_t;
+
+/* sample_neighbor, rw_cpu_edge_list.cpp:8-35 */
+static int64_t el_sample_neighbor(elist_t *g, int64_t node, int64_t jump_node, rng_t *rng)
+{
+    if (node == g->padding) return jump_node; /* :31-34 */
+    if (node < 0 || node >= g->n_nodes) { g->err = TRW_ORACLE_E_RANGE; return g->padding; }
+    const int64_t start_index = g->index[2 * node], end_index = g->index[2 * node + 1];
+    if (start_index == -1 || end_index == -1) return g->padding; /* :21-22 */
+    int64_t e = start_index; /* sample_int */
+    if (start_index != end_index) {
+        const int64_t span = (end_index + 1) - start_index;
+        if (span <= 0) { g->err = TRW_ORACLE_E_ARG; return g->padding; }
+        e = start_index + ((int64_t)rng_next(rng) % span);
+    }
+    if (e < 0 || e >= g->n_edges) { g->err = TRW_ORACLE_E_RANGE; return g->padding; }
+    return g->edges[2 * e + 1];
+}
+
+/* is_neighbor, rw_cpu_edge_list.cpp:37-62: scans [start, end), i.e. never the last edge */
+static int el_is_neighbor(elist_t *g, int64_t new_node, int64_t previous_node)
+{
+    if (previous_node < 0 || previous_node >= g->n_nodes) return 0; /* the reference reads out of bounds here */
+    const int64_t start_index = g->index[2 * previous_node], end_index = g->index[2 * previous_node + 1];
+    if (start_index == -1 || end_index == -1) return 0;
+    for (int64_t i = start_index; i < end_index; ++i) {
+        if (i < 0 || i >= g->n_edges) { g->err = TRW_ORACLE_E_RANGE; return 0; }
+        if (g->edges[2 * i + 1] == new_node) return 1;
+    }
+    return 0;
+}
+
+int trw_oracle_walk_edge_list(const int64_t *edges, int64_t n_edges,
+                              const int64_t *index, int64_t n_nodes,
+                              const int64_t *targets, int64_t n_walkers,
+                              int64_t walker_base, double p, double q,
+                              int32_t walk_length, int32_t seed,
+                              int64_t padding_idx, int32_t restart, int32_t rng_mode,
+                              int64_t *out, uint64_t *draws_total)
+{
+    if ((!edges && n_edges) || (!index && n_nodes) || (!targets && n_walkers) || (!out && n_walkers))
+        return TRW_ORACLE_E_ARG;
+    if (n_edges < 0 || n_nodes < 0 || n_walkers < 0 || walker_base < 0 || walk_length < 1) return TRW_ORACLE_E_ARG;
+    if (rng_mode != TRW_ORACLE_RNG_GLIBC_SEQ && rng_mode != TRW_ORACLE_RNG_LIBC && rng_mode != TRW_ORACLE_RNG_WALKER)
+        return TRW_ORACLE_E_ARG;
+    if (rng_mode != TRW_ORACLE_RNG_WALKER && walker_base != 0) return TRW_ORACLE_E_ARG;
+
+    elist_t g = { edges, index, n_edges, n_nodes, padding_idx, 0 };
+    rng_t rng;
+    memset(&rng, 0, sizeof rng);
+    rng.mode = rng_mode;
+    rng.seed = seed;
+    if (rng_mode == TRW_ORACLE_RNG_LIBC) srand((unsigned)seed); /* :73 / :140 */
+    else if (rng_mode == TRW_ORACLE_RNG_GLIBC_SEQ) glibc_init(&rng.gl, seed);
+
+    const int uniform = (p == 1.0 && q == 1.0); /* :260 */
+    double prob[3];
+    trw_oracle_probs(p, q, prob); /* :158-162 */
+    const int64_t walk_size = (int64_t)walk_length + 1;
+
+    for (int64_t i = 0; i < n_walkers && !g.err; ++i) {
+        int64_t *walk = out + i * walk_size;
+        rng_begin_walker(&rng, (uint64_t)walker_base + (uint64_t)i, walk_length);
+        const int64_t target_node = targets[i];
+        const int64_t jump_node = restart ? target_node : padding_idx; /* :103-108 */
+        walk[0] = target_node;
+        if (uniform) {
+            int64_t previous_node = target_node;
+            for (int64_t s = 1; s < walk_size; ++s) {
+                const int64_t next_node = el_sample_neighbor(&g, previous_node, jump_node, &rng);
+                walk[s] = next_node;
+                previous_node = next_node;
+            }
+        } else {
+            walk[1] = el_sample_neighbor(&g, target_node, jump_node, &rng);
+            int64_t previous_node = walk[1];
+            for (int64_t s = 2; s < walk_size && !g.err; ++s) {
+                int64_t selected_node = -1;
+                const int64_t t_node = walk[s - 2];
+                while (1) {
+                    const int64_t new_node = el_sample_neighbor(&g, previous_node, jump_node, &rng);
+                    const double random_prob = ((double)rng_next(&rng) / (double)RAND_MAX);
+                    if (g.err) { selected_node = new_node; break; }
+                    if (new_node == t_node) { /* :204-209, not chained with what follows */
+                        if (random_prob < prob[0]) { selected_node = new_node; break; }
+                    }
+                    if (new_node == padding_idx) { /* :212-217 */
+                        if (random_prob < prob[0]) { selected_node = jump_node; break; }
+                    } else if (el_is_neighbor(&g, new_node, t_node)) { /* :220-225 */
+                        if (random_prob < prob[1]) { selected_node = new_node; break; }
+                    } else if (random_prob < prob[2]) { /* :228-231 */
+                        selected_node = new_node;
+                        break;
+                    }
+                }
+                walk[s] = selected_node;
+                previous_node = selected_node;
+            }
+        }
+    }
+    if (draws_total) *draws_total = rng.ndraws;
+    return g.err;
+}

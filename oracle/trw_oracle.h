@@ -129,6 +129,31 @@ int trw_oracle_walk_triples(const int64_t *triples, int64_t n_triples,
                             int64_t padding_idx, int32_t seed, int32_t rng_mode,
                             int64_t *out, uint64_t *draws_total);
 
+/*
+ * walk_edge_list_cpu restated (csrc/cpu/rw_cpu_edge_list.cpp:240-265 ->
+ * uniform_walk_edge_list :64-126 or biased_walk_edge_list :128-238,
+ * sample_neighbor :8-35, is_neighbor :37-62, sample_int cpu_utils.cpp:3-10).
+ *
+ *   edges    [n_edges][2] int64 (head, tail), sorted by head
+ *   index    [n_nodes][2] int64 inclusive (first, last) edge per head, (-1,-1) if none
+ *   out      [n_walkers][walk_length+1]
+ * Kept from the reference: a dead-end node steps to padding_idx; a step from
+ * padding_idx goes to the jump node (the start node if `restart`, else padding)
+ * without a draw; is_neighbor scans [first, last) -- it never looks at a head's
+ * LAST edge (:51); in the biased loop the `new == t` test is a separate `if`, so a
+ * rejected return to t is tested again as neighbour / non-neighbour (:204-231).
+ * Where the reference indexes node_edge_index with the padding id (t == padding,
+ * an out-of-bounds read when padding_idx >= n_nodes) this restatement answers
+ * "not a neighbour".
+ */
+int trw_oracle_walk_edge_list(const int64_t *edges, int64_t n_edges,
+                              const int64_t *index, int64_t n_nodes,
+                              const int64_t *targets, int64_t n_walkers,
+                              int64_t walker_base, double p, double q,
+                              int32_t walk_length, int32_t seed,
+                              int64_t padding_idx, int32_t restart, int32_t rng_mode,
+                              int64_t *out, uint64_t *draws_total);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,11 @@ def cabi():
         L.trw_walk_triples_hip.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, i64, i32, i32, vp, vp,
                                            ctypes.c_size_t, vp]
         L.trw_walk_triples_hip.restype = ctypes.c_int
+        L.trw_walk_edge_list_workspace_bytes.argtypes = [i64, i64, i64, i32, i64, i32]
+        L.trw_walk_edge_list_workspace_bytes.restype = ctypes.c_size_t
+        L.trw_walk_edge_list_hip.argtypes = [vp, i64, vp, i64, vp, i64, i64, dbl, dbl, i32, i32, i64, i32, i32, vp,
+                                             vp, ctypes.c_size_t, vp]
+        L.trw_walk_edge_list_hip.restype = ctypes.c_int
         L.trw_walk_status.argtypes = [vp, vp, ctypes.POINTER(i64)]
         L.trw_walk_status.restype = ctypes.c_int
         L.trw_accept_threshold.argtypes = [dbl]

@@ -171,6 +171,66 @@ torch::Tensor walk_triples(const torch::Tensor &triples_indexed, const torch::Te
                            0, g_rng_mode.load(), g_check.load());
 }
 
+// walk_edge_list: reference dispatcher csrc/rw_init.cpp:27-45, same argument order.
+torch::Tensor walk_edge_list_ex(const torch::Tensor &edge_list_indexed, const torch::Tensor &node_edges_idx,
+                                const torch::Tensor &target_nodes, double p, double q, int64_t walk_length,
+                                int64_t seed, int64_t padding_idx, bool restart, int64_t walker_base,
+                                int64_t rng_mode, bool check)
+{
+    check_index_tensor(target_nodes, "target_nodes");
+    for (const auto *t : {&edge_list_indexed, &node_edges_idx}) {
+        TORCH_CHECK(t->is_cuda(), "edge_list_indexed and node_edge_index must be CUDA tensors (torch_rw_native here "
+                                  "is the MI355X HIP build; it has no CPU walker)");
+        TORCH_CHECK(t->scalar_type() == torch::kInt64, "expected scalar type Long but found ",
+                    c10::toString(t->scalar_type()));
+        TORCH_CHECK(t->dim() == 2 && t->size(1) == 2, "edge_list_indexed / node_edge_index must be [*, 2]");
+    }
+    TORCH_CHECK(edge_list_indexed.device() == target_nodes.device() && node_edges_idx.device() == target_nodes.device(),
+                "edge_list_indexed, node_edge_index and target_nodes must be on the same device");
+    TORCH_CHECK(walk_length >= 1, "walk_length must be >= 1, got ", walk_length);
+    TORCH_CHECK(walk_length < (int64_t(1) << 31) && seed >= INT32_MIN && seed <= INT32_MAX,
+                "walk_length/seed must fit the reference's int arguments");
+
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(target_nodes.device());
+    const auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(target_nodes.device().index());
+    const auto ed = edge_list_indexed.contiguous();
+    const auto ix = node_edges_idx.contiguous();
+    const auto tg = target_nodes.contiguous();
+    const int64_t n_edges = ed.size(0), n_nodes = ix.size(0), n_walkers = tg.numel();
+    auto walks = torch::empty({n_walkers, walk_length + 1}, tg.options());
+    const size_t ws_bytes = trw_walk_edge_list_workspace_bytes(n_edges, n_nodes, n_walkers, (int32_t)walk_length,
+                                                               padding_idx, (int32_t)rng_mode);
+    auto workspace = torch::empty({(int64_t)ws_bytes}, tg.options().dtype(torch::kUInt8));
+    int rc;
+    {
+        pybind11::gil_scoped_release nogil;
+        rc = trw_walk_edge_list_hip(ed.data_ptr<int64_t>(), n_edges, ix.data_ptr<int64_t>(), n_nodes,
+                                    tg.data_ptr<int64_t>(), n_walkers, walker_base, p, q, (int32_t)walk_length,
+                                    (int32_t)seed, padding_idx, restart ? 1 : 0, (int32_t)rng_mode,
+                                    walks.data_ptr<int64_t>(), workspace.data_ptr(), ws_bytes,
+                                    (void *)stream.stream());
+    }
+    TORCH_CHECK(rc == TRW_OK, "torch_rw walk_edge_list failed (", rc, "): ", trw_last_error());
+    if (check) {
+        int64_t status[4] = {0, 0, 0, 0};
+        {
+            pybind11::gil_scoped_release nogil;
+            rc = trw_walk_status(workspace.data_ptr(), (void *)stream.stream(), status);
+        }
+        TORCH_CHECK(rc == TRW_OK, "torch_rw status read failed (", rc, "): ", trw_last_error());
+        TORCH_CHECK(status[0] == 0, "torch_rw walk_edge_list: ", status_text(status[0]), "status bits ", status[0]);
+    }
+    return walks;
+}
+
+torch::Tensor walk_edge_list(const torch::Tensor &edge_list_indexed, const torch::Tensor &node_edges_idx,
+                             const torch::Tensor &target_nodes, const double p, const double q, const int walk_length,
+                             const int seed, const int64_t padding_idx, const bool restart)
+{
+    return walk_edge_list_ex(edge_list_indexed, node_edges_idx, target_nodes, p, q, walk_length, seed, padding_idx,
+                             restart, 0, g_rng_mode.load(), g_check.load());
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
@@ -181,6 +241,14 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("walk_ex", &walk_ex, "walk with an explicit global walker base, RNG mode and status check",
           pybind11::arg("row_ptr"), pybind11::arg("col_idx"), pybind11::arg("target_nodes"), pybind11::arg("p"),
           pybind11::arg("q"), pybind11::arg("walk_length"), pybind11::arg("seed"), pybind11::arg("walker_base") = 0,
+          pybind11::arg("rng_mode") = (int64_t)TRW_RNG_AUTO, pybind11::arg("check") = true);
+    m.def("walk_edge_list", &walk_edge_list, "walk_edge_list", pybind11::arg("edge_list_indexed"),
+          pybind11::arg("node_edge_index"), pybind11::arg("target_nodes"), pybind11::arg("p"), pybind11::arg("q"),
+          pybind11::arg("walk_length"), pybind11::arg("seed"), pybind11::arg("padding_idx"), pybind11::arg("restart"));
+    m.def("walk_edge_list_ex", &walk_edge_list_ex, "walk_edge_list with a global walker base, RNG mode, status check",
+          pybind11::arg("edge_list_indexed"), pybind11::arg("node_edge_index"), pybind11::arg("target_nodes"),
+          pybind11::arg("p"), pybind11::arg("q"), pybind11::arg("walk_length"), pybind11::arg("seed"),
+          pybind11::arg("padding_idx"), pybind11::arg("restart"), pybind11::arg("walker_base") = 0,
           pybind11::arg("rng_mode") = (int64_t)TRW_RNG_AUTO, pybind11::arg("check") = true);
     m.def("walk_triples", &walk_triples, "walk_triples", pybind11::arg("triples_indexed"),
           pybind11::arg("relation_tail_index"), pybind11::arg("target_nodes"), pybind11::arg("walk_length"),

@@ -29,6 +29,7 @@
 #include "trw_kernels_wide.hpp"
 #include "trw_kernels_narrow.hpp"
 #include "trw_kernels_triples.hpp"
+#include "trw_kernels_edgelist.hpp"
 
 namespace {
 
@@ -236,6 +237,44 @@ int resolve_triples_mode(int32_t rng_mode, int64_t n_walkers, int64_t walker_bas
     // (rw_cpu_triples.cpp:67); the serial replay is one lane, so it is also kept to small jobs
     return (walker_base == 0 && n_walkers <= 32768 && n_walkers * (int64_t)L <= ((int64_t)1 << 18)) ? TRW_RNG_GLIBC
                                                                                                     : TRW_RNG_WALKER;
+}
+}  // namespace
+
+namespace {
+struct EdgeListPlan {
+    bool narrow = false;
+    size_t off_tail32 = 0, off_ix32 = 0, off_stage = 0, total = 0;
+};
+
+EdgeListPlan make_elist_plan(int64_t n_edges, int64_t n_nodes, int64_t n_walkers, int32_t L, int64_t padding_idx,
+                             int32_t rng_mode)
+{
+    EdgeListPlan pl;
+    size_t off = kStatusBytes;
+    const bool fits = n_nodes < ((int64_t)1 << 31) && n_edges < ((int64_t)1 << 32) - 64 && padding_idx >= 0 &&
+                      padding_idx < ((int64_t)1 << 31) && env_long("TRW_FORCE_WIDE", 0, 1, 0) == 0;
+    pl.narrow = fits && rng_mode != TRW_RNG_GLIBC && n_walkers > 0 && L >= 1;
+    if (pl.narrow) {
+        pl.off_tail32 = off;
+        off += align_up((size_t)n_edges * 4 + 64, 256);
+        pl.off_ix32 = off;
+        off += align_up((size_t)n_nodes * 8 + 64, 256);
+        pl.off_stage = off;
+        off += align_up((size_t)n_walkers * ((size_t)L + 1) * sizeof(uint32_t), 256);
+    }
+    pl.total = off;
+    return pl;
+}
+
+int resolve_elist_mode(int32_t rng_mode, bool uniform, int64_t n_walkers, int64_t walker_base, int32_t L)
+{
+    if (rng_mode == TRW_RNG_GLIBC || rng_mode == TRW_RNG_WALKER) return rng_mode;
+    if (rng_mode != TRW_RNG_AUTO) return -1;
+    // rw_cpu_edge_list.cpp:83 / :149: the reference is deterministic up to its parallel_for grain; the
+    // serial replay is one lane, so it is also kept to small jobs
+    const int64_t grain = uniform ? 32768 : 32768 / ((int64_t)L + 1);
+    return (walker_base == 0 && n_walkers <= grain && n_walkers * (int64_t)L <= ((int64_t)1 << 18)) ? TRW_RNG_GLIBC
+                                                                                                   : TRW_RNG_WALKER;
 }
 }  // namespace
 
@@ -519,6 +558,107 @@ int trw_walk_triples_hip(const int64_t *triples, int64_t n_triples, const int64_
         transpose_rows_kernel<<<grid, kBlock, 0, stream>>>((const uint32_t *)(ws + pl.off_stage), targets,
                                                           padding_idx >= n_entities ? padding_idx + 1 : n_entities,
                                                           n_walkers, 2 * walk_length, 1, n_walkers, out);
+    }
+    prof_mark(3, stream);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "kernel launch");
+    return TRW_OK;
+}
+
+// ---- edge-list walk, reference csrc/cpu/rw_cpu_edge_list.cpp -------------------------------------
+
+size_t trw_walk_edge_list_workspace_bytes(int64_t n_edges, int64_t n_nodes, int64_t n_walkers, int32_t walk_length,
+                                          int64_t padding_idx, int32_t rng_mode)
+{
+    if (n_edges < 0 || n_nodes < 0) return kStatusBytes;
+    return make_elist_plan(n_edges, n_nodes, n_walkers, walk_length, padding_idx, rng_mode).total;
+}
+
+int trw_walk_edge_list_hip(const int64_t *edges, int64_t n_edges, const int64_t *node_edge_index, int64_t n_nodes,
+                           const int64_t *targets, int64_t n_walkers, int64_t walker_base, double p, double q,
+                           int32_t walk_length, int32_t seed, int64_t padding_idx, int32_t restart, int32_t rng_mode,
+                           int64_t *out, void *workspace, size_t workspace_bytes, void *hip_stream)
+{
+    t_last_error.clear();
+    if (n_edges < 0 || n_nodes < 0 || n_walkers < 0 || walker_base < 0)
+        return fail(TRW_E_ARG, "negative size argument");
+    if (walk_length < 1) return fail(TRW_E_ARG, "walk_length must be >= 1");
+    if (!(p > 0.0) || !(q > 0.0) || !std::isfinite(p) || !std::isfinite(q))
+        return fail(TRW_E_ARG, "p and q must be positive and finite");
+    if (n_edges > 0 && !edges) return fail(TRW_E_ARG, "edge_list_indexed is null");
+    if (n_nodes > 0 && !node_edge_index) return fail(TRW_E_ARG, "node_edge_index is null");
+    if (n_walkers > 0 && (!targets || !out)) return fail(TRW_E_ARG, "targets/out is null");
+    if (!workspace || workspace_bytes < (size_t)kStatusBytes)
+        return fail(TRW_E_WORKSPACE, "workspace missing or smaller than the status block");
+    if (((uintptr_t)workspace & 15u) != 0) return fail(TRW_E_WORKSPACE, "workspace must be 16-byte aligned");
+    const bool uniform = (p == 1.0 && q == 1.0);  // rw_cpu_edge_list.cpp:260
+    const int mode = resolve_elist_mode(rng_mode, uniform, n_walkers, walker_base, walk_length);
+    if (mode < 0) return fail(TRW_E_RNG_MODE, "unknown rng_mode");
+    if (mode == TRW_RNG_GLIBC && walker_base != 0)
+        return fail(TRW_E_RNG_MODE, "TRW_RNG_GLIBC edge-list walks replay one serial stream: walker_base must be 0");
+
+    hipStream_t stream = (hipStream_t)hip_stream;
+    int64_t *status = (int64_t *)workspace;
+    hipError_t e = hipMemsetAsync(status, 0, kStatusBytes, stream);
+    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(status)");
+    if (n_walkers == 0) return TRW_OK;
+
+    const EdgeListPlan pl = make_elist_plan(n_edges, n_nodes, n_walkers, walk_length, padding_idx, mode);
+    if (workspace_bytes < pl.total) return fail(TRW_E_WORKSPACE, "workspace too small for this call shape");
+    char *ws = (char *)workspace;
+    const unsigned walker_grid = (unsigned)((n_walkers + kBlock - 1) / kBlock);
+
+    BiasedParams bp = {0, 0, 0, 0, 0};
+    {
+        const double max_prob_init = std::fmax(1.0 / p, 1);  // rw_cpu_edge_list.cpp:158-162
+        const double max_prob = std::fmax(max_prob_init, 1.0 / q);
+        bp.t0 = trw_accept_threshold(1.0 / p / max_prob);
+        bp.t1 = trw_accept_threshold(1.0 / max_prob);
+        bp.t2 = trw_accept_threshold(1.0 / q / max_prob);
+        bp.lo = bp.t1 < bp.t2 ? bp.t1 : bp.t2;
+        bp.hi = bp.t1 < bp.t2 ? bp.t2 : bp.t1;
+    }
+    EdgeListView<false> wide = {edges, node_edge_index, nullptr, nullptr, n_edges, n_nodes};
+    EdgeListView<true> narrow = {nullptr, nullptr, (const uint32_t *)(ws + pl.off_tail32),
+                                 (const u32x2_a8 *)(ws + pl.off_ix32), n_edges, n_nodes};
+    uint32_t *stage = (uint32_t *)(ws + pl.off_stage);
+
+    prof_mark(0, stream);
+    if (pl.narrow)
+        elist_shadow_kernel<<<stream_grid(n_edges > n_nodes ? n_edges : n_nodes), kBlock, 0, stream>>>(
+            edges, n_edges, node_edge_index, n_nodes, padding_idx, (uint32_t *)(ws + pl.off_tail32),
+            (u32x2_a8 *)(ws + pl.off_ix32), status);
+    prof_mark(1, stream);
+    if (mode == TRW_RNG_GLIBC) {
+        SeedWindow sw;
+        trw::seed_window(seed, sw.w);
+        elist_glibc_seq_kernel<<<1, 64, 0, stream>>>(wide, targets, n_walkers, walk_length, padding_idx, restart,
+                                                    uniform ? 0 : 1, sw, bp, out, status);
+    } else if (pl.narrow) {
+        if (uniform)
+            elist_walk_kernel<false, true><<<walker_grid, kBlock, 0, stream>>>(
+                narrow, targets, n_walkers, walker_base, walk_length, padding_idx, restart, (uint32_t)seed, bp, stage,
+                out, status);
+        else
+            elist_walk_kernel<true, true><<<walker_grid, kBlock, 0, stream>>>(
+                narrow, targets, n_walkers, walker_base, walk_length, padding_idx, restart, (uint32_t)seed, bp, stage,
+                out, status);
+    } else {
+        if (uniform)
+            elist_walk_kernel<false, false><<<walker_grid, kBlock, 0, stream>>>(
+                wide, targets, n_walkers, walker_base, walk_length, padding_idx, restart, (uint32_t)seed, bp, stage,
+                out, status);
+        else
+            elist_walk_kernel<true, false><<<walker_grid, kBlock, 0, stream>>>(
+                wide, targets, n_walkers, walker_base, walk_length, padding_idx, restart, (uint32_t)seed, bp, stage,
+                out, status);
+    }
+    prof_mark(2, stream);
+    if (pl.narrow && mode == TRW_RNG_WALKER) {
+        const dim3 grid((unsigned)((n_walkers + 63) / 64), 1u);
+        transpose_rows_kernel<<<grid, kBlock, 0, stream>>>(stage, targets,
+                                                          padding_idx >= n_nodes ? padding_idx + 1 : n_nodes,
+                                                          n_walkers, walk_length, 1, n_walkers, out);
     }
     prof_mark(3, stream);
     e = hipGetLastError();

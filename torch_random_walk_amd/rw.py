@@ -60,3 +60,19 @@ def walk_triples_ex(triples_indexed, relation_tail_index, target_nodes, walk_len
     """``walk_triples`` with an explicit global walker base and RNG mode (see ``walk_ex``)."""
     return torch_rw_native.walk_triples_ex(triples_indexed, relation_tail_index, target_nodes, walk_length,
                                            padding_idx, restart, seed, walker_base, rng_mode, check)
+
+
+def walk_edge_list(edge_list_indexed, node_edge_index, target_nodes, p, q, walk_length, seed, padding_idx,
+                   restart=True):
+    """Walks over an edge list ``[E, 2]`` sorted by head + ``node_edge_index`` from
+    ``utils.build_node_edge_index``; dead ends step to ``padding_idx`` and, if ``restart``, the walk
+    then jumps back to its start node.  Same surface as the reference (torch_rw/rw.py:6-16)."""
+    return torch_rw_native.walk_edge_list(edge_list_indexed, node_edge_index, target_nodes, p, q, walk_length, seed,
+                                          padding_idx, restart)
+
+
+def walk_edge_list_ex(edge_list_indexed, node_edge_index, target_nodes, p, q, walk_length, seed, padding_idx,
+                      restart=True, walker_base=0, rng_mode=RNG_AUTO, check=True):
+    """``walk_edge_list`` with an explicit global walker base and RNG mode (see ``walk_ex``)."""
+    return torch_rw_native.walk_edge_list_ex(edge_list_indexed, node_edge_index, target_nodes, p, q, walk_length, seed,
+                                             padding_idx, restart, walker_base, rng_mode, check)
