@@ -173,6 +173,32 @@ int trw_walk_edge_list_hip(const int64_t *edges, int64_t n_edges,
                            int64_t padding_idx, int32_t restart, int32_t rng_mode,
                            int64_t *out, void *workspace, size_t workspace_bytes, void *hip_stream);
 
+/*
+ * Window builders.  Replace the reference's to_windows_gpu / to_windows_cbow_gpu
+ * (csrc/cuda/windows_cuda.h:5-17, called from csrc/rw_init.cpp:83-84 and :96-97) and produce what
+ * to_windows_cpu / to_windows_cbow_cpu (csrc/cpu/windows_cpu.cpp:5-77, :80-158) produce.
+ *
+ *   walks [num_walks][walk_cols] int64, contiguous; W = num_walks * (walk_cols - window_size + 1) windows,
+ *   walk-major; mid = window_size / 2.
+ * to_windows:      target_nodes [W] (the middle node), pos_windows [W][window_size-1] (the rest of the
+ *                  window), neg_windows [W][window_size-1] = rand() % num_nodes.  Exactly window_size-1 draws
+ *                  per window, so the negatives are the reference's glibc stream itself: reference exact at
+ *                  any size and for any shard (`walk_base` = global index of walks[0]).
+ * to_windows_cbow: pos_nodes [W], windows [W][window_size-1], neg_nodes [W]: one negative per window, redrawn
+ *                  while it equals the positive node (at most 101 times).  rng_mode: TRW_RNG_GLIBC replays the
+ *                  reference's serial stream with one lane (window_base == 0), TRW_RNG_WALKER gives window
+ *                  window_base + w its own stream, TRW_RNG_AUTO picks GLIBC up to 2^18 windows.
+ */
+size_t trw_to_windows_workspace_bytes(int64_t num_walks, int64_t walk_cols, int32_t window_size);
+int trw_to_windows_hip(const int64_t *walks, int64_t num_walks, int64_t walk_cols, int32_t window_size,
+                       int64_t num_nodes, int32_t seed, int64_t walk_base,
+                       int64_t *target_nodes, int64_t *pos_windows, int64_t *neg_windows,
+                       void *workspace, size_t workspace_bytes, void *hip_stream);
+int trw_to_windows_cbow_hip(const int64_t *walks, int64_t num_walks, int64_t walk_cols, int32_t window_size,
+                            int64_t num_nodes, int32_t seed, int64_t window_base, int32_t rng_mode,
+                            int64_t *pos_nodes, int64_t *neg_nodes, int64_t *windows,
+                            void *workspace, size_t workspace_bytes, void *hip_stream);
+
 /* Synchronises `hip_stream` and copies the status block of the last walk that
  * used `workspace` to the host: status[0] = OR of TRW_ST_* bits,
  * status[1] = 1 if some CSR row was found unsorted (biased walks only; the

@@ -88,6 +88,12 @@ def lib():
             ctypes.c_double, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, i64p,
             ctypes.POINTER(ctypes.c_uint64)]
         L.trw_oracle_walk_edge_list.restype = ctypes.c_int
+        L.trw_oracle_to_windows.argtypes = [i64p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64,
+                                            ctypes.c_int32, ctypes.c_int32, i64p, i64p, i64p]
+        L.trw_oracle_to_windows.restype = ctypes.c_int
+        L.trw_oracle_to_windows_cbow.argtypes = [i64p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64,
+                                                 ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, i64p, i64p, i64p]
+        L.trw_oracle_to_windows_cbow.restype = ctypes.c_int
         _lib = L
     return _lib
 
@@ -236,3 +242,41 @@ def walk_edge_list(edge_list_indexed, node_edge_index, target_nodes, p, q, walk_
     if return_draws:
         return out, int(draws.value)
     return out
+
+
+def _windows_common(walks, window_size):
+    wk = np.ascontiguousarray(np.asarray(walks), dtype=np.int64)
+    assert wk.ndim == 2
+    num_walks, cols = wk.shape
+    W = (cols - int(window_size) + 1) * num_walks
+    return wk, num_walks, cols, max(W, 0)
+
+
+def to_windows(walks, window_size, num_nodes, seed, rng_mode=RNG_GLIBC_SEQ):
+    """The reference's ``to_windows_cpu`` restated: (target_nodes, pos_windows, neg_windows)."""
+    wk, num_walks, cols, W = _windows_common(walks, window_size)
+    tgt = np.empty(W, dtype=np.int64)
+    pos = np.empty((W, int(window_size) - 1), dtype=np.int64)
+    neg = np.empty((W, int(window_size) - 1), dtype=np.int64)
+    p64 = ctypes.POINTER(ctypes.c_int64)
+    rc = lib().trw_oracle_to_windows(wk.ctypes.data_as(p64), num_walks, cols, int(window_size), int(num_nodes),
+                                     int(seed), int(rng_mode), tgt.ctypes.data_as(p64), pos.ctypes.data_as(p64),
+                                     neg.ctypes.data_as(p64))
+    if rc != 0:
+        raise OracleError(rc)
+    return tgt, pos, neg
+
+
+def to_windows_cbow(walks, window_size, num_nodes, seed, rng_mode=RNG_GLIBC_SEQ, window_base=0):
+    """The reference's ``to_windows_cbow_cpu`` restated: (pos_nodes, neg_nodes, windows)."""
+    wk, num_walks, cols, W = _windows_common(walks, window_size)
+    posn = np.empty(W, dtype=np.int64)
+    negn = np.empty(W, dtype=np.int64)
+    win = np.empty((W, int(window_size) - 1), dtype=np.int64)
+    p64 = ctypes.POINTER(ctypes.c_int64)
+    rc = lib().trw_oracle_to_windows_cbow(wk.ctypes.data_as(p64), num_walks, cols, int(window_size), int(num_nodes),
+                                          int(seed), int(rng_mode), int(window_base), posn.ctypes.data_as(p64),
+                                          negn.ctypes.data_as(p64), win.ctypes.data_as(p64))
+    if rc != 0:
+        raise OracleError(rc)
+    return posn, negn, win

@@ -546,3 +546,81 @@ int trw_oracle_walk_edge_list(const int64_t *edges, int64_t n_edges,
     if (draws_total) *draws_total = rng.ndraws;
     return g.err;
 }
+
+/* ------------------------------------------------------------------------ */
+/* Window builders                                                            */
+/* ------------------------------------------------------------------------ */
+
+static int windows_args_ok(int64_t num_walks, int64_t walk_cols, int32_t window_size, int64_t num_nodes)
+{
+    return num_walks >= 0 && walk_cols >= 1 && window_size >= 1 && window_size <= walk_cols && num_nodes >= 1;
+}
+
+int trw_oracle_to_windows(const int64_t *walks, int64_t num_walks, int64_t walk_cols, int32_t window_size,
+                          int64_t num_nodes, int32_t seed, int32_t rng_mode,
+                          int64_t *target_nodes, int64_t *pos_windows, int64_t *neg_windows)
+{
+    if (!windows_args_ok(num_walks, walk_cols, window_size, num_nodes)) return TRW_ORACLE_E_ARG;
+    if (rng_mode != TRW_ORACLE_RNG_GLIBC_SEQ && rng_mode != TRW_ORACLE_RNG_LIBC) return TRW_ORACLE_E_ARG;
+    rng_t rng;
+    memset(&rng, 0, sizeof rng);
+    rng.mode = rng_mode;
+    if (rng_mode == TRW_ORACLE_RNG_LIBC) srand((unsigned)seed); /* windows_cpu.cpp:12 */
+    else glibc_init(&rng.gl, seed);
+    const int64_t step_end = (walk_cols - window_size) + 1;
+    const int64_t mid_pos = window_size / 2;
+    const int64_t width = window_size - 1;
+    for (int64_t walk_idx = 0; walk_idx < num_walks; ++walk_idx) {
+        const int64_t *walk = walks + walk_idx * walk_cols;
+        for (int64_t step_idx = 0; step_idx < step_end; ++step_idx) {
+            const int64_t pos = walk_idx * step_end + step_idx;
+            target_nodes[pos] = walk[step_idx + mid_pos];
+            int64_t k = 0;
+            for (int64_t i = 0; i < window_size; ++i)
+                if (i != mid_pos) pos_windows[pos * width + k++] = walk[step_idx + i];
+            for (int64_t i = 0; i < width; ++i) /* :66-69 */
+                neg_windows[pos * width + i] = (int64_t)rng_next(&rng) % num_nodes;
+        }
+    }
+    return 0;
+}
+
+int trw_oracle_to_windows_cbow(const int64_t *walks, int64_t num_walks, int64_t walk_cols, int32_t window_size,
+                               int64_t num_nodes, int32_t seed, int32_t rng_mode, int64_t window_base,
+                               int64_t *pos_nodes, int64_t *neg_nodes, int64_t *windows)
+{
+    if (!windows_args_ok(num_walks, walk_cols, window_size, num_nodes) || window_base < 0) return TRW_ORACLE_E_ARG;
+    if (rng_mode != TRW_ORACLE_RNG_GLIBC_SEQ && rng_mode != TRW_ORACLE_RNG_LIBC && rng_mode != TRW_ORACLE_RNG_WALKER)
+        return TRW_ORACLE_E_ARG;
+    if (rng_mode != TRW_ORACLE_RNG_WALKER && window_base != 0) return TRW_ORACLE_E_ARG;
+    rng_t rng;
+    memset(&rng, 0, sizeof rng);
+    rng.mode = rng_mode;
+    rng.seed = seed;
+    if (rng_mode == TRW_ORACLE_RNG_LIBC) srand((unsigned)seed); /* windows_cpu.cpp:87 */
+    else if (rng_mode == TRW_ORACLE_RNG_GLIBC_SEQ) glibc_init(&rng.gl, seed);
+    const int64_t step_end = (walk_cols - window_size) + 1;
+    const int64_t mid_pos = window_size / 2;
+    const int64_t width = window_size - 1;
+    for (int64_t walk_idx = 0; walk_idx < num_walks; ++walk_idx) {
+        const int64_t *walk = walks + walk_idx * walk_cols;
+        for (int64_t step_idx = 0; step_idx < step_end; ++step_idx) {
+            const int64_t pos = walk_idx * step_end + step_idx;
+            rng_begin_walker(&rng, (uint64_t)window_base + (uint64_t)pos, 0);
+            const int64_t pos_node = walk[step_idx + mid_pos];
+            pos_nodes[pos] = pos_node;
+            /* sample_int(0, num_nodes-1): no draw when the range is a single value (cpu_utils.cpp:4-5) */
+            int64_t neg_node = num_nodes == 1 ? 0 : (int64_t)rng_next(&rng) % num_nodes;
+            int max_checks = 0;
+            while (neg_node == pos_node && max_checks <= 100) { /* :131-134 */
+                neg_node = num_nodes == 1 ? 0 : (int64_t)rng_next(&rng) % num_nodes;
+                max_checks = max_checks + 1;
+            }
+            neg_nodes[pos] = neg_node;
+            int64_t k = 0;
+            for (int64_t i = 0; i < window_size; ++i)
+                if (i != mid_pos) windows[pos * width + k++] = walk[step_idx + i];
+        }
+    }
+    return 0;
+}

@@ -154,6 +154,24 @@ int trw_oracle_walk_edge_list(const int64_t *edges, int64_t n_edges,
                               int64_t padding_idx, int32_t restart, int32_t rng_mode,
                               int64_t *out, uint64_t *draws_total);
 
+/*
+ * to_windows_cpu / to_windows_cbow_cpu restated (csrc/cpu/windows_cpu.cpp:5-77 and :80-158),
+ * single-thread semantics (one pass over the walks in order).
+ *
+ *   walks [num_walks][walk_cols]; windows per walk = walk_cols - window_size + 1; mid = window_size/2
+ * to_windows:      target_nodes [W], pos_windows [W][window_size-1] (the window without its middle),
+ *                  neg_windows [W][window_size-1] = rand() % num_nodes, window_size-1 draws per window.
+ * to_windows_cbow: pos_nodes [W], windows [W][window_size-1], neg_nodes [W] = sample_int(0,num_nodes-1)
+ *                  redrawn while it equals the positive node, at most 101 times (:129-135).
+ * rng_mode: GLIBC_SEQ / LIBC, or (cbow only) WALKER = one stream per window, keyed window_base + w.
+ */
+int trw_oracle_to_windows(const int64_t *walks, int64_t num_walks, int64_t walk_cols, int32_t window_size,
+                          int64_t num_nodes, int32_t seed, int32_t rng_mode,
+                          int64_t *target_nodes, int64_t *pos_windows, int64_t *neg_windows);
+int trw_oracle_to_windows_cbow(const int64_t *walks, int64_t num_walks, int64_t walk_cols, int32_t window_size,
+                               int64_t num_nodes, int32_t seed, int32_t rng_mode, int64_t window_base,
+                               int64_t *pos_nodes, int64_t *neg_nodes, int64_t *windows);
+
 #ifdef __cplusplus
 }
 #endif

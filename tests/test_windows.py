@@ -1,0 +1,145 @@
+"""Window builders (first half: to_windows, to_windows_cbow): oracle pinned on the
+reference's goldens, and (-m gpu) HIP parity.  Reference: csrc/cpu/windows_cpu.cpp, tests/test_windows.py."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def wgold():
+    with open(os.path.join(ROOT, "tests", "golden", "reference_test_windows.json")) as f:
+        return json.load(f)
+
+
+# ---- CPU tier ------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("mode", [O.RNG_GLIBC_SEQ, O.RNG_LIBC])
+def test_oracle_reproduces_reference_goldens(wgold, mode):
+    g = wgold
+    t, p, n = O.to_windows(g["walks"], g["window_size"], g["num_nodes"], g["seed"], rng_mode=mode)
+    e = g["to_windows_cpu"]
+    assert t.shape == (18,) and p.shape == (18, 4) and n.shape == (18, 4)
+    assert t[:6].tolist() == e["target_nodes"] and p[:6].tolist() == e["pos_windows"]
+    assert n[:6].tolist() == e["neg_windows"]
+    pn, nn, w = O.to_windows_cbow(g["walks"], g["window_size"], g["num_nodes"], g["seed"], rng_mode=mode)
+    e = g["to_windows_cbow_cpu"]
+    assert pn[:6].tolist() == e["pos_nodes"] and nn[:6].tolist() == e["neg_nodes"] and w[:6].tolist() == e["windows"]
+
+
+def test_fixture_walks_are_what_the_reference_test_draws(wgold):
+    torch.manual_seed(20)
+    assert torch.randint(low=0, high=30, size=(3, 10)).tolist() == wgold["walks"]   # tests/test_windows.py:6-7
+
+
+def test_oracle_window_semantics():
+    rng = np.random.default_rng(0)
+    walks = rng.integers(0, 50, (40, 21))
+    for ws in (1, 2, 5, 8, 21):
+        t, p, n = O.to_windows(walks, ws, 50, 3)
+        steps = 21 - ws + 1
+        assert t.shape == (40 * steps,) and p.shape == (40 * steps, ws - 1)
+        mid = ws // 2
+        w = 7 * steps + 2                                     # walk 7, step 2
+        assert t[w] == walks[7, 2 + mid]
+        assert p[w].tolist() == [walks[7, 2 + i] for i in range(ws) if i != mid]
+        assert (n.reshape(-1) == O.glibc_stream(3, n.size) % 50).all()     # the negatives ARE the stream
+        pn, nn, cw = O.to_windows_cbow(walks, ws, 50, 3)
+        assert (pn == t).all() and (cw == p).all() and (nn != pn).mean() > 0.999  # 101 tries at 1/50 each
+    # a collision forces a redraw: with 2 nodes half of the first draws collide
+    pn, nn, _ = O.to_windows_cbow(rng.integers(0, 2, (50, 9)), 3, 2, 5)
+    assert (nn != pn).all()
+    # num_nodes = 1: sample_int draws nothing and the loop gives up after 101 tries
+    pn, nn, _ = O.to_windows_cbow(np.zeros((3, 5), dtype=np.int64), 3, 1, 5)
+    assert (nn == 0).all()
+    with pytest.raises(O.OracleError):
+        O.to_windows(walks, 22, 50, 3)
+
+
+def test_surface_names():
+    from torch_rw import rw
+    import inspect
+    import torch_rw_native
+    assert list(inspect.signature(rw.to_windows).parameters) == ["walks", "window_size", "num_nodes", "seed"]
+    assert list(inspect.signature(rw.to_windows_cbow).parameters) == ["walks", "window_size", "num_nodes", "seed"]
+    assert callable(torch_rw_native.to_windows) and callable(torch_rw_native.to_windows_cbow)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        rw.to_windows(torch.zeros((2, 6), dtype=torch.int64), 3, 5, 1)
+
+
+# ---- GPU tier ------------------------------------------------------------------------------
+
+@pytest.mark.gpu
+def test_gpu_reference_goldens(wgold):
+    from torch_rw import rw
+    g = wgold
+    walks = torch.tensor(g["walks"], device=DEV)
+    target_nodes, pos_windows, neg_windows = rw.to_windows(walks=walks, window_size=5, num_nodes=30, seed=20)
+    e = g["to_windows_cpu"]
+    assert target_nodes.size(0) == 6 * 3 and target_nodes.dtype == torch.int64
+    assert target_nodes[:6].cpu().tolist() == e["target_nodes"]
+    assert pos_windows[:6].cpu().tolist() == e["pos_windows"]
+    assert neg_windows[:6].cpu().tolist() == e["neg_windows"]          # the reference's CPU golden
+    pos_nodes, neg_nodes, windows = rw.to_windows_cbow(walks=walks, window_size=5, num_nodes=30, seed=20)
+    e = g["to_windows_cbow_cpu"]
+    assert pos_nodes[:6].cpu().tolist() == e["pos_nodes"] and neg_nodes[:6].cpu().tolist() == e["neg_nodes"]
+    assert windows[:6].cpu().tolist() == e["windows"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ws,num_nodes,seed", [(1, 7, 1), (2, 1, 3), (5, 30, 20), (8, 10**6, -1), (11, 2**33, 10)])
+def test_gpu_to_windows_equals_oracle(ws, num_nodes, seed):
+    from torch_rw import rw
+    walks = np.random.default_rng(ws).integers(0, min(num_nodes, 10**6), (700, 41))
+    t, p, n = O.to_windows(walks, ws, num_nodes, seed)
+    gt, gp, gn = rw.to_windows(torch.as_tensor(walks).to(DEV), ws, num_nodes, seed)
+    assert (gt.cpu().numpy() == t).all() and (gp.cpu().numpy() == p).all() and (gn.cpu().numpy() == n).all()
+    # a shard of the walks, told where it starts, produces exactly its rows
+    steps = 41 - ws + 1
+    st, sp, sn = rw.to_windows_ex(torch.as_tensor(walks[300:]).to(DEV), ws, num_nodes, seed, walk_base=300)
+    assert (sn.cpu().numpy() == n[300 * steps:]).all() and (st.cpu().numpy() == t[300 * steps:]).all()
+
+
+@pytest.mark.gpu
+def test_gpu_to_windows_full_size_properties():
+    """10 M-walk scale is bench territory; here 200k walks x 81 columns (15.4 M windows, 61 M negatives)."""
+    from torch_rw import rw
+    g = torch.Generator(device=DEV).manual_seed(5)
+    walks = torch.randint(0, 10_000_000, (200_000, 81), generator=g, device=DEV)
+    t, p, n = rw.to_windows(walks, 5, 10_000_000, 10)
+    assert tuple(n.shape) == (200_000 * 77, 4) and int(n.min()) >= 0 and int(n.max()) < 10_000_000
+    flat = n.reshape(-1)
+    for k in (0, 1, 123_456, 7_700_000 * 4 + 3, flat.numel() - 1):     # spot draws against the stream
+        assert int(flat[k]) == int(O.glibc_stream(10, 1, start=k)[0]) % 10_000_000
+    assert torch.equal(t.view(200_000, 77), walks[:, 2:79])
+    assert torch.equal(p.view(200_000, 77, 4)[:, :, 0], walks[:, 0:77])
+    assert torch.equal(p.view(200_000, 77, 4)[:, :, 3], walks[:, 4:81])
+
+
+@pytest.mark.gpu
+def test_gpu_cbow_modes_equal_oracle():
+    from torch_rw import rw
+    walks = np.random.default_rng(3).integers(0, 12, (900, 30))         # 12 nodes: many collisions
+    d = torch.as_tensor(walks).to(DEV)
+    pn, nn, w = O.to_windows_cbow(walks, 4, 12, 9, rng_mode=O.RNG_GLIBC_SEQ)
+    gp, gn, gw = rw.to_windows_cbow(d, 4, 12, 9)                        # AUTO: 24300 windows -> serial replay
+    assert (gp.cpu().numpy() == pn).all() and (gn.cpu().numpy() == nn).all() and (gw.cpu().numpy() == w).all()
+    pn, nn, w = O.to_windows_cbow(walks, 4, 12, 9, rng_mode=O.RNG_WALKER, window_base=1 << 34)
+    gp, gn, gw = rw.to_windows_cbow_ex(d, 4, 12, 9, window_base=1 << 34, rng_mode=rw.RNG_WALKER)
+    assert (gp.cpu().numpy() == pn).all() and (gn.cpu().numpy() == nn).all() and (gw.cpu().numpy() == w).all()
+    one = torch.zeros((4, 6), dtype=torch.int64, device=DEV)
+    for mode in (rw.RNG_GLIBC, rw.RNG_WALKER):
+        assert (rw.to_windows_cbow_ex(one, 3, 1, 5, rng_mode=mode)[1] == 0).all()
+    with pytest.raises(RuntimeError, match="contigous"):
+        rw.to_windows(d[:, ::2], 3, 12, 1)
+    with pytest.raises(RuntimeError, match="window_size"):
+        rw.to_windows(d, 31, 12, 1)
+    with pytest.raises(RuntimeError, match="num_nodes"):
+        rw.to_windows(d, 3, 0, 1)

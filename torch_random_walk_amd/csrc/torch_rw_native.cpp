@@ -231,6 +231,59 @@ torch::Tensor walk_edge_list(const torch::Tensor &edge_list_indexed, const torch
                              restart, 0, g_rng_mode.load(), g_check.load());
 }
 
+// to_windows / to_windows_cbow: reference dispatchers csrc/rw_init.cpp:77-101.
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> windows_impl(const torch::Tensor &walks, int64_t window_size,
+                                                                     int64_t num_nodes, int64_t seed, bool cbow,
+                                                                     int64_t base, int64_t rng_mode)
+{
+    TORCH_CHECK(walks.is_cuda(), "walks must be a CUDA tensor (torch_rw_native here is the MI355X HIP build; it has "
+                                 "no CPU path)");
+    TORCH_CHECK(walks.scalar_type() == torch::kInt64, "expected scalar type Long but found ",
+                c10::toString(walks.scalar_type()));
+    TORCH_CHECK(walks.dim() == 2, "walks must be 2-dimensional");
+    TORCH_CHECK(walks.is_contiguous(), "walks must be a contigous tensor");  // windows_cpu.cpp:15 (sic)
+    const int64_t num_walks = walks.size(0), cols = walks.size(1);
+    TORCH_CHECK(window_size >= 1 && window_size <= cols, "window_size must be between 1 and the walk width");
+    TORCH_CHECK(seed >= INT32_MIN && seed <= INT32_MAX, "seed must fit the reference's int argument");
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(walks.device());
+    const auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(walks.device().index());
+    const int64_t W = (cols - window_size + 1) * num_walks;
+    auto centre = torch::empty({W}, walks.options());
+    auto rest = torch::empty({W, window_size - 1}, walks.options());
+    auto neg = cbow ? torch::empty({W}, walks.options()) : torch::empty({W, window_size - 1}, walks.options());
+    const size_t ws_bytes = trw_to_windows_workspace_bytes(num_walks, cols, (int32_t)window_size);
+    auto workspace = torch::empty({(int64_t)ws_bytes}, walks.options().dtype(torch::kUInt8));
+    int rc;
+    {
+        pybind11::gil_scoped_release nogil;
+        if (cbow)
+            rc = trw_to_windows_cbow_hip(walks.data_ptr<int64_t>(), num_walks, cols, (int32_t)window_size, num_nodes,
+                                         (int32_t)seed, base, (int32_t)rng_mode, centre.data_ptr<int64_t>(),
+                                         neg.data_ptr<int64_t>(), rest.data_ptr<int64_t>(), workspace.data_ptr(),
+                                         ws_bytes, (void *)stream.stream());
+        else
+            rc = trw_to_windows_hip(walks.data_ptr<int64_t>(), num_walks, cols, (int32_t)window_size, num_nodes,
+                                    (int32_t)seed, base, centre.data_ptr<int64_t>(), rest.data_ptr<int64_t>(),
+                                    neg.data_ptr<int64_t>(), workspace.data_ptr(), ws_bytes, (void *)stream.stream());
+    }
+    TORCH_CHECK(rc == TRW_OK, "torch_rw to_windows failed (", rc, "): ", trw_last_error());
+    if (cbow) return std::make_tuple(centre, neg, rest);   // (pos_nodes, neg_nodes, windows), windows_cpu.cpp:157
+    return std::make_tuple(centre, rest, neg);             // (target_nodes, pos_windows, neg_windows), :76
+}
+
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> to_windows(const torch::Tensor &walks, const int window_size,
+                                                                   const int64_t num_nodes, const int seed)
+{
+    return windows_impl(walks, window_size, num_nodes, seed, false, 0, TRW_RNG_GLIBC);
+}
+
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> to_windows_cbow(const torch::Tensor &walks,
+                                                                        const int window_size,
+                                                                        const int64_t num_nodes, const int seed)
+{
+    return windows_impl(walks, window_size, num_nodes, seed, true, 0, g_rng_mode.load());
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
@@ -242,6 +295,20 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           pybind11::arg("row_ptr"), pybind11::arg("col_idx"), pybind11::arg("target_nodes"), pybind11::arg("p"),
           pybind11::arg("q"), pybind11::arg("walk_length"), pybind11::arg("seed"), pybind11::arg("walker_base") = 0,
           pybind11::arg("rng_mode") = (int64_t)TRW_RNG_AUTO, pybind11::arg("check") = true);
+    m.def("to_windows", &to_windows, "to_windows", pybind11::arg("walks"), pybind11::arg("window_size"),
+          pybind11::arg("num_nodes"), pybind11::arg("seed"));
+    m.def("to_windows_cbow", &to_windows_cbow, "to_windows", pybind11::arg("walks"), pybind11::arg("window_size"),
+          pybind11::arg("num_nodes"), pybind11::arg("seed"));
+    m.def("to_windows_ex", [](const torch::Tensor &walks, int64_t window_size, int64_t num_nodes, int64_t seed,
+                              int64_t walk_base) {
+        return windows_impl(walks, window_size, num_nodes, seed, false, walk_base, TRW_RNG_GLIBC);
+    }, pybind11::arg("walks"), pybind11::arg("window_size"), pybind11::arg("num_nodes"), pybind11::arg("seed"),
+          pybind11::arg("walk_base") = 0);
+    m.def("to_windows_cbow_ex", [](const torch::Tensor &walks, int64_t window_size, int64_t num_nodes, int64_t seed,
+                                   int64_t window_base, int64_t rng_mode) {
+        return windows_impl(walks, window_size, num_nodes, seed, true, window_base, rng_mode);
+    }, pybind11::arg("walks"), pybind11::arg("window_size"), pybind11::arg("num_nodes"), pybind11::arg("seed"),
+          pybind11::arg("window_base") = 0, pybind11::arg("rng_mode") = (int64_t)TRW_RNG_AUTO);
     m.def("walk_edge_list", &walk_edge_list, "walk_edge_list", pybind11::arg("edge_list_indexed"),
           pybind11::arg("node_edge_index"), pybind11::arg("target_nodes"), pybind11::arg("p"), pybind11::arg("q"),
           pybind11::arg("walk_length"), pybind11::arg("seed"), pybind11::arg("padding_idx"), pybind11::arg("restart"));

@@ -30,6 +30,7 @@
 #include "trw_kernels_narrow.hpp"
 #include "trw_kernels_triples.hpp"
 #include "trw_kernels_edgelist.hpp"
+#include "trw_kernels_windows.hpp"
 
 namespace {
 
@@ -660,6 +661,121 @@ int trw_walk_edge_list_hip(const int64_t *edges, int64_t n_edges, const int64_t 
                                                           padding_idx >= n_nodes ? padding_idx + 1 : n_nodes,
                                                           n_walkers, walk_length, 1, n_walkers, out);
     }
+    prof_mark(3, stream);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "kernel launch");
+    return TRW_OK;
+}
+
+// ---- window builders, reference csrc/cpu/windows_cpu.cpp ------------------------------------------
+
+static int windows_check(const int64_t *walks, int64_t num_walks, int64_t walk_cols, int32_t window_size,
+                         int64_t num_nodes, int64_t base, void *workspace, size_t workspace_bytes)
+{
+    if (num_walks < 0 || base < 0) return fail(TRW_E_ARG, "negative size argument");
+    if (walk_cols < 1 || window_size < 1 || window_size > walk_cols)
+        return fail(TRW_E_ARG, "window_size must be between 1 and the walk width");
+    if (num_nodes < 1) return fail(TRW_E_ARG, "num_nodes must be >= 1 (the reference computes rand() % num_nodes)");
+    if (num_walks > 0 && !walks) return fail(TRW_E_ARG, "walks is null");
+    if (!workspace || workspace_bytes < (size_t)kStatusBytes)
+        return fail(TRW_E_WORKSPACE, "workspace missing or smaller than the status block");
+    if (((uintptr_t)workspace & 15u) != 0) return fail(TRW_E_WORKSPACE, "workspace must be 16-byte aligned");
+    return TRW_OK;
+}
+
+size_t trw_to_windows_workspace_bytes(int64_t num_walks, int64_t walk_cols, int32_t window_size)
+{
+    if (num_walks <= 0 || walk_cols < 1 || window_size < 1 || window_size > walk_cols) return kStatusBytes;
+    const int64_t draws = num_walks * (walk_cols - window_size + 1) * (int64_t)(window_size - 1);
+    const int64_t nlanes = (draws + kFillRun - 1) / kFillRun;
+    return kStatusBytes + align_up((size_t)nlanes * kGlDeg * sizeof(uint32_t), 256);
+}
+
+int trw_to_windows_hip(const int64_t *walks, int64_t num_walks, int64_t walk_cols, int32_t window_size,
+                       int64_t num_nodes, int32_t seed, int64_t walk_base, int64_t *target_nodes,
+                       int64_t *pos_windows, int64_t *neg_windows, void *workspace, size_t workspace_bytes,
+                       void *hip_stream)
+{
+    t_last_error.clear();
+    if (int rc = windows_check(walks, num_walks, walk_cols, window_size, num_nodes, walk_base, workspace,
+                               workspace_bytes))
+        return rc;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    int64_t *status = (int64_t *)workspace;
+    hipError_t e = hipMemsetAsync(status, 0, kStatusBytes, stream);
+    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(status)");
+    const int64_t step_end = walk_cols - window_size + 1;
+    const int64_t total_windows = num_walks * step_end;
+    if (total_windows == 0) return TRW_OK;
+    if (!target_nodes || (window_size > 1 && (!pos_windows || !neg_windows)))
+        return fail(TRW_E_ARG, "output pointer is null");
+    const int64_t width = window_size - 1;
+    const int64_t draws = total_windows * width;
+    const unsigned __int128 last = ((unsigned __int128)walk_base + num_walks) * step_end * width;
+    if (last >= ((unsigned __int128)1 << 48)) return fail(TRW_E_RANGE, "glibc stream position beyond 2^48 draws");
+    if (workspace_bytes < trw_to_windows_workspace_bytes(num_walks, walk_cols, window_size))
+        return fail(TRW_E_WORKSPACE, "workspace too small for this call shape");
+    if (int rc = ensure_jump_table()) return rc;
+
+    prof_mark(0, stream);
+    uint32_t *win = (uint32_t *)((char *)workspace + kStatusBytes);
+    const int64_t nlanes = (draws + kFillRun - 1) / kFillRun;
+    if (draws > 0) {
+        SeedWindow sw;
+        trw::seed_window(seed, sw.w);
+        glibc_windows_kernel<<<(unsigned)((nlanes + kBlock - 1) / kBlock), kBlock, 0, stream>>>(
+            sw, (uint64_t)walk_base * (uint64_t)step_end * (uint64_t)width, (uint64_t)kFillRun, nlanes, win);
+    }
+    prof_mark(1, stream);
+    windows_gather_kernel<<<stream_grid(total_windows), kBlock, 0, stream>>>(walks, num_walks, walk_cols, window_size,
+                                                                           target_nodes, pos_windows);
+    if (draws > 0)
+        glibc_fill_mod_kernel<<<(unsigned)((nlanes + kBlock - 1) / kBlock), kBlock, 0, stream>>>(win, nlanes, draws,
+                                                                                              num_nodes, neg_windows);
+    prof_mark(2, stream);
+    prof_mark(3, stream);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "kernel launch");
+    return TRW_OK;
+}
+
+int trw_to_windows_cbow_hip(const int64_t *walks, int64_t num_walks, int64_t walk_cols, int32_t window_size,
+                            int64_t num_nodes, int32_t seed, int64_t window_base, int32_t rng_mode,
+                            int64_t *pos_nodes, int64_t *neg_nodes, int64_t *windows, void *workspace,
+                            size_t workspace_bytes, void *hip_stream)
+{
+    t_last_error.clear();
+    if (int rc = windows_check(walks, num_walks, walk_cols, window_size, num_nodes, window_base, workspace,
+                               workspace_bytes))
+        return rc;
+    const int64_t total_windows = num_walks * (walk_cols - window_size + 1);
+    int mode = rng_mode;
+    if (mode == TRW_RNG_AUTO)  // serial replay (one lane) while the job is small, one stream per window beyond
+        mode = (window_base == 0 && total_windows <= ((int64_t)1 << 18)) ? TRW_RNG_GLIBC : TRW_RNG_WALKER;
+    if (mode != TRW_RNG_GLIBC && mode != TRW_RNG_WALKER) return fail(TRW_E_RNG_MODE, "unknown rng_mode");
+    if (mode == TRW_RNG_GLIBC && window_base != 0)
+        return fail(TRW_E_RNG_MODE, "TRW_RNG_GLIBC replays one serial stream: window_base must be 0");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    int64_t *status = (int64_t *)workspace;
+    hipError_t e = hipMemsetAsync(status, 0, kStatusBytes, stream);
+    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(status)");
+    if (total_windows == 0) return TRW_OK;
+    if (!pos_nodes || !neg_nodes || (window_size > 1 && !windows)) return fail(TRW_E_ARG, "output pointer is null");
+
+    prof_mark(0, stream);
+    prof_mark(1, stream);
+    windows_gather_kernel<<<stream_grid(total_windows), kBlock, 0, stream>>>(walks, num_walks, walk_cols, window_size,
+                                                                           pos_nodes, windows);
+    if (mode == TRW_RNG_GLIBC) {
+        SeedWindow sw;
+        trw::seed_window(seed, sw.w);
+        cbow_negatives_glibc_seq_kernel<<<1, 64, 0, stream>>>(pos_nodes, total_windows, num_nodes, sw, neg_nodes,
+                                                             status);
+    } else {
+        cbow_negatives_walker_kernel<<<(unsigned)((total_windows + kBlock - 1) / kBlock), kBlock, 0, stream>>>(
+            pos_nodes, total_windows, num_nodes, window_base, (uint32_t)seed, neg_nodes, status);
+    }
+    prof_mark(2, stream);
     prof_mark(3, stream);
     e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "kernel launch");

@@ -1,0 +1,128 @@
+// trw_kernels_windows.hpp -- skip-gram / CBOW window builders, SURVEY 8(f) row f-3 (first half).
+//
+// Reference: to_windows_cpu (csrc/cpu/windows_cpu.cpp:5-77), to_windows_cbow_cpu (:80-158).
+// Every walk [cols] yields cols-window_size+1 windows; a window gives its middle node, the other
+// window_size-1 nodes, and negatives drawn uniformly from [0, num_nodes).
+//   * to_windows draws exactly window_size-1 negatives per window, so negative k of the whole output is
+//     draw k of glibc's stream: neg_windows (row-major) IS the stream modulo num_nodes.  It is filled by
+//     lanes that jump straight to their run of the stream (the uniform walk's jump-ahead) -- reference
+//     exact at any size, in parallel.
+//   * to_windows_cbow redraws its one negative while it equals the positive node, a data-dependent number
+//     of draws: serial replay of the reference's stream (one lane) or one Philox stream per window.
+// Included by trw_hip.hip only.
+#pragma once
+
+namespace {
+
+constexpr int kFillRun = 4 * kGlDeg;  // draws per lane of glibc_fill_mod_kernel (a multiple of the generator order)
+
+// centre[w] = middle node of window w; pos[w][*] = the window without its middle.
+__global__ void __launch_bounds__(kBlock)
+windows_gather_kernel(const int64_t *__restrict__ walks, int64_t num_walks, int64_t cols, int32_t window_size,
+                      int64_t *__restrict__ centre, int64_t *__restrict__ pos)
+{
+    const int64_t step_end = cols - window_size + 1;
+    const int64_t total = num_walks * step_end;
+    const int32_t mid = window_size / 2;
+    const int32_t width = window_size - 1;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t w = (int64_t)blockIdx.x * kBlock + threadIdx.x; w < total; w += stride) {
+        const int64_t walk_idx = w / step_end;
+        const int64_t step = w - walk_idx * step_end;
+        const int64_t *src = walks + walk_idx * cols + step;
+        int64_t *dst = pos + w * width;
+        for (int32_t i = 0; i < window_size; ++i) {
+            const int64_t v = src[i];
+            if (i == mid) centre[w] = v;
+            else dst[i < mid ? i : i - 1] = v;
+        }
+    }
+}
+
+// out[k] = (draw k of the stream) % num_nodes for k in [0, total); lane l produces draws
+// [l*kFillRun, (l+1)*kFillRun) from the window glibc_windows_kernel left in win[.][l].
+__global__ void __launch_bounds__(kBlock)
+glibc_fill_mod_kernel(const uint32_t *__restrict__ win, int64_t nlanes, int64_t total, int64_t num_nodes,
+                      int64_t *__restrict__ out)
+{
+    const int64_t lane = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (lane >= nlanes) return;
+    uint32_t w[kGlDeg];
+#pragma unroll
+    for (int j = 0; j < kGlDeg; ++j) w[j] = win[(int64_t)j * nlanes + lane];
+    const bool small = num_nodes < ((int64_t)1 << 32);
+    FastMod fm;
+    fm.init(small ? (uint32_t)num_nodes : 1u);
+    int64_t k = lane * kFillRun;
+    int64_t *dst = out + k;
+    for (int rep = 0; rep < kFillRun / kGlDeg; ++rep) {
+#pragma unroll
+        for (int j = 0; j < kGlDeg; ++j) {
+            const uint32_t v = w[j] + w[(j + kGlDeg - kGlSep) % kGlDeg];
+            w[j] = v;
+            const uint32_t r = v >> 1;
+            if (k < total) *dst = small ? (int64_t)fm.mod(r) : (int64_t)r;  // r < 2^31 <= num_nodes otherwise
+            ++k;
+            ++dst;
+        }
+    }
+}
+
+// One negative per window on the window's own stream (key window_base + w), redrawn while it equals
+// the positive node, at most 101 times (windows_cpu.cpp:129-135).
+__global__ void __launch_bounds__(kBlock)
+cbow_negatives_walker_kernel(const int64_t *__restrict__ pos_nodes, int64_t total, int64_t num_nodes,
+                             int64_t window_base, uint32_t seed, int64_t *__restrict__ neg_nodes,
+                             int64_t *__restrict__ status)
+{
+    const int64_t w = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (w == 0) status[2] = TRW_RNG_WALKER;
+    if (w >= total) return;
+    const int64_t pos_node = pos_nodes[w];
+    WalkerDraws rng;
+    rng.gw = (uint64_t)window_base + (uint64_t)w;
+    rng.seed = seed;
+    rng.d = 0;
+    auto sample = [&]() -> int64_t {  // sample_int(0, num_nodes-1): no draw for a single-value range
+        return num_nodes == 1 ? 0 : (int64_t)draw_mod(rng.next(), num_nodes);
+    };
+    int64_t neg = sample();
+    int checks = 0;
+    while (neg == pos_node && checks <= 100) {
+        neg = sample();
+        ++checks;
+    }
+    neg_nodes[w] = neg;
+}
+
+// The same on the reference's single serial glibc stream: one lane, windows in order.
+__global__ void __launch_bounds__(64)
+cbow_negatives_glibc_seq_kernel(const int64_t *__restrict__ pos_nodes, int64_t total, int64_t num_nodes,
+                                SeedWindow sw, int64_t *__restrict__ neg_nodes, int64_t *__restrict__ status)
+{
+    __shared__ uint32_t w[kGlDeg];
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    status[2] = TRW_RNG_GLIBC;
+    for (int j = 0; j < kGlDeg; ++j) w[j] = sw.w[j];
+    uint32_t slot = 0;
+    auto next = [&]() -> uint32_t {
+        uint32_t k = slot + (kGlDeg - kGlSep);
+        if (k >= kGlDeg) k -= kGlDeg;
+        const uint32_t v = w[slot] + w[k];
+        w[slot] = v;
+        slot = (slot + 1 == kGlDeg) ? 0 : slot + 1;
+        return v >> 1;
+    };
+    for (int64_t i = 0; i < total; ++i) {
+        const int64_t pos_node = pos_nodes[i];
+        int64_t neg = num_nodes == 1 ? 0 : (int64_t)draw_mod(next(), num_nodes);
+        int checks = 0;
+        while (neg == pos_node && checks <= 100) {
+            neg = num_nodes == 1 ? 0 : (int64_t)draw_mod(next(), num_nodes);
+            ++checks;
+        }
+        neg_nodes[i] = neg;
+    }
+}
+
+}  // namespace

@@ -76,3 +76,26 @@ def walk_edge_list_ex(edge_list_indexed, node_edge_index, target_nodes, p, q, wa
     """``walk_edge_list`` with an explicit global walker base and RNG mode (see ``walk_ex``)."""
     return torch_rw_native.walk_edge_list_ex(edge_list_indexed, node_edge_index, target_nodes, p, q, walk_length, seed,
                                              padding_idx, restart, walker_base, rng_mode, check)
+
+
+def to_windows(walks, window_size, num_nodes, seed):
+    """Skip-gram windows over ``walks``: ``(target_nodes [W], pos_windows [W, ws-1], neg_windows [W, ws-1])``
+    with ``W = num_walks * (walk_width - window_size + 1)``; negatives are ``rand() % num_nodes``.
+    Same surface as the reference (torch_rw/rw.py:29-30); reference-exact negatives at any size."""
+    return torch_rw_native.to_windows(walks, window_size, num_nodes, seed)
+
+
+def to_windows_cbow(walks, window_size, num_nodes, seed):
+    """CBOW windows: ``(pos_nodes [W], neg_nodes [W], windows [W, ws-1])``; the negative is redrawn while it
+    equals the positive node.  Same surface as the reference (torch_rw/rw.py:32-33)."""
+    return torch_rw_native.to_windows_cbow(walks, window_size, num_nodes, seed)
+
+
+def to_windows_ex(walks, window_size, num_nodes, seed, walk_base=0):
+    """``to_windows`` for a shard: ``walk_base`` = global index of ``walks[0]``."""
+    return torch_rw_native.to_windows_ex(walks, window_size, num_nodes, seed, walk_base)
+
+
+def to_windows_cbow_ex(walks, window_size, num_nodes, seed, window_base=0, rng_mode=RNG_AUTO):
+    """``to_windows_cbow`` with an explicit global window base and RNG mode."""
+    return torch_rw_native.to_windows_cbow_ex(walks, window_size, num_nodes, seed, window_base, rng_mode)

@@ -5,6 +5,8 @@ from torch_random_walk_amd._native import ext as _ext
 walk = _ext.walk
 walk_ex = _ext.walk_ex
 walk_triples = _ext.walk_triples
+to_windows = _ext.to_windows
+to_windows_cbow = _ext.to_windows_cbow
 walk_edge_list = _ext.walk_edge_list
 walk_edge_list_ex = _ext.walk_edge_list_ex
 walk_triples_ex = _ext.walk_triples_ex
