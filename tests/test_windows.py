@@ -47,9 +47,10 @@ def test_oracle_window_semantics():
         steps = 21 - ws + 1
         assert t.shape == (40 * steps,) and p.shape == (40 * steps, ws - 1)
         mid = ws // 2
-        w = 7 * steps + 2                                     # walk 7, step 2
-        assert t[w] == walks[7, 2 + mid]
-        assert p[w].tolist() == [walks[7, 2 + i] for i in range(ws) if i != mid]
+        st = min(2, steps - 1)
+        w = 7 * steps + st                                    # walk 7, step st
+        assert t[w] == walks[7, st + mid]
+        assert p[w].tolist() == [walks[7, st + i] for i in range(ws) if i != mid]
         assert (n.reshape(-1) == O.glibc_stream(3, n.size) % 50).all()     # the negatives ARE the stream
         pn, nn, cw = O.to_windows_cbow(walks, ws, 50, 3)
         assert (pn == t).all() and (cw == p).all() and (nn != pn).mean() > 0.999  # 101 tries at 1/50 each
