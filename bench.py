@@ -45,6 +45,11 @@ WORKLOADS = {
     # torch_rw/rw.py:18 / rw_cpu_triples.cpp:105-127 -- there is no biased triples walk to reproduce)
     "kg5m_triples": dict(graph="kg", nodes=1_000_000, edges=5_000_000, relations=1000, p=1.0, q=1.0,
                          walks_per_node=1),
+    # rows f-2 / f-3 of the scope table (edge-list walk, window builders)
+    "elist_rmat1m_biased": dict(graph="elist", nodes=1_000_000, edges=10_000_000, p=0.25, q=4.0, walks_per_node=1),
+    "elist_rmat1m_uniform": dict(graph="elist", nodes=1_000_000, edges=10_000_000, p=1.0, q=1.0, walks_per_node=1),
+    "windows_1m": dict(graph="windows", nodes=10_000_000, edges=0, p=1.0, q=1.0, walks_per_node=1, walks=1_000_000,
+                       window_size=5),
     # small variants for quick checks / CI on the GPU box
     "rmat1m_biased": dict(graph="rmat", nodes=1_000_000, edges=10_000_000, p=0.25, q=4.0, walks_per_node=1),
     "rmat1m_uniform": dict(graph="rmat", nodes=1_000_000, edges=10_000_000, p=1.0, q=1.0, walks_per_node=1),
@@ -104,32 +109,65 @@ def main():
 
     # ---- synthetic graph, generated on the device from a seed (identical on every rank) ----
     t0 = time.time()
+    elist = cfg["graph"] == "elist"
+    windows = cfg["graph"] == "windows"
     if kg:
         from torch_random_walk_amd import utils as trw_utils
         triples, entities, pad = graphs.synthetic_kg(n, cfg["edges"], cfg["relations"], seed=args.graph_seed, device=dev)
         rt_index, triples = trw_utils.build_relation_tail_index(triples, entities)
         nnz = int(triples.shape[0])
         cols = 2 * L + 1
+    elif elist:
+        # the same R-MAT edges as the CSR workloads, as an edge list sorted by head + (first,last) index;
+        # no ring here: dead ends exercise the padding / restart path
+        from torch_random_walk_amd import utils as trw_utils
+        rp_tmp, ci_tmp = graphs.rmat(n, cfg["edges"], seed=args.graph_seed, device=dev)
+        deg_tmp = rp_tmp[1:] - rp_tmp[:-1]
+        heads = torch.repeat_interleave(torch.arange(n, device=dev), deg_tmp)
+        keep = ci_tmp != (heads + 1) % n                      # drop the ring edges again
+        el_edges, el_index = None, None
+        el_index, el_edges = trw_utils.build_node_edge_index(torch.stack([heads[keep], ci_tmp[keep]], 1),
+                                                             torch.arange(n, device=dev))
+        pad = n
+        nnz = int(el_edges.shape[0])
+        cols = L + 1
+        del rp_tmp, ci_tmp, deg_tmp, heads, keep
+    elif windows:
+        g_w = torch.Generator(device=dev).manual_seed(args.graph_seed)
+        win_walks = torch.randint(0, n, (cfg["walks"], L + 1), generator=g_w, device=dev)
+        nnz = 0
+        cols = L + 1
     elif cfg["graph"] == "rmat":
         row_ptr, col_idx = graphs.rmat(n, cfg["edges"], seed=args.graph_seed, device=dev)
     else:
         row_ptr, col_idx = graphs.erdos_renyi(n, cfg["edges"], seed=args.graph_seed, device=dev)
-    if not kg:
+    if not (kg or elist or windows):
         nnz = int(col_idx.numel())
         cols = L + 1
     targets = torch.arange(n, device=dev, dtype=torch.int64).repeat(cfg["walks_per_node"])
-    B = int(targets.numel())          # walkers per GPU (fixed: weak scaling)
+    if windows:
+        targets = targets[:cfg["walks"]]
+    B = int(targets.numel())          # walkers (walks, for the window builder) per GPU: fixed, weak scaling
     walker_base = rank * B            # global walker index of this rank's first walker
     torch.cuda.synchronize()
     t_graph = time.time() - t0
 
-    mode = rw.RNG_WALKER if (kg or not uniform) else rw.RNG_GLIBC
+    mode = rw.RNG_WALKER if (kg or elist or not uniform) else rw.RNG_GLIBC
     gather = (world > 1) and not args.no_gather
     full = None
     if gather and rank == 0:
+        if windows:
+            cols = (L + 1 - cfg["window_size"] + 1) * (cfg["window_size"] - 1)
         full = torch.empty((world * B, cols), dtype=torch.int64, device="cpu" if dry else dev)
 
     def walk(tg, base, check):
+        if windows:   # "walkers" are walks here; the result the bench tracks is the negatives tensor
+            lo = int(tg[0]) if tg.numel() else 0
+            return rw.to_windows_ex(win_walks[lo:lo + tg.numel()], cfg["window_size"], n, args.seed,
+                                    walk_base=base + lo)[2].view(tg.numel(), -1)
+        if elist:
+            return rw.walk_edge_list_ex(el_edges, el_index, tg, p, q, L, args.seed, pad, restart=True,
+                                        walker_base=base, rng_mode=mode, check=check)
         if kg:
             return rw.walk_triples_ex(triples, rt_index, tg, L, pad, args.seed, walker_base=base, rng_mode=mode,
                                       check=check)
@@ -200,7 +238,18 @@ def main():
 
     # ---- algorithmic bytes of one launch ----------------------------------------
     counters = None
-    if kg:
+    if windows:
+        # per window: ws centre/positive entries read once (8 B) + ws written (8 B) + (ws-1) negatives written (8 B)
+        ws_ = cfg["window_size"]
+        n_win = B * (L + 1 - ws_ + 1)
+        alg_bytes = n_win * (8 * ws_ + 8 * ws_ + 8 * (ws_ - 1))
+        kernel_name = "glibc_fill_mod_kernel+windows_gather_kernel"
+    elif elist:
+        # uniform: per step 16 B index pair + 16 B edge row + 8 B stored; the biased walk's data-dependent reads
+        # are not counted yet (first, untuned kernel): a lower bound
+        alg_bytes = B * (16 + 40 * L)
+        kernel_name = "elist_walk_kernel"
+    elif kg:
         # per LIVE hop (not yet on the padding id / a dead end): 16 B index pair + 16 B (relation, tail);
         # per hop 16 B stored; per walker 8 B target + 8 B column 0.  Hops after a dead end read nothing.
         live_hops = int((walks[:, 1::2] != pad).sum())
@@ -258,7 +307,23 @@ def main():
         g = torch.Generator().manual_seed(12345)
         perm = torch.randperm(B, generator=g)
         tg_cpu = targets.cpu()
-        if kg:
+        if windows:
+            ww_h = win_walks.cpu().numpy()
+
+            def cpu_run(tg_h):
+                import time as _t
+                t_ = _t.perf_counter()
+                O.to_windows(ww_h[:len(tg_h)], cfg["window_size"], n, args.seed, rng_mode=O.RNG_LIBC)
+                return _t.perf_counter() - t_
+        elif elist:
+            ee_h, ei_h = el_edges.cpu().numpy(), el_index.cpu().numpy()
+
+            def cpu_run(tg_h):
+                import time as _t
+                t_ = _t.perf_counter()
+                O.walk_edge_list(ee_h, ei_h, tg_h, p, q, L, args.seed, pad, restart=True, rng_mode=O.RNG_LIBC)
+                return _t.perf_counter() - t_
+        elif kg:
             ts_h, ix_h = triples.cpu().numpy(), rt_index.cpu().numpy()
 
             def cpu_run(tg_h):
@@ -268,7 +333,7 @@ def main():
 
             def cpu_run(tg_h):
                 return O.walk_timed(rp_h, ci_h, tg_h, p, q, L, args.seed, rng_mode=O.RNG_LIBC)[1]
-        probe = 5000 if (uniform or kg) else 500
+        probe = 5000 if (uniform or kg or windows) else 500
         dt = cpu_run(tg_cpu[perm[:probe]].numpy())
         rate = probe * L / dt
         sample = int(min(B, max(probe, args.cpu_seconds * rate / L)))
@@ -278,7 +343,14 @@ def main():
                           "oracle libc srand/rand single thread (the reference's csrc/cpu algorithm; its "
                           "multi-threaded run is slower and non-deterministic, SURVEY 0.2)" % (sample, sample * L, dt))
         m = min(B, 2000)
-        if kg:
+        if windows:
+            ref_n = O.to_windows(ww_h[:m], cfg["window_size"], n, args.seed)[2].reshape(m, -1)
+            assert (ref_n == walks[:m].cpu().numpy()).all(), "GPU negatives differ from the oracle"
+        elif elist:
+            ref_w = O.walk_edge_list(ee_h, ei_h, tg_cpu[:m].numpy(), p, q, L, args.seed, pad, restart=True,
+                                     rng_mode=O.RNG_WALKER, walker_base=walker_base)
+            assert (ref_w == walks[:m].cpu().numpy()).all(), "GPU rows differ from the oracle"
+        elif kg:
             ref_w = O.walk_triples(ts_h, ix_h, tg_cpu[:m].numpy(), L, pad, args.seed, rng_mode=O.RNG_WALKER,
                                    walker_base=walker_base)
             assert (ref_w == walks[:m].cpu().numpy()).all(), "GPU rows differ from the oracle"
@@ -329,6 +401,8 @@ def main():
                 "workload": args.workload,
                 "graph": ("kg entities=%d triples=%d relations=%d graph_seed=%d" % (n, nnz, cfg["relations"],
                                                                                       args.graph_seed)) if kg else
+                         ("random walks [%d, %d] over %d nodes, window_size=%d" % (B, L + 1, n, cfg["window_size"]))
+                         if windows else
                          "%s nodes=%d directed_edges=%d (+ring) nnz=%d graph_seed=%d" % (
                     cfg["graph"], n, cfg["edges"], nnz, args.graph_seed),
                 "p": p, "q": q, "walk_length": L, "seed": args.seed,

@@ -123,7 +123,7 @@ def test_gpu_all_reference_goldens(egold):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{}, {"TRW_FORCE_WIDE": "1"}])
+@pytest.mark.parametrize("env", [{}, {"TRW_FORCE_WIDE": "1"}, {"TRW_HASH": "0"}, {"TRW_HASH": "1"}])
 @pytest.mark.parametrize("p,q", [(1.0, 1.0), (0.25, 4.0), (0.7, 0.2), (4.0, 0.25)])
 @pytest.mark.parametrize("restart", [True, False])
 def test_gpu_walker_stream_equals_oracle(env, p, q, restart, monkeypatch):

@@ -244,11 +244,13 @@ int resolve_triples_mode(int32_t rng_mode, int64_t n_walkers, int64_t walker_bas
 namespace {
 struct EdgeListPlan {
     bool narrow = false;
-    size_t off_tail32 = 0, off_ix32 = 0, off_stage = 0, total = 0;
+    bool hash = false;
+    uint32_t hash_mask = 0;
+    size_t off_tail32 = 0, off_ix32 = 0, off_stage = 0, off_table = 0, total = 0;
 };
 
 EdgeListPlan make_elist_plan(int64_t n_edges, int64_t n_nodes, int64_t n_walkers, int32_t L, int64_t padding_idx,
-                             int32_t rng_mode)
+                             int32_t rng_mode, bool uniform)
 {
     EdgeListPlan pl;
     size_t off = kStatusBytes;
@@ -262,6 +264,18 @@ EdgeListPlan make_elist_plan(int64_t n_edges, int64_t n_nodes, int64_t n_walkers
         off += align_up((size_t)n_nodes * 8 + 64, 256);
         pl.off_stage = off;
         off += align_up((size_t)n_walkers * ((size_t)L + 1) * sizeof(uint32_t), 256);
+        if (!uniform) {  // same rule as the CSR walk: build the edge table when the batch will out-query the graph
+            uint64_t cap = 1024;
+            while (cap < 3 * (uint64_t)n_edges) cap <<= 1;
+            const long forced = env_long("TRW_HASH", 0, 1, -1);
+            const bool worth = (__int128)n_walkers * L >= (__int128)n_edges / 4;
+            if (cap <= ((uint64_t)1 << 31) && (forced == 1 || (forced == -1 && worth))) {
+                pl.hash = true;
+                pl.hash_mask = (uint32_t)(cap - 1);
+                pl.off_table = off;
+                off += (size_t)cap * 16;
+            }
+        }
     }
     pl.total = off;
     return pl;
@@ -572,7 +586,8 @@ size_t trw_walk_edge_list_workspace_bytes(int64_t n_edges, int64_t n_nodes, int6
                                           int64_t padding_idx, int32_t rng_mode)
 {
     if (n_edges < 0 || n_nodes < 0) return kStatusBytes;
-    return make_elist_plan(n_edges, n_nodes, n_walkers, walk_length, padding_idx, rng_mode).total;
+    // sized for the biased walk (the larger of the two shapes): the query does not know p and q
+    return make_elist_plan(n_edges, n_nodes, n_walkers, walk_length, padding_idx, rng_mode, false).total;
 }
 
 int trw_walk_edge_list_hip(const int64_t *edges, int64_t n_edges, const int64_t *node_edge_index, int64_t n_nodes,
@@ -604,7 +619,7 @@ int trw_walk_edge_list_hip(const int64_t *edges, int64_t n_edges, const int64_t 
     if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(status)");
     if (n_walkers == 0) return TRW_OK;
 
-    const EdgeListPlan pl = make_elist_plan(n_edges, n_nodes, n_walkers, walk_length, padding_idx, mode);
+    const EdgeListPlan pl = make_elist_plan(n_edges, n_nodes, n_walkers, walk_length, padding_idx, mode, uniform);
     if (workspace_bytes < pl.total) return fail(TRW_E_WORKSPACE, "workspace too small for this call shape");
     char *ws = (char *)workspace;
     const unsigned walker_grid = (unsigned)((n_walkers + kBlock - 1) / kBlock);
@@ -625,10 +640,20 @@ int trw_walk_edge_list_hip(const int64_t *edges, int64_t n_edges, const int64_t 
     uint32_t *stage = (uint32_t *)(ws + pl.off_stage);
 
     prof_mark(0, stream);
-    if (pl.narrow)
+    uint32_t *el_table = nullptr;
+    if (pl.narrow) {
         elist_shadow_kernel<<<stream_grid(n_edges > n_nodes ? n_edges : n_nodes), kBlock, 0, stream>>>(
             edges, n_edges, node_edge_index, n_nodes, padding_idx, (uint32_t *)(ws + pl.off_tail32),
             (u32x2_a8 *)(ws + pl.off_ix32), status);
+        if (pl.hash && mode == TRW_RNG_WALKER) {
+            el_table = (uint32_t *)(ws + pl.off_table);
+            e = hipMemsetAsync(el_table, 0xFF, ((size_t)pl.hash_mask + 1) * 16, stream);
+            if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(edge table)");
+            elist_table_build_kernel<<<stream_grid(n_edges), kBlock, 0, stream>>>(
+                edges, n_edges, n_nodes, (const uint32_t *)(ws + pl.off_tail32),
+                (const u32x2_a8 *)(ws + pl.off_ix32), el_table, pl.hash_mask);
+        }
+    }
     prof_mark(1, stream);
     if (mode == TRW_RNG_GLIBC) {
         SeedWindow sw;
@@ -638,21 +663,21 @@ int trw_walk_edge_list_hip(const int64_t *edges, int64_t n_edges, const int64_t 
     } else if (pl.narrow) {
         if (uniform)
             elist_walk_kernel<false, true><<<walker_grid, kBlock, 0, stream>>>(
-                narrow, targets, n_walkers, walker_base, walk_length, padding_idx, restart, (uint32_t)seed, bp, stage,
-                out, status);
+                narrow, targets, n_walkers, walker_base, walk_length, padding_idx, restart, (uint32_t)seed, bp,
+                el_table, pl.hash_mask, stage, out, status);
         else
             elist_walk_kernel<true, true><<<walker_grid, kBlock, 0, stream>>>(
-                narrow, targets, n_walkers, walker_base, walk_length, padding_idx, restart, (uint32_t)seed, bp, stage,
-                out, status);
+                narrow, targets, n_walkers, walker_base, walk_length, padding_idx, restart, (uint32_t)seed, bp,
+                el_table, pl.hash_mask, stage, out, status);
     } else {
         if (uniform)
             elist_walk_kernel<false, false><<<walker_grid, kBlock, 0, stream>>>(
-                wide, targets, n_walkers, walker_base, walk_length, padding_idx, restart, (uint32_t)seed, bp, stage,
-                out, status);
+                wide, targets, n_walkers, walker_base, walk_length, padding_idx, restart, (uint32_t)seed, bp, nullptr,
+                0u, stage, out, status);
         else
             elist_walk_kernel<true, false><<<walker_grid, kBlock, 0, stream>>>(
-                wide, targets, n_walkers, walker_base, walk_length, padding_idx, restart, (uint32_t)seed, bp, stage,
-                out, status);
+                wide, targets, n_walkers, walker_base, walk_length, padding_idx, restart, (uint32_t)seed, bp, nullptr,
+                0u, stage, out, status);
     }
     prof_mark(2, stream);
     if (pl.narrow && mode == TRW_RNG_WALKER) {

@@ -49,6 +49,44 @@ elist_shadow_kernel(const int64_t *__restrict__ edges, int64_t n_edges, const in
     if (st) atomicOr((unsigned long long *)&status[0], (unsigned long long)st);
 }
 
+// is_neighbor(x, t) looks at t's edges [first, last) -- never the last one (rw_cpu_edge_list.cpp:51).  That
+// exact set, {(head, tail) of every edge that is not its head's last}, goes into the same open-addressing
+// table the CSR walk uses (slots of {u, v, -, -}, all 0xFF when empty), so the test is one probe instead
+// of a scan of t's edges.
+__global__ void __launch_bounds__(kBlock)
+elist_table_build_kernel(const int64_t *__restrict__ edges, int64_t n_edges, int64_t n_nodes,
+                         const uint32_t *__restrict__ tail32, const u32x2_a8 *__restrict__ ix32,
+                         uint32_t *__restrict__ table, uint32_t mask)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n_edges; e += stride) {
+        const int64_t head = edges[2 * e];
+        if ((uint64_t)head >= (uint64_t)n_nodes) continue;  // never indexed by a walk
+        const u32x2_a8 ix = ix32[head];
+        if (ix.x == kNoEdge || (uint32_t)e < ix.x || (uint32_t)e >= ix.y) continue;  // outside [first, last)
+        const uint32_t u = (uint32_t)head, v = tail32[e];
+        const unsigned long long key = ((unsigned long long)v << 32) | u;
+        uint32_t slot = edge_hash(u, v) & mask;
+        while (true) {
+            const unsigned long long old = atomicCAS((unsigned long long *)(table + 4 * (size_t)slot), ~0ull, key);
+            if (old == ~0ull || old == key) break;
+            slot = (slot + 1) & mask;
+        }
+    }
+}
+
+__device__ __forceinline__ bool elist_table_contains(const uint32_t *__restrict__ table, uint32_t mask, uint32_t u,
+                                                     uint32_t v)
+{
+    uint32_t slot = edge_hash(u, v) & mask;
+    while (true) {
+        const u32x2_a8 kv = *reinterpret_cast<const u32x2_a8 *>(table + 4 * (size_t)slot);
+        if (kv.x == 0xFFFFFFFFu) return false;
+        if (kv.x == u && kv.y == v) return true;
+        slot = (slot + 1) & mask;
+    }
+}
+
 // Uniform views of the two layouts: node ids as int64, "no edges" as first < 0.
 template <bool kNarrow>
 struct EdgeListView {
@@ -108,7 +146,8 @@ template <bool kBiased, bool kNarrow>
 __global__ void __launch_bounds__(kBlock)
 elist_walk_kernel(EdgeListView<kNarrow> g, const int64_t *__restrict__ targets, int64_t n_walkers,
                   int64_t walker_base, int32_t L, int64_t pad, int32_t restart, uint32_t seed, BiasedParams bp,
-                  uint32_t *__restrict__ stage, int64_t *__restrict__ out, int64_t *__restrict__ status)
+                  const uint32_t *__restrict__ table, uint32_t mask, uint32_t *__restrict__ stage,
+                  int64_t *__restrict__ out, int64_t *__restrict__ status)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i == 0) {
@@ -182,11 +221,17 @@ elist_walk_kernel(EdgeListView<kNarrow> g, const int64_t *__restrict__ targets, 
                     accept = true;
                 } else if (ru < bp.hi) {                           // is_neighbor decides (:220-231)
                     bool nb = false;
-                    for (int64_t e = t_first; t_first >= 0 && e < t_last; ++e)  // [first, last): never the last edge
-                        if (g.tail(e, pad, st) == x) {
-                            nb = true;
-                            break;
+                    if (t_first >= 0 && t_last > t_first) {
+                        if (table) {
+                            nb = elist_table_contains(table, mask, (uint32_t)t, (uint32_t)x);
+                        } else {
+                            for (int64_t e = t_first; e < t_last; ++e)  // [first, last): never the last edge
+                                if (g.tail(e, pad, st) == x) {
+                                    nb = true;
+                                    break;
+                                }
                         }
+                    }
                     accept = ru < (nb ? bp.t1 : bp.t2);
                 }
                 if (accept) break;
