@@ -199,6 +199,30 @@ int trw_to_windows_cbow_hip(const int64_t *walks, int64_t num_walks, int64_t wal
                             int64_t *pos_nodes, int64_t *neg_nodes, int64_t *windows,
                             void *workspace, size_t workspace_bytes, void *hip_stream);
 
+/*
+ * Triples window builders.  Replace to_windows_triples_gpu / to_windows_triples_cbow_gpu
+ * (csrc/cuda/windows_cuda.h:19-31, called from csrc/rw_init.cpp:111-112 and :126-127) and produce what
+ * to_windows_triples_cpu / to_windows_triples_cbow_cpu (csrc/cpu/windows_cpu.cpp:160-314, :316-474) produce.
+ *
+ *   walks [num_walks][walk_cols] = start, (relation, tail)*; W = num_walks * ((walk_cols-1)/2) windows (one per hop)
+ *   triples [num_triples][3]: the pool negatives are drawn from; padding_idx fills window rows past the walk's ends
+ * to_windows_triples:      target_triples [W][3], pos_windows [W][2*window_size][3], neg_windows [W][2*window_size][3]
+ *                          (2*window_size draws per window: reference exact at any size, `walk_base` for shards)
+ * to_windows_triples_cbow: pos_triples [W][3], neg_triples [W][3] (redrawn while equal to the positive triple),
+ *                          pos_windows [W][2*window_size][3]; rng_mode as trw_to_windows_cbow_hip.
+ * The reference's `num_nodes` argument is unused there and has no counterpart here.
+ */
+size_t trw_to_windows_triples_workspace_bytes(int64_t num_walks, int64_t walk_cols, int32_t window_size);
+int trw_to_windows_triples_hip(const int64_t *walks, int64_t num_walks, int64_t walk_cols, int32_t window_size,
+                               int64_t padding_idx, const int64_t *triples, int64_t num_triples, int32_t seed,
+                               int64_t walk_base, int64_t *target_triples, int64_t *pos_windows,
+                               int64_t *neg_windows, void *workspace, size_t workspace_bytes, void *hip_stream);
+int trw_to_windows_triples_cbow_hip(const int64_t *walks, int64_t num_walks, int64_t walk_cols, int32_t window_size,
+                                    int64_t padding_idx, const int64_t *triples, int64_t num_triples, int32_t seed,
+                                    int64_t window_base, int32_t rng_mode, int64_t *pos_triples,
+                                    int64_t *neg_triples, int64_t *pos_windows, void *workspace,
+                                    size_t workspace_bytes, void *hip_stream);
+
 /* Synchronises `hip_stream` and copies the status block of the last walk that
  * used `workspace` to the host: status[0] = OR of TRW_ST_* bits,
  * status[1] = 1 if some CSR row was found unsorted (biased walks only; the

@@ -94,6 +94,14 @@ def lib():
         L.trw_oracle_to_windows_cbow.argtypes = [i64p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64,
                                                  ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, i64p, i64p, i64p]
         L.trw_oracle_to_windows_cbow.restype = ctypes.c_int
+        L.trw_oracle_to_windows_triples.argtypes = [
+            i64p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64, i64p, ctypes.c_int64, ctypes.c_int32,
+            ctypes.c_int32, i64p, i64p, i64p]
+        L.trw_oracle_to_windows_triples.restype = ctypes.c_int
+        L.trw_oracle_to_windows_triples_cbow.argtypes = [
+            i64p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64, i64p, ctypes.c_int64, ctypes.c_int32,
+            ctypes.c_int32, ctypes.c_int64, i64p, i64p, i64p]
+        L.trw_oracle_to_windows_triples_cbow.restype = ctypes.c_int
         _lib = L
     return _lib
 
@@ -280,3 +288,45 @@ def to_windows_cbow(walks, window_size, num_nodes, seed, rng_mode=RNG_GLIBC_SEQ,
     if rc != 0:
         raise OracleError(rc)
     return posn, negn, win
+
+
+def _triples_windows_common(walks, triples, window_size):
+    wk = np.ascontiguousarray(np.asarray(walks), dtype=np.int64)
+    tr = np.ascontiguousarray(np.asarray(triples), dtype=np.int64).reshape(-1, 3)
+    num_walks, cols = wk.shape
+    W = ((cols - 1) // 2) * num_walks
+    return wk, tr, num_walks, cols, W
+
+
+def to_windows_triples(walks, window_size, num_nodes, padding_idx, triples, seed, rng_mode=RNG_GLIBC_SEQ):
+    """``to_windows_triples_cpu`` restated: (target_triples [W,3], pos_windows [W,2ws,3], neg_windows [W,2ws,3])."""
+    wk, tr, num_walks, cols, W = _triples_windows_common(walks, triples, window_size)
+    ws = int(window_size)
+    tgt = np.empty((W, 3), dtype=np.int64)
+    pos = np.empty((W, 2 * ws, 3), dtype=np.int64)
+    neg = np.empty((W, 2 * ws, 3), dtype=np.int64)
+    p64 = ctypes.POINTER(ctypes.c_int64)
+    rc = lib().trw_oracle_to_windows_triples(wk.ctypes.data_as(p64), num_walks, cols, ws, int(padding_idx),
+                                             tr.ctypes.data_as(p64), tr.shape[0], int(seed), int(rng_mode),
+                                             tgt.ctypes.data_as(p64), pos.ctypes.data_as(p64), neg.ctypes.data_as(p64))
+    if rc != 0:
+        raise OracleError(rc)
+    return tgt, pos, neg
+
+
+def to_windows_triples_cbow(walks, window_size, num_nodes, padding_idx, triples, seed, rng_mode=RNG_GLIBC_SEQ,
+                            window_base=0):
+    """``to_windows_triples_cbow_cpu`` restated: (pos_triples [W,3], neg_triples [W,3], pos_windows [W,2ws,3])."""
+    wk, tr, num_walks, cols, W = _triples_windows_common(walks, triples, window_size)
+    ws = int(window_size)
+    post = np.empty((W, 3), dtype=np.int64)
+    negt = np.empty((W, 3), dtype=np.int64)
+    pos = np.empty((W, 2 * ws, 3), dtype=np.int64)
+    p64 = ctypes.POINTER(ctypes.c_int64)
+    rc = lib().trw_oracle_to_windows_triples_cbow(wk.ctypes.data_as(p64), num_walks, cols, ws, int(padding_idx),
+                                                  tr.ctypes.data_as(p64), tr.shape[0], int(seed), int(rng_mode),
+                                                  int(window_base), post.ctypes.data_as(p64),
+                                                  negt.ctypes.data_as(p64), pos.ctypes.data_as(p64))
+    if rc != 0:
+        raise OracleError(rc)
+    return post, negt, pos

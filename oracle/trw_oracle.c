@@ -624,3 +624,106 @@ int trw_oracle_to_windows_cbow(const int64_t *walks, int64_t num_walks, int64_t 
     }
     return 0;
 }
+
+/* pos_windows of one target triple, windows_cpu.cpp:212-276 (identical at :392-455) */
+static void triples_pos_window(const int64_t *walk, int64_t walk_length, int64_t target_rel_index,
+                               int32_t window_size, int64_t padding_idx, int64_t *win /* [2*ws][3] */)
+{
+    for (int64_t hop = 0; hop <= window_size; hop++) { /* sic: window_size+1 rows */
+        const int64_t rel_idx = target_rel_index - ((hop + 1) * 2);
+        const int64_t head_idx = rel_idx - 1, tail_idx = rel_idx + 1;
+        if (hop >= 2 * (int64_t)window_size) break; /* window_size == 0 guard; never taken for ws >= 1 */
+        win[hop * 3 + 0] = head_idx >= 0 ? walk[rel_idx] : padding_idx; /* sic: walk[rel_idx] */
+        win[hop * 3 + 1] = rel_idx >= 0 ? walk[rel_idx] : padding_idx;
+        win[hop * 3 + 2] = tail_idx >= 0 ? walk[tail_idx] : padding_idx;
+    }
+    for (int64_t hop = 0; hop < window_size; hop++) {
+        const int64_t pos = hop + window_size;
+        const int64_t rel_idx = target_rel_index + ((hop + 1) * 2);
+        const int64_t head_idx = rel_idx - 1, tail_idx = rel_idx + 1;
+        win[pos * 3 + 0] = head_idx < walk_length ? walk[head_idx] : padding_idx;
+        win[pos * 3 + 1] = rel_idx < walk_length ? walk[rel_idx] : padding_idx;
+        win[pos * 3 + 2] = tail_idx < walk_length ? walk[tail_idx] : padding_idx;
+    }
+}
+
+static int triples_windows_args_ok(int64_t num_walks, int64_t walk_cols, int32_t window_size, int64_t num_triples)
+{
+    return num_walks >= 0 && walk_cols >= 1 && window_size >= 1 && num_triples >= 1;
+}
+
+int trw_oracle_to_windows_triples(const int64_t *walks, int64_t num_walks, int64_t walk_cols, int32_t window_size,
+                                  int64_t padding_idx, const int64_t *triples, int64_t num_triples, int32_t seed,
+                                  int32_t rng_mode, int64_t *target_triples, int64_t *pos_windows,
+                                  int64_t *neg_windows)
+{
+    if (!triples_windows_args_ok(num_walks, walk_cols, window_size, num_triples)) return TRW_ORACLE_E_ARG;
+    if (rng_mode != TRW_ORACLE_RNG_GLIBC_SEQ && rng_mode != TRW_ORACLE_RNG_LIBC) return TRW_ORACLE_E_ARG;
+    rng_t rng;
+    memset(&rng, 0, sizeof rng);
+    rng.mode = rng_mode;
+    if (rng_mode == TRW_ORACLE_RNG_LIBC) srand((unsigned)seed);
+    else glibc_init(&rng.gl, seed);
+    const int64_t per_walk = (walk_cols - 1) / 2;
+    const int64_t slots = 2 * (int64_t)window_size;
+    for (int64_t walk_idx = 0; walk_idx < num_walks; ++walk_idx) {
+        const int64_t *walk = walks + walk_idx * walk_cols;
+        int64_t target_index = 0;
+        for (int64_t tri = 1; tri < walk_cols - 1; tri += 2) {
+            const int64_t pos = per_walk * walk_idx + target_index;
+            target_triples[pos * 3 + 0] = walk[tri - 1];
+            target_triples[pos * 3 + 1] = walk[tri];
+            target_triples[pos * 3 + 2] = walk[tri + 1];
+            triples_pos_window(walk, walk_cols, tri, window_size, padding_idx, pos_windows + pos * slots * 3);
+            for (int64_t hop = 0; hop < slots; ++hop) { /* :279-290 */
+                const int64_t idx = num_triples == 1 ? 0 : (int64_t)rng_next(&rng) % num_triples;
+                for (int k = 0; k < 3; ++k) neg_windows[(pos * slots + hop) * 3 + k] = triples[idx * 3 + k];
+            }
+            target_index++;
+        }
+    }
+    return 0;
+}
+
+int trw_oracle_to_windows_triples_cbow(const int64_t *walks, int64_t num_walks, int64_t walk_cols,
+                                       int32_t window_size, int64_t padding_idx, const int64_t *triples,
+                                       int64_t num_triples, int32_t seed, int32_t rng_mode, int64_t window_base,
+                                       int64_t *pos_triples, int64_t *neg_triples, int64_t *pos_windows)
+{
+    if (!triples_windows_args_ok(num_walks, walk_cols, window_size, num_triples) || window_base < 0)
+        return TRW_ORACLE_E_ARG;
+    if (rng_mode != TRW_ORACLE_RNG_GLIBC_SEQ && rng_mode != TRW_ORACLE_RNG_LIBC && rng_mode != TRW_ORACLE_RNG_WALKER)
+        return TRW_ORACLE_E_ARG;
+    if (rng_mode != TRW_ORACLE_RNG_WALKER && window_base != 0) return TRW_ORACLE_E_ARG;
+    rng_t rng;
+    memset(&rng, 0, sizeof rng);
+    rng.mode = rng_mode;
+    rng.seed = seed;
+    if (rng_mode == TRW_ORACLE_RNG_LIBC) srand((unsigned)seed);
+    else if (rng_mode == TRW_ORACLE_RNG_GLIBC_SEQ) glibc_init(&rng.gl, seed);
+    const int64_t per_walk = (walk_cols - 1) / 2;
+    const int64_t slots = 2 * (int64_t)window_size;
+    for (int64_t walk_idx = 0; walk_idx < num_walks; ++walk_idx) {
+        const int64_t *walk = walks + walk_idx * walk_cols;
+        int64_t target_index = 0;
+        for (int64_t tri = 1; tri < walk_cols - 1; tri += 2) {
+            const int64_t pos = per_walk * walk_idx + target_index;
+            rng_begin_walker(&rng, (uint64_t)window_base + (uint64_t)pos, 0);
+            const int64_t ph = walk[tri - 1], pr = walk[tri], pt = walk[tri + 1];
+            pos_triples[pos * 3 + 0] = ph;
+            pos_triples[pos * 3 + 1] = pr;
+            pos_triples[pos * 3 + 2] = pt;
+            int64_t idx = num_triples == 1 ? 0 : (int64_t)rng_next(&rng) % num_triples; /* :374 */
+            int max_checks = 0;
+            while (triples[idx * 3] == ph && triples[idx * 3 + 1] == pr && triples[idx * 3 + 2] == pt &&
+                   max_checks <= 100) { /* :381-389 */
+                idx = num_triples == 1 ? 0 : (int64_t)rng_next(&rng) % num_triples;
+                max_checks = max_checks + 1;
+            }
+            for (int k = 0; k < 3; ++k) neg_triples[pos * 3 + k] = triples[idx * 3 + k];
+            triples_pos_window(walk, walk_cols, tri, window_size, padding_idx, pos_windows + pos * slots * 3);
+            target_index++;
+        }
+    }
+    return 0;
+}

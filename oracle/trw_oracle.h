@@ -172,6 +172,29 @@ int trw_oracle_to_windows_cbow(const int64_t *walks, int64_t num_walks, int64_t 
                                int64_t num_nodes, int32_t seed, int32_t rng_mode, int64_t window_base,
                                int64_t *pos_nodes, int64_t *neg_nodes, int64_t *windows);
 
+/*
+ * to_windows_triples_cpu / to_windows_triples_cbow_cpu restated (csrc/cpu/windows_cpu.cpp:160-314, :316-474).
+ *
+ *   walks [num_walks][walk_cols] = start, (relation, tail)*; one window per hop: W = num_walks*((walk_cols-1)/2)
+ *   pos_windows [W][2*window_size][3]: window_size triples to the left then window_size to the right of the
+ *   target triple, padding_idx where the walk ends.  Kept from the reference: the left half writes
+ *   window_size+1 rows (the extra one is overwritten by the first right row) and stores walk[rel] in the HEAD
+ *   slot of left rows (:221-225).
+ * to_windows_triples:      target_triples [W][3], neg_windows [W][2*window_size][3] = uniformly drawn rows of
+ *                          `triples` (sample_int(0, num_triples-1), one draw each unless num_triples == 1)
+ * to_windows_triples_cbow: pos_triples [W][3], neg_triples [W][3]: one drawn row, redrawn while it equals
+ *                          the positive triple (at most 101 times)
+ * rng_mode: GLIBC_SEQ / LIBC, or (cbow only) WALKER keyed window_base + w.
+ */
+int trw_oracle_to_windows_triples(const int64_t *walks, int64_t num_walks, int64_t walk_cols, int32_t window_size,
+                                  int64_t padding_idx, const int64_t *triples, int64_t num_triples, int32_t seed,
+                                  int32_t rng_mode, int64_t *target_triples, int64_t *pos_windows,
+                                  int64_t *neg_windows);
+int trw_oracle_to_windows_triples_cbow(const int64_t *walks, int64_t num_walks, int64_t walk_cols,
+                                       int32_t window_size, int64_t padding_idx, const int64_t *triples,
+                                       int64_t num_triples, int32_t seed, int32_t rng_mode, int64_t window_base,
+                                       int64_t *pos_triples, int64_t *neg_triples, int64_t *pos_windows);
+
 #ifdef __cplusplus
 }
 #endif

@@ -144,3 +144,79 @@ def test_gpu_cbow_modes_equal_oracle():
         rw.to_windows(d, 31, 12, 1)
     with pytest.raises(RuntimeError, match="num_nodes"):
         rw.to_windows(d, 3, 0, 1)
+
+
+# ---- triples window builders (windows_cpu.cpp:160-474) ------------------------------------------
+
+@pytest.mark.parametrize("mode", [O.RNG_GLIBC_SEQ, O.RNG_LIBC])
+def test_oracle_reproduces_triples_window_goldens(wgold, mode):
+    c = wgold["triples_case"]
+    t, p, n = O.to_windows_triples(c["walks"], c["window_size"], c["num_nodes"], c["padding_idx"], c["triples"],
+                                   c["seed"], rng_mode=mode)
+    e = c["to_windows_triples_cpu"]
+    assert t.shape == (30, 3) and p.shape == (30, 8, 3) and n.shape == (30, 8, 3)
+    assert t[:2].tolist() == e["target_triples"] and p[:2].tolist() == e["pos_windows"]
+    assert n[:2].tolist() == e["neg_windows"]
+    pt, nt, w = O.to_windows_triples_cbow(c["walks"], c["window_size"], c["num_nodes"], c["padding_idx"],
+                                          c["triples"], c["seed"], rng_mode=mode)
+    e2 = c["to_windows_triples_cbow_cpu"]
+    assert pt[:2].tolist() == e2["pos_triples"] and nt[:2].tolist() == e2["neg_triples"]
+    assert w[:2].tolist() == e["pos_windows"]
+
+
+def test_triples_fixture_is_what_the_reference_test_draws(wgold):
+    torch.manual_seed(20)
+    c = wgold["triples_case"]
+    assert torch.randint(low=0, high=30, size=(3, 21)).tolist() == c["walks"]        # tests/test_windows.py:124
+    assert torch.randint(low=0, high=30, size=(10, 3)).tolist() == c["triples"]      # :125
+
+
+def test_surface_names_triples():
+    from torch_rw import rw
+    import inspect
+    assert list(inspect.signature(rw.to_windows_triples).parameters) == \
+        ["walks", "window_size", "num_nodes", "padding_idx", "triples", "seed"]          # torch_rw/rw.py:35
+    assert list(inspect.signature(rw.to_windows_triples_cbow).parameters) == \
+        ["walks", "window_size", "num_nodes", "padding_idx", "triples", "seed"]
+
+
+@pytest.mark.gpu
+def test_gpu_triples_window_goldens(wgold):
+    from torch_rw import rw
+    c = wgold["triples_case"]
+    walks, triples = torch.tensor(c["walks"], device=DEV), torch.tensor(c["triples"], device=DEV)
+    target_triples, pos_windows, neg_windows = rw.to_windows_triples(walks=walks, window_size=4, num_nodes=30,
+                                                                     padding_idx=-1, triples=triples, seed=20)
+    e = c["to_windows_triples_cpu"]
+    assert target_triples[:2].cpu().tolist() == e["target_triples"]
+    assert pos_windows[:2].cpu().tolist() == e["pos_windows"]
+    assert neg_windows[:2].cpu().tolist() == e["neg_windows"]           # the reference's CPU golden
+    pos_triples, neg_triples, windows = rw.to_windows_triples_cbow(walks=walks, window_size=4, num_nodes=30,
+                                                                   padding_idx=-1, triples=triples, seed=20)
+    e2 = c["to_windows_triples_cbow_cpu"]
+    assert pos_triples[:2].cpu().tolist() == e2["pos_triples"] and neg_triples[:2].cpu().tolist() == e2["neg_triples"]
+    assert windows[:2].cpu().tolist() == e["pos_windows"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ws,cols,ntr", [(1, 3, 1), (2, 7, 5), (4, 21, 10), (3, 161, 1000), (5, 20, 3)])
+def test_gpu_triples_windows_equal_oracle(ws, cols, ntr):
+    from torch_rw import rw
+    rng = np.random.default_rng(ws * 100 + cols)
+    walks = rng.integers(0, 40, (500, cols))
+    triples = rng.integers(0, 40, (ntr, 3))
+    if ntr >= 3:
+        walks[::7, 0:3] = triples[1]                                     # some positives that are in the pool
+    d_w, d_t = torch.as_tensor(walks).to(DEV), torch.as_tensor(triples).to(DEV)
+    t, p, n = O.to_windows_triples(walks, ws, 40, -7, triples, 11)
+    gt, gp, gn = rw.to_windows_triples(d_w, ws, 40, -7, d_t, 11)
+    assert (gt.cpu().numpy() == t).all() and (gp.cpu().numpy() == p).all() and (gn.cpu().numpy() == n).all()
+    per_walk = (cols - 1) // 2
+    st, sp, sn = rw.to_windows_triples_ex(d_w[200:], ws, -7, d_t, 11, base=200)
+    assert (sn.cpu().numpy() == n[200 * per_walk:]).all() and (sp.cpu().numpy() == p[200 * per_walk:]).all()
+    pt, nt, w = O.to_windows_triples_cbow(walks, ws, 40, -7, triples, 11, rng_mode=O.RNG_GLIBC_SEQ)
+    gpt, gnt, gw = rw.to_windows_triples_ex(d_w, ws, -7, d_t, 11, cbow=True, rng_mode=rw.RNG_GLIBC)
+    assert (gpt.cpu().numpy() == pt).all() and (gnt.cpu().numpy() == nt).all() and (gw.cpu().numpy() == w).all()
+    pt, nt, w = O.to_windows_triples_cbow(walks, ws, 40, -7, triples, 11, rng_mode=O.RNG_WALKER, window_base=99)
+    gpt, gnt, gw = rw.to_windows_triples_ex(d_w, ws, -7, d_t, 11, cbow=True, base=99, rng_mode=rw.RNG_WALKER)
+    assert (gpt.cpu().numpy() == pt).all() and (gnt.cpu().numpy() == nt).all() and (gw.cpu().numpy() == w).all()

@@ -284,6 +284,76 @@ std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> to_windows_cbow(const to
     return windows_impl(walks, window_size, num_nodes, seed, true, 0, g_rng_mode.load());
 }
 
+// to_windows_triples / to_windows_triples_cbow: reference dispatchers csrc/rw_init.cpp:103-131.
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> triples_windows_impl(const torch::Tensor &walks,
+                                                                             int64_t window_size, int64_t padding_idx,
+                                                                             const torch::Tensor &triples, int64_t seed,
+                                                                             bool cbow, int64_t base, int64_t rng_mode)
+{
+    for (const auto *t : {&walks, &triples}) {
+        TORCH_CHECK(t->is_cuda(), "walks and triples must be CUDA tensors (torch_rw_native here is the MI355X HIP "
+                                  "build; it has no CPU path)");
+        TORCH_CHECK(t->scalar_type() == torch::kInt64, "expected scalar type Long but found ",
+                    c10::toString(t->scalar_type()));
+        TORCH_CHECK(t->dim() == 2, "walks and triples must be 2-dimensional");
+    }
+    TORCH_CHECK(walks.is_contiguous(), "walks must be a contigous tensor");  // windows_cpu.cpp:172 (sic)
+    TORCH_CHECK(triples.size(1) == 3 && triples.size(0) >= 1, "triples must be [T >= 1, 3]");
+    TORCH_CHECK(walks.device() == triples.device(), "walks and triples must be on the same device");
+    TORCH_CHECK(window_size >= 1, "window_size must be >= 1");
+    TORCH_CHECK(seed >= INT32_MIN && seed <= INT32_MAX, "seed must fit the reference's int argument");
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(walks.device());
+    const auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(walks.device().index());
+    const auto tr = triples.contiguous();
+    const int64_t num_walks = walks.size(0), cols = walks.size(1);
+    const int64_t W = ((cols - 1) / 2) * num_walks;
+    auto centre = torch::empty({W, 3}, walks.options());
+    auto pos = torch::empty({W, 2 * window_size, 3}, walks.options());
+    auto neg = cbow ? torch::empty({W, 3}, walks.options()) : torch::empty({W, 2 * window_size, 3}, walks.options());
+    const size_t ws_bytes = trw_to_windows_triples_workspace_bytes(num_walks, cols, (int32_t)window_size);
+    auto workspace = torch::empty({(int64_t)ws_bytes}, walks.options().dtype(torch::kUInt8));
+    int rc;
+    {
+        pybind11::gil_scoped_release nogil;
+        if (cbow)
+            rc = trw_to_windows_triples_cbow_hip(walks.data_ptr<int64_t>(), num_walks, cols, (int32_t)window_size,
+                                                 padding_idx, tr.data_ptr<int64_t>(), tr.size(0), (int32_t)seed, base,
+                                                 (int32_t)rng_mode, centre.data_ptr<int64_t>(),
+                                                 neg.data_ptr<int64_t>(), pos.data_ptr<int64_t>(),
+                                                 workspace.data_ptr(), ws_bytes, (void *)stream.stream());
+        else
+            rc = trw_to_windows_triples_hip(walks.data_ptr<int64_t>(), num_walks, cols, (int32_t)window_size,
+                                            padding_idx, tr.data_ptr<int64_t>(), tr.size(0), (int32_t)seed, base,
+                                            centre.data_ptr<int64_t>(), pos.data_ptr<int64_t>(),
+                                            neg.data_ptr<int64_t>(), workspace.data_ptr(), ws_bytes,
+                                            (void *)stream.stream());
+    }
+    TORCH_CHECK(rc == TRW_OK, "torch_rw to_windows_triples failed (", rc, "): ", trw_last_error());
+    if (cbow) return std::make_tuple(centre, neg, pos);   // (pos_triples, neg_triples, pos_windows), windows_cpu.cpp:473
+    return std::make_tuple(centre, pos, neg);             // (target_triples, pos_windows, neg_windows), :313
+}
+
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> to_windows_triples(const torch::Tensor &walks,
+                                                                           const int window_size,
+                                                                           const int64_t num_nodes,
+                                                                           const int64_t padding_idx,
+                                                                           const torch::Tensor &triples, const int seed)
+{
+    (void)num_nodes;  // unused by the reference as well
+    return triples_windows_impl(walks, window_size, padding_idx, triples, seed, false, 0, TRW_RNG_GLIBC);
+}
+
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> to_windows_triples_cbow(const torch::Tensor &walks,
+                                                                                const int window_size,
+                                                                                const int64_t num_nodes,
+                                                                                const int64_t padding_idx,
+                                                                                const torch::Tensor &triples,
+                                                                                const int seed)
+{
+    (void)num_nodes;
+    return triples_windows_impl(walks, window_size, padding_idx, triples, seed, true, 0, g_rng_mode.load());
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
@@ -299,6 +369,20 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           pybind11::arg("num_nodes"), pybind11::arg("seed"));
     m.def("to_windows_cbow", &to_windows_cbow, "to_windows", pybind11::arg("walks"), pybind11::arg("window_size"),
           pybind11::arg("num_nodes"), pybind11::arg("seed"));
+    m.def("to_windows_triples", &to_windows_triples, "to_windows_triples", pybind11::arg("walks"),
+          pybind11::arg("window_size"), pybind11::arg("num_nodes"), pybind11::arg("padding_idx"),
+          pybind11::arg("triples"), pybind11::arg("seed"));
+    m.def("to_windows_triples_cbow", &to_windows_triples_cbow, "to_windows_triples_cbow", pybind11::arg("walks"),
+          pybind11::arg("window_size"), pybind11::arg("num_nodes"), pybind11::arg("padding_idx"),
+          pybind11::arg("triples"), pybind11::arg("seed"));
+    m.def("to_windows_triples_ex", [](const torch::Tensor &walks, int64_t window_size, int64_t padding_idx,
+                                      const torch::Tensor &triples, int64_t seed, bool cbow, int64_t base,
+                                      int64_t rng_mode) {
+        return triples_windows_impl(walks, window_size, padding_idx, triples, seed, cbow, base,
+                                    cbow ? rng_mode : (int64_t)TRW_RNG_GLIBC);
+    }, pybind11::arg("walks"), pybind11::arg("window_size"), pybind11::arg("padding_idx"), pybind11::arg("triples"),
+          pybind11::arg("seed"), pybind11::arg("cbow") = false, pybind11::arg("base") = 0,
+          pybind11::arg("rng_mode") = (int64_t)TRW_RNG_AUTO);
     m.def("to_windows_ex", [](const torch::Tensor &walks, int64_t window_size, int64_t num_nodes, int64_t seed,
                               int64_t walk_base) {
         return windows_impl(walks, window_size, num_nodes, seed, false, walk_base, TRW_RNG_GLIBC);

@@ -755,8 +755,8 @@ int trw_to_windows_hip(const int64_t *walks, int64_t num_walks, int64_t walk_col
     windows_gather_kernel<<<stream_grid(total_windows), kBlock, 0, stream>>>(walks, num_walks, walk_cols, window_size,
                                                                            target_nodes, pos_windows);
     if (draws > 0)
-        glibc_fill_mod_kernel<<<(unsigned)((nlanes + kBlock - 1) / kBlock), kBlock, 0, stream>>>(win, nlanes, draws,
-                                                                                              num_nodes, neg_windows);
+        glibc_fill_mod_kernel<false><<<(unsigned)((nlanes + kBlock - 1) / kBlock), kBlock, 0, stream>>>(
+            win, nlanes, draws, num_nodes, nullptr, neg_windows);
     prof_mark(2, stream);
     prof_mark(3, stream);
     e = hipGetLastError();
@@ -800,6 +800,114 @@ int trw_to_windows_cbow_hip(const int64_t *walks, int64_t num_walks, int64_t wal
         cbow_negatives_walker_kernel<<<(unsigned)((total_windows + kBlock - 1) / kBlock), kBlock, 0, stream>>>(
             pos_nodes, total_windows, num_nodes, window_base, (uint32_t)seed, neg_nodes, status);
     }
+    prof_mark(2, stream);
+    prof_mark(3, stream);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "kernel launch");
+    return TRW_OK;
+}
+
+static int triples_windows_check(const int64_t *walks, int64_t num_walks, int64_t walk_cols, int32_t window_size,
+                                 const int64_t *triples, int64_t num_triples, int64_t base, void *workspace,
+                                 size_t workspace_bytes)
+{
+    if (num_walks < 0 || base < 0) return fail(TRW_E_ARG, "negative size argument");
+    if (walk_cols < 1 || window_size < 1) return fail(TRW_E_ARG, "window_size and the walk width must be >= 1");
+    if (num_triples < 1 || !triples) return fail(TRW_E_ARG, "triples must hold at least one row");
+    if (num_walks > 0 && !walks) return fail(TRW_E_ARG, "walks is null");
+    if (!workspace || workspace_bytes < (size_t)kStatusBytes)
+        return fail(TRW_E_WORKSPACE, "workspace missing or smaller than the status block");
+    if (((uintptr_t)workspace & 15u) != 0) return fail(TRW_E_WORKSPACE, "workspace must be 16-byte aligned");
+    return TRW_OK;
+}
+
+size_t trw_to_windows_triples_workspace_bytes(int64_t num_walks, int64_t walk_cols, int32_t window_size)
+{
+    if (num_walks <= 0 || walk_cols < 1 || window_size < 1) return kStatusBytes;
+    const int64_t draws = num_walks * ((walk_cols - 1) / 2) * 2 * (int64_t)window_size;
+    const int64_t nlanes = (draws + kFillRun - 1) / kFillRun;
+    return kStatusBytes + align_up((size_t)nlanes * kGlDeg * sizeof(uint32_t), 256);
+}
+
+int trw_to_windows_triples_hip(const int64_t *walks, int64_t num_walks, int64_t walk_cols, int32_t window_size,
+                               int64_t padding_idx, const int64_t *triples, int64_t num_triples, int32_t seed,
+                               int64_t walk_base, int64_t *target_triples, int64_t *pos_windows,
+                               int64_t *neg_windows, void *workspace, size_t workspace_bytes, void *hip_stream)
+{
+    t_last_error.clear();
+    if (int rc = triples_windows_check(walks, num_walks, walk_cols, window_size, triples, num_triples, walk_base,
+                                       workspace, workspace_bytes))
+        return rc;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    hipError_t e = hipMemsetAsync(workspace, 0, kStatusBytes, stream);
+    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(status)");
+    const int64_t per_walk = (walk_cols - 1) / 2;
+    const int64_t total_windows = num_walks * per_walk;
+    if (total_windows == 0) return TRW_OK;
+    if (!target_triples || !pos_windows || !neg_windows) return fail(TRW_E_ARG, "output pointer is null");
+    const int64_t slots = 2 * (int64_t)window_size;
+    // sample_int(0, num_triples-1) draws nothing when there is a single triple (cpu_utils.cpp:4-5)
+    const int64_t draws = total_windows * slots;
+    const unsigned __int128 last = ((unsigned __int128)walk_base + num_walks) * per_walk * slots;
+    if (last >= ((unsigned __int128)1 << 48)) return fail(TRW_E_RANGE, "glibc stream position beyond 2^48 draws");
+    if (workspace_bytes < trw_to_windows_triples_workspace_bytes(num_walks, walk_cols, window_size))
+        return fail(TRW_E_WORKSPACE, "workspace too small for this call shape");
+    if (int rc = ensure_jump_table()) return rc;
+    prof_mark(0, stream);
+    uint32_t *win = (uint32_t *)((char *)workspace + kStatusBytes);
+    const int64_t nlanes = (draws + kFillRun - 1) / kFillRun;
+    SeedWindow sw;
+    trw::seed_window(seed, sw.w);
+    glibc_windows_kernel<<<(unsigned)((nlanes + kBlock - 1) / kBlock), kBlock, 0, stream>>>(
+        sw, num_triples == 1 ? 0 : (uint64_t)walk_base * (uint64_t)per_walk * (uint64_t)slots, (uint64_t)kFillRun,
+        nlanes, win);
+    prof_mark(1, stream);
+    triples_windows_gather_kernel<<<stream_grid(total_windows), kBlock, 0, stream>>>(
+        walks, num_walks, walk_cols, window_size, padding_idx, target_triples, pos_windows);
+    glibc_fill_mod_kernel<true><<<(unsigned)((nlanes + kBlock - 1) / kBlock), kBlock, 0, stream>>>(
+        win, nlanes, draws, num_triples, triples, neg_windows);
+    prof_mark(2, stream);
+    prof_mark(3, stream);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "kernel launch");
+    return TRW_OK;
+}
+
+int trw_to_windows_triples_cbow_hip(const int64_t *walks, int64_t num_walks, int64_t walk_cols, int32_t window_size,
+                                    int64_t padding_idx, const int64_t *triples, int64_t num_triples, int32_t seed,
+                                    int64_t window_base, int32_t rng_mode, int64_t *pos_triples,
+                                    int64_t *neg_triples, int64_t *pos_windows, void *workspace,
+                                    size_t workspace_bytes, void *hip_stream)
+{
+    t_last_error.clear();
+    if (int rc = triples_windows_check(walks, num_walks, walk_cols, window_size, triples, num_triples, window_base,
+                                       workspace, workspace_bytes))
+        return rc;
+    const int64_t total_windows = num_walks * ((walk_cols - 1) / 2);
+    int mode = rng_mode;
+    if (mode == TRW_RNG_AUTO)
+        mode = (window_base == 0 && total_windows <= ((int64_t)1 << 18)) ? TRW_RNG_GLIBC : TRW_RNG_WALKER;
+    if (mode != TRW_RNG_GLIBC && mode != TRW_RNG_WALKER) return fail(TRW_E_RNG_MODE, "unknown rng_mode");
+    if (mode == TRW_RNG_GLIBC && window_base != 0)
+        return fail(TRW_E_RNG_MODE, "TRW_RNG_GLIBC replays one serial stream: window_base must be 0");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    int64_t *status = (int64_t *)workspace;
+    hipError_t e = hipMemsetAsync(status, 0, kStatusBytes, stream);
+    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(status)");
+    if (total_windows == 0) return TRW_OK;
+    if (!pos_triples || !neg_triples || !pos_windows) return fail(TRW_E_ARG, "output pointer is null");
+    prof_mark(0, stream);
+    prof_mark(1, stream);
+    triples_windows_gather_kernel<<<stream_grid(total_windows), kBlock, 0, stream>>>(
+        walks, num_walks, walk_cols, window_size, padding_idx, pos_triples, pos_windows);
+    SeedWindow sw;
+    trw::seed_window(seed, sw.w);
+    if (mode == TRW_RNG_GLIBC)
+        cbow_negative_triples_kernel<true><<<1, 64, 0, stream>>>(pos_triples, total_windows, triples, num_triples, 0,
+                                                                (uint32_t)seed, sw, neg_triples, status);
+    else
+        cbow_negative_triples_kernel<false><<<(unsigned)((total_windows + kBlock - 1) / kBlock), kBlock, 0, stream>>>(
+            pos_triples, total_windows, triples, num_triples, window_base, (uint32_t)seed, sw, neg_triples, status);
     prof_mark(2, stream);
     prof_mark(3, stream);
     e = hipGetLastError();

@@ -41,9 +41,12 @@ windows_gather_kernel(const int64_t *__restrict__ walks, int64_t num_walks, int6
 
 // out[k] = (draw k of the stream) % num_nodes for k in [0, total); lane l produces draws
 // [l*kFillRun, (l+1)*kFillRun) from the window glibc_windows_kernel left in win[.][l].
+// With `rows` set, draw k selects a row of that [num_nodes][3] table instead and out[k][0..2] gets the row
+// (the negatives of to_windows_triples, windows_cpu.cpp:279-290).
+template <bool kRows>
 __global__ void __launch_bounds__(kBlock)
 glibc_fill_mod_kernel(const uint32_t *__restrict__ win, int64_t nlanes, int64_t total, int64_t num_nodes,
-                      int64_t *__restrict__ out)
+                      const int64_t *__restrict__ rows, int64_t *__restrict__ out)
 {
     const int64_t lane = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (lane >= nlanes) return;
@@ -54,17 +57,117 @@ glibc_fill_mod_kernel(const uint32_t *__restrict__ win, int64_t nlanes, int64_t 
     FastMod fm;
     fm.init(small ? (uint32_t)num_nodes : 1u);
     int64_t k = lane * kFillRun;
-    int64_t *dst = out + k;
+    int64_t *dst = out + k * (kRows ? 3 : 1);
     for (int rep = 0; rep < kFillRun / kGlDeg; ++rep) {
 #pragma unroll
         for (int j = 0; j < kGlDeg; ++j) {
             const uint32_t v = w[j] + w[(j + kGlDeg - kGlSep) % kGlDeg];
             w[j] = v;
             const uint32_t r = v >> 1;
-            if (k < total) *dst = small ? (int64_t)fm.mod(r) : (int64_t)r;  // r < 2^31 <= num_nodes otherwise
+            if (k < total) {
+                const int64_t idx = small ? (int64_t)fm.mod(r) : (int64_t)r;  // r < 2^31 <= num_nodes otherwise
+                if (kRows) {
+                    const int64_t *row = rows + idx * 3;
+                    dst[0] = row[0];
+                    dst[1] = row[1];
+                    dst[2] = row[2];
+                } else {
+                    *dst = idx;
+                }
+            }
             ++k;
-            ++dst;
+            dst += kRows ? 3 : 1;
         }
+    }
+}
+
+// Triples windows (windows_cpu.cpp:160-474).  One thread per window: the target triple and the
+// 2*window_size positive rows around it, with the reference's off-by-one left half and its
+// walk[rel] in the head slot of left rows kept as they are.
+__global__ void __launch_bounds__(kBlock)
+triples_windows_gather_kernel(const int64_t *__restrict__ walks, int64_t num_walks, int64_t cols,
+                              int32_t window_size, int64_t pad, int64_t *__restrict__ target_triples,
+                              int64_t *__restrict__ pos_windows)
+{
+    const int64_t per_walk = (cols - 1) / 2;
+    const int64_t total = num_walks * per_walk;
+    const int64_t slots = 2 * (int64_t)window_size;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t w = (int64_t)blockIdx.x * kBlock + threadIdx.x; w < total; w += stride) {
+        const int64_t walk_idx = w / per_walk;
+        const int64_t tri = 2 * (w - walk_idx * per_walk) + 1;  // index of the target relation
+        const int64_t *walk = walks + walk_idx * cols;
+        target_triples[w * 3 + 0] = walk[tri - 1];
+        target_triples[w * 3 + 1] = walk[tri];
+        target_triples[w * 3 + 2] = walk[tri + 1];
+        int64_t *win = pos_windows + w * slots * 3;
+        // left rows 0..window_size-1 (the reference also writes row window_size, which the right half overwrites)
+        for (int64_t hop = 0; hop < window_size; ++hop) {
+            const int64_t rel = tri - (hop + 1) * 2;
+            win[hop * 3 + 0] = rel - 1 >= 0 ? walk[rel] : pad;  // sic: walk[rel], windows_cpu.cpp:221
+            win[hop * 3 + 1] = rel >= 0 ? walk[rel] : pad;
+            win[hop * 3 + 2] = rel + 1 >= 0 ? walk[rel + 1] : pad;
+        }
+        for (int64_t hop = 0; hop < window_size; ++hop) {
+            const int64_t rel = tri + (hop + 1) * 2;
+            int64_t *o = win + (hop + window_size) * 3;
+            o[0] = rel - 1 < cols ? walk[rel - 1] : pad;
+            o[1] = rel < cols ? walk[rel] : pad;
+            o[2] = rel + 1 < cols ? walk[rel + 1] : pad;
+        }
+    }
+}
+
+// CBOW negative triple: one drawn row of `triples`, redrawn while it equals the positive triple
+// (windows_cpu.cpp:374-389); kSerial replays the reference's one glibc stream with a single lane.
+template <bool kSerial>
+__global__ void __launch_bounds__(kSerial ? 64 : kBlock)
+cbow_negative_triples_kernel(const int64_t *__restrict__ pos_triples, int64_t total,
+                             const int64_t *__restrict__ triples, int64_t num_triples, int64_t window_base,
+                             uint32_t seed, SeedWindow sw, int64_t *__restrict__ neg_triples,
+                             int64_t *__restrict__ status)
+{
+    __shared__ uint32_t gw[kGlDeg];
+    uint32_t slot = 0;
+    auto gnext = [&]() -> uint32_t {
+        uint32_t k = slot + (kGlDeg - kGlSep);
+        if (k >= kGlDeg) k -= kGlDeg;
+        const uint32_t v = gw[slot] + gw[k];
+        gw[slot] = v;
+        slot = (slot + 1 == kGlDeg) ? 0 : slot + 1;
+        return v >> 1;
+    };
+    int64_t lo, hi;
+    if (kSerial) {
+        if (threadIdx.x != 0 || blockIdx.x != 0) return;
+        status[2] = TRW_RNG_GLIBC;
+        for (int j = 0; j < kGlDeg; ++j) gw[j] = sw.w[j];
+        lo = 0;
+        hi = total;
+    } else {
+        lo = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+        if (lo == 0) status[2] = TRW_RNG_WALKER;
+        hi = lo < total ? lo + 1 : lo;
+    }
+    for (int64_t w = lo; w < hi; ++w) {
+        const int64_t ph = pos_triples[w * 3], pr = pos_triples[w * 3 + 1], pt = pos_triples[w * 3 + 2];
+        WalkerDraws rng;
+        rng.gw = (uint64_t)window_base + (uint64_t)w;
+        rng.seed = seed;
+        rng.d = 0;
+        auto sample = [&]() -> int64_t {
+            if (num_triples == 1) return 0;
+            return (int64_t)draw_mod(kSerial ? gnext() : rng.next(), num_triples);
+        };
+        int64_t idx = sample();
+        int checks = 0;
+        while (triples[idx * 3] == ph && triples[idx * 3 + 1] == pr && triples[idx * 3 + 2] == pt && checks <= 100) {
+            idx = sample();
+            ++checks;
+        }
+        neg_triples[w * 3 + 0] = triples[idx * 3];
+        neg_triples[w * 3 + 1] = triples[idx * 3 + 1];
+        neg_triples[w * 3 + 2] = triples[idx * 3 + 2];
     }
 }
 

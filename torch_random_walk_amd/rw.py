@@ -99,3 +99,22 @@ def to_windows_ex(walks, window_size, num_nodes, seed, walk_base=0):
 def to_windows_cbow_ex(walks, window_size, num_nodes, seed, window_base=0, rng_mode=RNG_AUTO):
     """``to_windows_cbow`` with an explicit global window base and RNG mode."""
     return torch_rw_native.to_windows_cbow_ex(walks, window_size, num_nodes, seed, window_base, rng_mode)
+
+
+def to_windows_triples(walks, window_size, num_nodes, padding_idx, triples, seed):
+    """Windows over triples walks: ``(target_triples [W,3], pos_windows [W,2ws,3], neg_windows [W,2ws,3])``,
+    ``W = num_walks * ((walk_width-1)//2)``; negatives are uniformly drawn rows of ``triples``.
+    Same surface as the reference (torch_rw/rw.py:35-36; ``num_nodes`` is unused there too)."""
+    return torch_rw_native.to_windows_triples(walks, window_size, num_nodes, padding_idx, triples, seed)
+
+
+def to_windows_triples_cbow(walks, window_size, num_nodes, padding_idx, triples, seed):
+    """CBOW form: ``(pos_triples [W,3], neg_triples [W,3], pos_windows [W,2ws,3])``
+    (torch_rw/rw.py:38-39)."""
+    return torch_rw_native.to_windows_triples_cbow(walks, window_size, num_nodes, padding_idx, triples, seed)
+
+
+def to_windows_triples_ex(walks, window_size, padding_idx, triples, seed, cbow=False, base=0, rng_mode=RNG_AUTO):
+    """Shard/RNG-mode form of the two triples window builders (``base`` = global index of the first walk,
+    or of the first window for the CBOW form)."""
+    return torch_rw_native.to_windows_triples_ex(walks, window_size, padding_idx, triples, seed, cbow, base, rng_mode)

@@ -7,6 +7,8 @@ walk_ex = _ext.walk_ex
 walk_triples = _ext.walk_triples
 to_windows = _ext.to_windows
 to_windows_cbow = _ext.to_windows_cbow
+to_windows_triples = _ext.to_windows_triples
+to_windows_triples_cbow = _ext.to_windows_triples_cbow
 walk_edge_list = _ext.walk_edge_list
 walk_edge_list_ex = _ext.walk_edge_list_ex
 walk_triples_ex = _ext.walk_triples_ex
