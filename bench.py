@@ -151,6 +151,21 @@ def main():
     walker_base = rank * B            # global walker index of this rank's first walker
     torch.cuda.synchronize()
     t_graph = time.time() - t0
+    if world > 1:
+        # every rank generated its replica from the same seed: they must be the same graph
+        if kg:
+            chk = triples.sum() + rt_index.sum()
+        elif elist:
+            chk = el_edges.sum() + el_index.sum()
+        elif windows:
+            chk = win_walks.sum()
+        else:
+            chk = row_ptr.sum() * 31 + col_idx.sum()
+        lo_hi = torch.stack([chk, -chk]).to(torch.int64)
+        if dry:
+            lo_hi = lo_hi.cpu()
+        dist.all_reduce(lo_hi, op=dist.ReduceOp.MAX)
+        assert int(lo_hi[0]) == -int(lo_hi[1]), "graph replicas differ across ranks"
 
     mode = rw.RNG_WALKER if (kg or elist or not uniform) else rw.RNG_GLIBC
     gather = (world > 1) and not args.no_gather
@@ -176,13 +191,26 @@ def main():
     def walk_once():
         return walk(targets, walker_base, False)
 
+    class _Pending:
+        def __init__(self, works, keep):
+            self.works, self.keep = works, keep
+
+        def wait(self):
+            for w in self.works:
+                w.wait()
+
     def gather_async(walks):
-        """The one collective of the path: every rank's [B, cols] block to rank 0 (RCCL gather)."""
+        """The one collective of the path: every rank's [B, cols] block lands in its slice of rank 0's
+        buffer.  Issued as one RCCL group of point-to-point transfers (what a gather is on xGMI: each
+        peer -> root pair rides its own link), straight into the destination slices -- no staging copy."""
         if dry:
             walks = walks.cpu()
         if rank == 0:
-            return dist.gather(walks, list(full.split(B, dim=0)), dst=0, async_op=True)
-        return dist.gather(walks, None, dst=0, async_op=True)
+            full[:B].copy_(walks, non_blocking=True)
+            ops = [dist.P2POp(dist.irecv, full[r * B:(r + 1) * B], r) for r in range(1, world)]
+        else:
+            ops = [dist.P2POp(dist.isend, walks, 0)]
+        return _Pending(dist.batch_isend_irecv(ops) if ops else [], walks)
 
     for _ in range(args.warmup):
         walks = walk_once()
@@ -409,8 +437,9 @@ def main():
                 "walkers_per_gpu": B, "global_walkers": world * B,
                 "rng": "per-walker philox4x32-10" if mode == rw.RNG_WALKER else "glibc-indexed (csrc/cpu-exact)",
                 "partition": "start nodes block-sharded, CSR replicated",
-                "collective": ("one RCCL gather to rank 0 per step, inside the timed region, overlapped with the "
-                               "next step's walk") if gather else "none",
+                "collective": ("one RCCL gather to rank 0 per step (a group of peer->root transfers into the "
+                               "destination slices), inside the timed region, overlapped with the next step's "
+                               "walk") if gather else "none",
             },
             "roofline": {
                 "bound": "hbm",

@@ -52,11 +52,23 @@ def walk_sharded(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, group=
         dist.all_gather_into_tensor(full, padded.contiguous(), group=group)
         return full[:n]
     if gather == "root":
+        # a gather on xGMI is world-1 independent peer -> root transfers; issued as one group of
+        # point-to-point operations they land directly in the root's result, no staging copy
         if rank == 0:
             full = torch.empty((world * block, cols), dtype=mine.dtype, device=mine.device)
-            pieces = list(full.split(block, dim=0))
-            dist.gather(padded.contiguous(), pieces, dst=0, group=group)
+            full[: hi - lo] = mine
+            ops = []
+            for r in range(1, world):
+                r_lo, r_hi, _ = shard_bounds(n, world, r)
+                if r_hi > r_lo:
+                    src = r if group is None else dist.get_global_rank(group, r)
+                    ops.append(dist.P2POp(dist.irecv, full[r_lo:r_hi], src, group))
+            for w in (dist.batch_isend_irecv(ops) if ops else []):
+                w.wait()
             return full[:n]
-        dist.gather(padded.contiguous(), None, dst=0, group=group)
+        if hi > lo:
+            dst = 0 if group is None else dist.get_global_rank(group, 0)
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, mine.contiguous(), dst, group)]):
+                w.wait()
         return mine
     raise ValueError("gather must be 'root', 'all' or 'none'")
