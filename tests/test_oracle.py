@@ -216,3 +216,53 @@ def test_bias_statistics_match_node2vec():
     expect = weights / weights.sum() * counts.sum()
     chi2 = ((counts - expect) ** 2 / expect).sum()
     assert chi2 < 20.0, (counts, expect)
+
+
+# ---- an independent pure-Python reading of rw_cpu.cpp, fed by the oracle's draw stream ---------------
+
+def _py_walk(row_ptr, col_idx, targets, p, q, L, draws):
+    """Small-case restatement in plain Python (rw_cpu.cpp:58-201), consuming `draws` in order."""
+    it = iter(draws.tolist())
+    RAND_MAX = 2147483647
+    uniform = (p == 1.0 and q == 1.0)
+    max_prob = max(max(1.0 / p, 1), 1.0 / q)
+    p0, p1, p2 = 1.0 / p / max_prob, 1.0 / max_prob, 1.0 / q / max_prob
+
+    def sample(v):
+        a, b = row_ptr[v], row_ptr[v + 1]
+        return col_idx[a + next(it) % (b - a)]
+
+    out = []
+    for tnode in targets:
+        walk = [int(tnode)]
+        if uniform:
+            for _ in range(L):
+                walk.append(int(sample(walk[-1])))
+        else:
+            walk.append(int(sample(walk[0])))
+            for s in range(2, L + 1):
+                t = walk[s - 2]
+                while True:
+                    x = int(sample(walk[s - 1]))
+                    u = next(it) / RAND_MAX
+                    if x == t:
+                        if u < p0:
+                            break
+                    elif x in col_idx[row_ptr[t]:row_ptr[t + 1]]:
+                        if u < p1:
+                            break
+                    elif u < p2:
+                        break
+                walk.append(x)
+        out.append(walk)
+    return out
+
+
+@pytest.mark.parametrize("p,q", [(1.0, 1.0), (0.25, 4.0), (0.7, 0.5), (3.0, 1.0)])
+def test_c_oracle_equals_plain_python_restatement(p, q):
+    rp, ci = random_graph(40, 3, 17)
+    tg = np.random.default_rng(4).integers(0, 40, 25)
+    for seed in (1, 10):
+        w, c = O.walk(rp, ci, tg, p, q, 9, seed, return_counters=True)
+        py = _py_walk(rp.tolist(), ci.tolist(), tg, p, q, 9, O.libc_stream(seed, c["draws_total"] + 8))
+        assert w.tolist() == py
