@@ -493,7 +493,10 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col
     // ---- finish ----------------------------------------------------------------------------
     prof_mark(2, stream);
     const bool staged = pl.narrow && (uniform ? mode == TRW_RNG_GLIBC : mode == TRW_RNG_WALKER);
-    if (staged) {
+    if (staged && !uniform && pl.hash) {  // biased_hash_kernel stages walker-major
+        widen_rows_kernel<<<(unsigned)((n_walkers + 63) / 64), kBlock, 0, stream>>>(stage, targets, n_nodes, n_walkers,
+                                                                                  walk_length + 1, out);
+    } else if (staged) {
         const dim3 grid((unsigned)((pl.nlanes + 63) / 64), (unsigned)pl.G);
         transpose_rows_kernel<<<grid, kBlock, 0, stream>>>(stage, targets, n_nodes, n_walkers, walk_length, pl.G,
                                                           pl.nlanes, out);

@@ -239,6 +239,27 @@ struct FastMod {
     }
 };
 
+// Row-major uint32 staging (stage[i*cols + c], what biased_hash_kernel writes) -> int64 rows.  A block
+// converts 64 consecutive rows, i.e. one contiguous run of 64*cols elements, 16-byte loads where aligned.
+__global__ void __launch_bounds__(kBlock)
+widen_rows_kernel(const uint32_t *__restrict__ stage, const int64_t *__restrict__ targets, int64_t n_nodes,
+                  int64_t n_walkers, int32_t cols, int64_t *__restrict__ out)
+{
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int64_t rows = n_walkers - r0 < 64 ? n_walkers - r0 : 64;
+    const uint32_t total = (uint32_t)rows * (uint32_t)cols;
+    const uint32_t *src = stage + r0 * cols;
+    int64_t *dst = out + r0 * cols;
+    FastMod fm;
+    fm.init((uint32_t)cols);
+    for (uint32_t e = threadIdx.x; e < total; e += kBlock) {
+        const uint32_t c = fm.mod(e);
+        const int64_t tg = targets[r0 + (e - c) / (uint32_t)cols];
+        const bool dead = (uint64_t)tg >= (uint64_t)n_nodes;  // reported by the walk kernel
+        dst[e] = dead ? tg : (int64_t)src[e];
+    }
+}
+
 // First offset in [0, n) whose entry is >= x (n if none); rows sorted ascending.
 __device__ __forceinline__ uint32_t lower_bound32(const uint32_t *__restrict__ col32, uint32_t start, uint32_t n,
                                                   uint32_t x, uint32_t &probes)
@@ -594,10 +615,13 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                     state = LS_IDLE;
                 } else {
                     const int64_t tg = targets[walker];
-                    stage[walker] = (uint32_t)tg;  // column 0
-                    sp = stage + n_walkers + walker;
+                    // this kernel stages walker-major: the 16 columns of a 64-byte line are written by one
+                    // lane within a few hundred iterations, so the line is completed in cache instead of
+                    // reaching DRAM as sixteen 32-byte partial writes
+                    sp = stage + walker * (int64_t)(L + 1);
+                    *sp++ = (uint32_t)tg;  // column 0
                     if ((uint64_t)tg >= (uint64_t)n_nodes) {
-                        st |= TRW_ST_NODE_RANGE;  // transpose_rows_kernel fills the row with the bad id
+                        st |= TRW_ST_NODE_RANGE;  // widen_rows_kernel fills the row with the bad id
                     } else {
                         gw = (uint64_t)walker_base + (uint64_t)walker;
                         d_cons = 0;
@@ -733,8 +757,7 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
 
         // ---- emit an accepted candidate and move to the next step ----
         if (ev_accept) {
-            *sp = cand;
-            sp += n_walkers;
+            *sp++ = cand;
             ++s;
             rejected = 0;
             if (s > L) {
