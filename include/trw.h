@@ -11,7 +11,8 @@
  * and allocate nothing after the first call on a device (which uploads a 190 KB
  * constant jump table once).  Environment knobs (debug/tests): TRW_GLIBC_CHAIN=k
  * walkers chained per lane in the uniform kernel; TRW_FORCE_WIDE=1 use the int64
- * kernels; TRW_NO_POS=1 disable the located-t shortcut of the biased kernel.
+ * kernels; TRW_NO_POS=1 disable the located-t shortcut of the biased kernel;
+ * TRW_HASH=0/1, TRW_EXT=0/1 force the edge table / the fat entries off or on.
  * None of them changes a result.
  */
 #ifndef TRW_H
@@ -228,7 +229,8 @@ int trw_to_windows_triples_cbow_hip(const int64_t *walks, int64_t num_walks, int
  * status[1] = 1 if some CSR row was found unsorted (biased walks only; the
  * membership test then scans linearly like rw_cpu.cpp:32-56 instead of
  * bisecting), status[2] = the RNG mode that ran (TRW_RNG_GLIBC/WALKER),
- * status[3] = 0 int64 kernels, 1 uint32-shadow kernels, 2 shadow + edge hash table.  Returns TRW_OK or TRW_E_HIP. */
+ * status[3] = 0 int64 kernels, 1 uint32-shadow kernels, 2 shadow + edge hash table,
+ * 3 shadow + fat entries (uniform walk, one gather per step).  Returns TRW_OK or TRW_E_HIP. */
 int trw_walk_status(const void *workspace, void *hip_stream, int64_t status[4]);
 
 /* Integer form of the reference's accept test (rw_cpu.cpp:169-194):

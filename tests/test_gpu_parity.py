@@ -255,11 +255,13 @@ def test_c_abi_direct_call(rw):
         assert rc == 0, L.trw_last_error()
         st = (ctypes.c_int64 * 4)()
         assert L.trw_walk_status(ws.data_ptr(), stream, st) == 0
-        assert st[0] == 0 and st[2] == mode and st[3] in (1, 2)   # 1: uint32-shadow kernels, 2: + edge table
+        assert st[0] == 0 and st[2] == mode and st[3] in (1, 2, 3)   # uint32-shadow kernels (2: + edge table, 3: fat entries)
         assert (out.cpu().numpy() == O.walk(rp, ci, tg, p, q, 40, 10, rng_mode=omode)).all()
 
 
 VARIANTS = [{"TRW_FORCE_WIDE": "1"},                      # int64 kernels
+            {"TRW_EXT": "0"},                            # uniform: compact shadow, two gathers per step
+            {"TRW_EXT": "1"},                            # uniform: fat entries, one gather per step
             {"TRW_HASH": "0"},                           # bisection kernel, located-t shortcut
             {"TRW_HASH": "0", "TRW_NO_POS": "1"},        # bisection kernel, every candidate loaded
             {"TRW_HASH": "1"},                           # edge table + state machine

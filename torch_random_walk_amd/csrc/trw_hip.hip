@@ -110,8 +110,9 @@ struct Plan {
     int32_t G = 1;         // walkers chained per lane (uniform glibc)
     int64_t nlanes = 0;
     bool hash = false;     // biased: edge hash table + state-machine kernel
+    bool ext = false;      // uniform: fat entries {v, start(v), deg(v)}, one gather per step
     uint32_t hash_mask = 0;
-    size_t off_win = 0, off_row32 = 0, off_col32 = 0, off_stage = 0, off_table = 0, total = 0;
+    size_t off_win = 0, off_row32 = 0, off_col32 = 0, off_stage = 0, off_table = 0, off_ext = 0, total = 0;
 };
 
 Plan make_plan(int64_t n_nodes, int64_t nnz, int64_t n_walkers, int32_t L, bool uniform, int32_t rng_mode)
@@ -142,6 +143,20 @@ Plan make_plan(int64_t n_nodes, int64_t nnz, int64_t n_walkers, int32_t L, bool 
         off += align_up((size_t)nnz * sizeof(uint32_t) + 64, 256);
         pl.off_stage = off;
         off += align_up((size_t)pl.nlanes * pl.G * (size_t)(L + 1) * sizeof(uint32_t), 256);
+        // Fat entries cost one pass over the graph per call too: worth it when the batch takes more steps
+        // than the graph has entries (TRW_EXT=0/1 forces).
+        if (uniform) {
+            const long forced = env_long("TRW_EXT", 0, 1, -1);
+            // measured: 15.1 vs 22.6 ms on a 480 MB shadow (R-MAT 10M/110M), 1.14 vs 0.82 ms on a 4.8 MB one
+            // (ER 100k/1.1M, cache resident): the compact shadow wins while it fits the caches
+            const bool big = (size_t)(n_nodes + nnz) * 4 > ((size_t)32 << 20);  // the XCDs' aggregate L2
+            const bool worth = big && (__int128)n_walkers * L >= (__int128)nnz * 2;
+            if (forced == 1 || (forced == -1 && worth)) {
+                pl.ext = true;
+                pl.off_ext = off;
+                off += align_up((size_t)nnz * 16 + 64, 256);
+            }
+        }
         // The edge table costs one pass over the graph per call, so it is built when the batch
         // is going to make more membership queries than the graph has edges (TRW_HASH=0/1 forces).
         if (!uniform) {
@@ -389,6 +404,8 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col
             csr_shadow_kernel<true><<<grid, kBlock, 0, stream>>>(row_ptr, col_idx, n_nodes, nnz, row32, col32,
                                                                  status);
     }
+    if (pl.narrow && pl.ext && mode == TRW_RNG_GLIBC)
+        csr_ext_kernel<<<stream_grid(nnz), kBlock, 0, stream>>>(row32, col32, nnz, (u32x4_a16 *)(ws + pl.off_ext));
     if (pl.narrow && pl.hash && mode == TRW_RNG_WALKER) {
         e = hipMemsetAsync(table, 0xFF, ((size_t)pl.hash_mask + 1) * 16, stream);
         if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(edge table)");
@@ -432,7 +449,11 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col
     prof_mark(1, stream);
     if (uniform) {
         if (mode == TRW_RNG_GLIBC) {
-            if (pl.narrow && env_long("TRW_UNIFORM_WAVES", 1, 8, 8) < 8)
+            if (pl.narrow && pl.ext)
+                uniform_glibc_ext_kernel<8><<<lane_grid, kBlock, 0, stream>>>(
+                    row32, (const u32x4_a16 *)(ws + pl.off_ext), targets, n_nodes, n_walkers, walk_length, pl.G,
+                    pl.nlanes, win, stage, status);
+            else if (pl.narrow && env_long("TRW_UNIFORM_WAVES", 1, 8, 8) < 8)
                 uniform_glibc_kernel<1><<<lane_grid, kBlock, 0, stream>>>(row32, col32, targets, n_nodes, n_walkers,
                                                                          walk_length, pl.G, pl.nlanes, win, stage,
                                                                          status);

@@ -73,6 +73,7 @@ csr_shadow_kernel(const int64_t *__restrict__ row_ptr, const int64_t *__restrict
 // Both offsets come back from ONE 8-byte gather (4-byte aligned global_load_dwordx2):
 // a divergent load costs the memory pipeline per lane-request, not per byte.
 typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef uint32_t u32x4_a16 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void load_row32(const uint32_t *__restrict__ row32, uint32_t node, uint32_t &start,
                                            uint32_t &deg)
@@ -139,6 +140,107 @@ uniform_glibc_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restr
                 st |= TRW_ST_DEGREE0;  // rw_cpu.cpp:20 divides by zero here
             } else {
                 cur = col32[start + r % deg];
+            }
+        }
+        if (mine) *sp = cur;
+        sp += nlanes;
+        if (++s > L) {
+            s = 0;
+            ++walker;
+        }
+    };
+    int32_t d0 = 0;
+    for (; d0 + kGlDeg <= total; d0 += kGlDeg) {
+#pragma unroll
+        for (int j = 0; j < kGlDeg; ++j) {
+            const uint32_t v = w[j] + w[(j + kGlDeg - kGlSep) % kGlDeg];
+            w[j] = v;
+            step(v >> 1);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kGlDeg - 1; ++j) {
+        if (d0 + j < total) {  // wave-uniform tail
+            const uint32_t v = w[j] + w[(j + kGlDeg - kGlSep) % kGlDeg];
+            w[j] = v;
+            step(v >> 1);
+        }
+    }
+    if (st) atomicOr((unsigned long long *)&status[0], (unsigned long long)st);
+}
+
+// ---------------------------------------------------------------------------
+// Uniform walk over "fat" entries: one gather per step
+// ---------------------------------------------------------------------------
+// ext[e] = {v, row32[v], deg(v), 0} for v = col32[e]: the entry a walker picks already carries the row of
+// the node it lands on, so a step is ONE 16-byte gather instead of the dependent pair row32 -> col32.
+// Costs one pass over the entries per call (random 8-byte reads of row32, which is cache resident) and
+// 16 bytes per entry of workspace.
+__global__ void __launch_bounds__(kBlock)
+csr_ext_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32, int64_t nnz,
+               u32x4_a16 *__restrict__ ext)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < nnz; e += stride) {
+        const uint32_t v = col32[e];
+        uint32_t start, deg;
+        load_row32(row32, v, start, deg);
+        u32x4_a16 o = {v, start, deg, 0u};
+        ext[e] = o;
+    }
+}
+
+template <int kMinWaves>
+__global__ void __launch_bounds__(kBlock, kMinWaves)
+uniform_glibc_ext_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restrict__ ext,
+                         const int64_t *__restrict__ targets, int64_t n_nodes, int64_t n_walkers, int32_t L,
+                         int32_t G, int64_t nlanes, const uint32_t *__restrict__ win,
+                         uint32_t *__restrict__ stage, int64_t *__restrict__ status)
+{
+    const int64_t lane = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (lane == 0) {
+        status[2] = TRW_RNG_GLIBC;
+        status[3] = 3;
+    }
+    if (lane >= nlanes) return;
+
+    uint32_t w[kGlDeg];
+#pragma unroll
+    for (int j = 0; j < kGlDeg; ++j) w[j] = win[(int64_t)j * nlanes + lane];
+
+    uint32_t st = 0;
+    int64_t walker = lane * G;
+    int32_t s = 0;  // next column of the current walker; 0 = start a new walker
+    uint32_t cur = 0, start = 0, deg = 0;
+    uint32_t *sp = stage + lane;  // advances by nlanes per column written
+    bool live = false, mine = false;
+    const int32_t total = G * L;
+
+    auto step = [&](uint32_t r) {
+        if (s == 0) {  // wave-uniform: every lane starts its next walker together
+            mine = walker < n_walkers;
+            live = mine;
+            if (mine) {
+                const int64_t tg = targets[walker];
+                if ((uint64_t)tg >= (uint64_t)n_nodes) {  // reported; transpose_rows_kernel fills the row
+                    st |= TRW_ST_NODE_RANGE;
+                    live = false;
+                }
+                cur = (uint32_t)tg;
+                *sp = cur;
+                if (live) load_row32(row32, cur, start, deg);  // the only row32 gather of the walk
+            }
+            sp += nlanes;
+            s = 1;
+        }
+        if (live) {
+            if (deg == 0) {
+                st |= TRW_ST_DEGREE0;  // rw_cpu.cpp:20 divides by zero here
+            } else {
+                const u32x4_a16 x = ext[start + r % deg];
+                cur = x.x;
+                start = x.y;
+                deg = x.z;
             }
         }
         if (mine) *sp = cur;
