@@ -666,7 +666,7 @@ constexpr int kRing = 16;  // draws buffered per lane in LDS (4 Philox blocks)
 template <bool kCount>
 __global__ void __launch_bounds__(kBlock)
 biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32,
-                   const uint32_t *__restrict__ table, uint32_t mask, const int64_t *__restrict__ targets,
+                   const uint32_t *__restrict__ ext, const uint32_t *__restrict__ table, uint32_t mask, const int64_t *__restrict__ targets,
                    int64_t n_nodes, int64_t n_walkers, int64_t walker_base, int32_t L, uint32_t seed,
                    BiasedParams bp, int32_t want_pos, uint32_t *__restrict__ stage, int64_t *__restrict__ status)
 {
@@ -683,6 +683,11 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
     const bool use_pos = want_pos && status[kStDescents] == status[kStBoundary];
     const int lane = threadIdx.x & 63;
     uint32_t *my_ring = ring + threadIdx.x;
+    // candidates come from the fat entries {v, start(v), deg(v), 0} when the call built them: the accepted
+    // candidate then brings its own row and the LS_ROW gather of the next step is skipped
+    const bool fat = ext != nullptr;
+    const uint32_t *cand_base = fat ? ext : col32;
+    const uint32_t cand_shift = fat ? 2u : 0u;
 
     uint32_t st = 0;
     uint32_t n_trials = 0, n_fetch = 0, n_tests = 0, n_probes = 0;
@@ -698,6 +703,7 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
     fm.z = 0;
     uint32_t d_cons = 0, d_prod = 0;  // draws consumed / produced for the current walker
     uint32_t slot = 0, ku = 0, kv = 0, ru = 0, rejected = 0;
+    uint32_t c_start = 0, c_deg = 0;  // row of the candidate being judged (fat entries only)
     const uint32_t *addr = row32;
     uint32_t *sp = stage;
 
@@ -772,7 +778,7 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
             } else if (s == 1) {  // first step: plain uniform neighbour, draw 0 (rw_cpu.cpp:159)
                 const uint32_t r0 = my_ring[0] >> 1;
                 d_cons = 1;
-                addr = col32 + p_start + r0 % p_deg;
+                addr = cand_base + ((size_t)(p_start + r0 % p_deg) << cand_shift);
                 ru = 0;
                 state = LS_CAND;
             } else {
@@ -801,8 +807,10 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                 if (ru < (match ? bp.t1 : bp.t2)) ev_accept = true;
                 else ev_reject = true;
             }
-        } else if (state == LS_CAND) {  // g.x = the candidate node
+        } else if (state == LS_CAND) {  // g.x = the candidate node (g.y, g.z = its row when fat)
             cand = g.x;
+            c_start = g.y;
+            c_deg = g.z;
             if (s == 1) {
                 ev_accept = true;
             } else {
@@ -846,13 +854,13 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                     ev_accept = ev_known = true;
                 } else if (++rejected >= kTrialCap) {
                     st |= (uint32_t)kStTrialCap;
-                    addr = col32 + p_start + idx;  // take whatever this trial drew
+                    addr = cand_base + ((size_t)(p_start + idx) << cand_shift);  // take whatever this trial drew
                     ru = 0;
                     rejected = 0;
                     state = LS_CAND;
                 }
             } else {
-                addr = col32 + p_start + idx;
+                addr = cand_base + ((size_t)(p_start + idx) << cand_shift);
                 state = LS_CAND;
             }
         }
@@ -886,8 +894,22 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                 t_start = p_start;
                 t_deg = p_deg;
                 prev = cand;
-                addr = row32 + prev;
-                state = LS_ROW;
+                if (fat && c_deg != 0 && !(st & TRW_ST_DEGREE0)) {  // the candidate brought its row along
+                    p_start = c_start;
+                    p_deg = c_deg;
+                    fm.init(p_deg);
+                    if (use_pos) {
+                        ku = prev;
+                        kv = t;
+                        ev_probe = true;
+                        probe_state = LS_POS;
+                    } else {
+                        state = LS_TRIAL;
+                    }
+                } else {
+                    addr = row32 + prev;
+                    state = LS_ROW;
+                }
             }
         }
 
