@@ -286,7 +286,21 @@ def main():
         kernel_name = "triples_walker_kernel"
     elif uniform:
         alg_bytes = B * (16 + 32 * L)
-        kernel_name = "uniform_glibc_kernel"
+        # which kernel family ran: one more (untimed) call through the C ABI, then its status block
+        nbytes = lib.trw_walk_csr_workspace_bytes(n, nnz, B, L, p, q, mode)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        out = torch.empty((B, L + 1), dtype=torch.int64, device=dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = lib.trw_walk_csr_hip(row_ptr.data_ptr(), n, col_idx.data_ptr(), nnz, targets.data_ptr(), B,
+                                  walker_base, p, q, L, args.seed, mode, out.data_ptr(), ws.data_ptr(), nbytes,
+                                  stream)
+        assert rc == 0, lib.trw_last_error()
+        stw = (ctypes.c_int64 * 4)()
+        assert lib.trw_walk_status(ws.data_ptr(), stream, stw) == 0 and stw[0] == 0
+        assert torch.equal(out, walks), "direct C-ABI call produced different walks"
+        kernel_name = {0: "uniform_glibc_wide_kernel", 1: "uniform_glibc_kernel",
+                       3: "uniform_glibc_ext_kernel"}[int(stw[3])]
+        del out, ws
     else:
         lib.trw_profile_enable(2)
         nbytes = lib.trw_walk_csr_workspace_bytes(n, nnz, B, L, p, q, mode)

@@ -16,7 +16,8 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 DOMINANT = {"rmat10m_biased": ("biased_hash_kernel", "biased_walker_kernel"),
-            "rmat10m_uniform": ("uniform_glibc_kernel",), "er100k_uniform": ("uniform_glibc_kernel",)}
+            "rmat10m_uniform": ("uniform_glibc_ext_kernel", "uniform_glibc_kernel"),
+            "er100k_uniform": ("uniform_glibc_kernel", "uniform_glibc_ext_kernel")}
 traffic_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 traffic = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
 for wl in sys.argv[2:]:
@@ -30,12 +31,16 @@ for wl in sys.argv[2:]:
     # largest dispatch of the dominant kernel in each PMC pass (the full-size launches; the bench's
     # 1024-walker check launch is ignored by taking the max)
     vals = defaultdict(float)
+    names = {}
     for path in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
         with open(path) as f:
             for row in csv.DictReader(f):
-                if any(k in row["Kernel_Name"] for k in DOMINANT.get(wl, ())):
+                hit = [k for k in DOMINANT.get(wl, ()) if k + "<" in row["Kernel_Name"] or k + "(" in row["Kernel_Name"]]
+                if hit:
                     c = row["Counter_Name"]
-                    vals[c] = max(vals[c], float(row["Counter_Value"]))
+                    if float(row["Counter_Value"]) > vals[c]:
+                        vals[c] = float(row["Counter_Value"])
+                        names[c] = hit[0]
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
         # rocprofv3 reports both in KiB.  MI355X_MICROARCH.md (HBM): FETCH_SIZE = TCC_EA0_RDREQ x 64 B and
         # under-reports wide streaming reads by 2x; these kernels issue 4..16-byte random gathers, for which
@@ -43,7 +48,7 @@ for wl in sys.argv[2:]:
         # the measured 6.3 TB/s), so no doubling is applied here ("Traffic").
         traffic[wl] = {
             "tag": tag,
-            "kernel": [k for k in DOMINANT[wl]][0],
+            "kernel": names.get("FETCH_SIZE", DOMINANT[wl][0]),
             "FETCH_SIZE_KiB": vals["FETCH_SIZE"], "WRITE_SIZE_KiB": vals["WRITE_SIZE"],
             "hbm_bytes_per_launch": (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
             "TCC_REQ": vals.get("TCC_REQ_sum"), "TCC_HIT": vals.get("TCC_HIT_sum"), "TCC_MISS": vals.get("TCC_MISS_sum"),
