@@ -1,19 +1,21 @@
-// trw_hip.hip -- MI355X (gfx950) CSR random-walk library: host side and C ABI.
+// trw_hip.hip -- MI355X (gfx950) random-walk library: host side and C ABI (include/trw.h).
 //
-// One hot path of Sachinx0e/torch_random_walk, written from scratch for CDNA4:
-// the CSR walker behind torch_rw.rw.walk (reference csrc/cpu/rw_cpu.cpp is the
-// behaviour, csrc/cuda/rw_cuda.cu the shape of the GPU entry point).  This is
-// integer gather work bounded by the memory system's random-access rate; there
-// is no contraction in it and therefore no MFMA.
+// The hot path of Sachinx0e/torch_random_walk, written from scratch for CDNA4: the CSR walker
+// behind torch_rw.rw.walk (reference csrc/cpu/rw_cpu.cpp is the behaviour, csrc/cuda/rw_cuda.cu
+// the shape of the GPU entry point), and the rows next to it (triples walk, edge-list walk,
+// window builders).  This is integer gather work bounded by the memory system's random-access
+// rate; there is no contraction in it and therefore no MFMA.
 //
-// A call is three phases on the caller's stream:
-//   prepare  csr_shadow_kernel (int64 CSR -> validated uint32 shadow) and, for
-//            uniform walks, glibc_windows_kernel (per-lane jump-ahead into rand()'s stream)
-//   walk     uniform_glibc_kernel | biased_walker_kernel      (trw_kernels_narrow.hpp)
-//   finish   transpose_rows_kernel (uint32 staging planes -> [N, L+1] int64 rows)
-// Graphs beyond 2^31 nodes / 2^32 entries, the uniform walk on the per-walker
-// stream and the serial reference-exact replay of a biased walk run the int64
-// kernels of trw_kernels_wide.hpp, which write the result directly.
+// A CSR walk is three phases on the caller's stream:
+//   prepare  csr_shadow_kernel (int64 CSR -> validated uint32 shadow); glibc_windows_kernel (per-lane
+//            jump-ahead into rand()'s stream, uniform walks); csr_ext_kernel (fat entries, large graphs);
+//            edge_table_build_kernel (biased walks, large batches)
+//   walk     uniform_glibc_kernel | uniform_glibc_ext_kernel | biased_hash_kernel | biased_walker_kernel
+//   finish   transpose_rows_kernel | widen_rows_kernel (uint32 staging -> [N, L+1] int64 rows)
+// Graphs beyond 2^31 nodes / 2^32 entries, the uniform walk on the per-walker stream and the serial
+// reference-exact replay of a biased walk run the int64 kernels of trw_kernels_wide.hpp, which write
+// the result directly.  make_plan() decides which of these a call shape gets and where their
+// buffers live in the caller's workspace.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
