@@ -168,16 +168,9 @@ triples_glibc_seq_kernel(const int64_t *__restrict__ triples, int64_t n_triples,
     __shared__ uint32_t w[kGlDeg];
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     status[2] = TRW_RNG_GLIBC;
-    for (int j = 0; j < kGlDeg; ++j) w[j] = sw.w[j];
-    uint32_t slot = 0;
-    auto next = [&]() -> uint32_t {
-        uint32_t k = slot + (kGlDeg - kGlSep);
-        if (k >= kGlDeg) k -= kGlDeg;
-        const uint32_t v = w[slot] + w[k];
-        w[slot] = v;
-        slot = (slot + 1 == kGlDeg) ? 0 : slot + 1;
-        return v >> 1;
-    };
+    GlibcSerial glibc;
+    glibc.init(w, sw);
+    auto next = [&]() -> uint32_t { return glibc.next(); };
     uint32_t st = 0;
     for (int64_t i = 0; i < n_walkers && !st; ++i) {
         int64_t *row = out + i * (2 * (int64_t)L + 1);

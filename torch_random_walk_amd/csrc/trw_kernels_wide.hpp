@@ -26,6 +26,28 @@ struct SeedWindow {
     uint32_t w[kGlDeg];
 };
 
+// The reference's one serial rand() stream, stepped by a single lane: the 31-word generator window
+// lives in LDS (it is indexed by a running slot), seeded from the host-computed window of srand(seed).
+struct GlibcSerial {
+    uint32_t *w;
+    uint32_t slot;
+    __device__ __forceinline__ void init(uint32_t *lds31, const SeedWindow &sw)
+    {
+        w = lds31;
+        slot = 0;
+        for (int j = 0; j < kGlDeg; ++j) w[j] = sw.w[j];
+    }
+    __device__ __forceinline__ uint32_t next()  // one rand(): r[k] = r[k-31] + r[k-3], value >> 1
+    {
+        uint32_t k = slot + (kGlDeg - kGlSep);
+        if (k >= kGlDeg) k -= kGlDeg;
+        const uint32_t v = w[slot] + w[k];
+        w[slot] = v;
+        slot = (slot + 1 == kGlDeg) ? 0 : slot + 1;
+        return v >> 1;
+    }
+};
+
 struct Thresholds {
     uint32_t t0, t1, t2;  // accept iff rand31 < t_k  (k = distance class 0,1,2)
 };
@@ -476,16 +498,9 @@ biased_glibc_seq_kernel(const int64_t *__restrict__ row_ptr, const int64_t *__re
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     status[2] = TRW_RNG_GLIBC;
     const bool sorted = (status[1] == 0);
-    for (int j = 0; j < kGlDeg; ++j) w[j] = sw.w[j];
-    uint32_t slot = 0;
-    auto next = [&]() -> uint32_t {
-        uint32_t k = slot + (kGlDeg - kGlSep);
-        if (k >= kGlDeg) k -= kGlDeg;
-        const uint32_t v = w[slot] + w[k];
-        w[slot] = v;
-        slot = (slot + 1 == kGlDeg) ? 0 : slot + 1;
-        return v >> 1;
-    };
+    GlibcSerial glibc;
+    glibc.init(w, sw);
+    auto next = [&]() -> uint32_t { return glibc.next(); };
     uint32_t st = 0;
     uint32_t n_probes = 0;
     uint64_t n_refscan = 0;

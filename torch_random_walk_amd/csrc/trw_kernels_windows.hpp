@@ -128,20 +128,15 @@ cbow_negative_triples_kernel(const int64_t *__restrict__ pos_triples, int64_t to
                              int64_t *__restrict__ status)
 {
     __shared__ uint32_t gw[kGlDeg];
-    uint32_t slot = 0;
-    auto gnext = [&]() -> uint32_t {
-        uint32_t k = slot + (kGlDeg - kGlSep);
-        if (k >= kGlDeg) k -= kGlDeg;
-        const uint32_t v = gw[slot] + gw[k];
-        gw[slot] = v;
-        slot = (slot + 1 == kGlDeg) ? 0 : slot + 1;
-        return v >> 1;
-    };
+    GlibcSerial glibc;
+    glibc.w = gw;
+    glibc.slot = 0;
+    auto gnext = [&]() -> uint32_t { return glibc.next(); };
     int64_t lo, hi;
     if (kSerial) {
         if (threadIdx.x != 0 || blockIdx.x != 0) return;
         status[2] = TRW_RNG_GLIBC;
-        for (int j = 0; j < kGlDeg; ++j) gw[j] = sw.w[j];
+        glibc.init(gw, sw);
         lo = 0;
         hi = total;
     } else {
@@ -206,16 +201,9 @@ cbow_negatives_glibc_seq_kernel(const int64_t *__restrict__ pos_nodes, int64_t t
     __shared__ uint32_t w[kGlDeg];
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     status[2] = TRW_RNG_GLIBC;
-    for (int j = 0; j < kGlDeg; ++j) w[j] = sw.w[j];
-    uint32_t slot = 0;
-    auto next = [&]() -> uint32_t {
-        uint32_t k = slot + (kGlDeg - kGlSep);
-        if (k >= kGlDeg) k -= kGlDeg;
-        const uint32_t v = w[slot] + w[k];
-        w[slot] = v;
-        slot = (slot + 1 == kGlDeg) ? 0 : slot + 1;
-        return v >> 1;
-    };
+    GlibcSerial glibc;
+    glibc.init(w, sw);
+    auto next = [&]() -> uint32_t { return glibc.next(); };
     for (int64_t i = 0; i < total; ++i) {
         const int64_t pos_node = pos_nodes[i];
         int64_t neg = num_nodes == 1 ? 0 : (int64_t)draw_mod(next(), num_nodes);
