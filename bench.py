@@ -16,6 +16,7 @@ Workloads (BASELINE.json `configs`):
                                the graph the north-star target is quoted on)
   rmat10m_uniform  same graph, p=q=1 (reference-exact glibc draws)
   er100k_uniform   configs[1]  Erdos-Renyi 100k nodes / 1M edges, p=q=1, L=80, 10 walks per node
+  papers100m_uniform configs[3] R-MAT 111M nodes / 1.6B edges, p=q=1, L=80, 13.9M start nodes per GPU
   kg5m_triples     configs[4]  synthetic KG, 5M triples / 1M entities / 1000 relations, walk_triples, L=80
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the walk
@@ -41,6 +42,10 @@ WORKLOADS = {
     "rmat10m_biased": dict(graph="rmat", nodes=10_000_000, edges=100_000_000, p=0.25, q=4.0, walks_per_node=1),
     "rmat10m_uniform": dict(graph="rmat", nodes=10_000_000, edges=100_000_000, p=1.0, q=1.0, walks_per_node=1),
     "er100k_uniform": dict(graph="er", nodes=100_000, edges=1_000_000, p=1.0, q=1.0, walks_per_node=10),
+    # BASELINE configs[3]: ogbn-papers100M-scale synthetic CSR, uniform; each GPU walks one eighth of the start
+    # nodes (at 8 GPUs: the whole graph once), CSR replicated
+    "papers100m_uniform": dict(graph="rmat", nodes=111_000_000, edges=1_600_000_000, p=1.0, q=1.0, walks_per_node=1,
+                               shard_of=8),
     # BASELINE configs[4]: knowledge-graph triples path (the reference's triples walk is uniform only,
     # torch_rw/rw.py:18 / rw_cpu_triples.cpp:105-127 -- there is no biased triples walk to reproduce)
     "kg5m_triples": dict(graph="kg", nodes=1_000_000, edges=5_000_000, relations=1000, p=1.0, q=1.0,
@@ -144,7 +149,11 @@ def main():
     if not (kg or elist or windows):
         nnz = int(col_idx.numel())
         cols = L + 1
-    targets = torch.arange(n, device=dev, dtype=torch.int64).repeat(cfg["walks_per_node"])
+    if cfg.get("shard_of"):
+        per = (n + cfg["shard_of"] - 1) // cfg["shard_of"]
+        targets = (torch.arange(per, device=dev, dtype=torch.int64) + rank * per) % n
+    else:
+        targets = torch.arange(n, device=dev, dtype=torch.int64).repeat(cfg["walks_per_node"])
     if windows:
         targets = targets[:cfg["walks"]]
     B = int(targets.numel())          # walkers (walks, for the window builder) per GPU: fixed, weak scaling
