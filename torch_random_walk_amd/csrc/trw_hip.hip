@@ -11,7 +11,8 @@
 //            jump-ahead into rand()'s stream, uniform walks); csr_ext_kernel (fat entries, large graphs);
 //            edge_table_build_kernel (biased walks, large batches)
 //   walk     uniform_glibc_kernel | uniform_glibc_ext_kernel | biased_hash_kernel | biased_walker_kernel
-//   finish   transpose_rows_kernel | widen_rows_kernel (uint32 staging -> [N, L+1] int64 rows)
+//   finish   transpose_rows_kernel (uint32 staging planes -> [N, L+1] int64 rows; biased_hash_kernel
+//            writes its rows directly)
 // Graphs beyond 2^31 nodes / 2^32 entries, the uniform walk on the per-walker stream and the serial
 // reference-exact replay of a biased walk run the int64 kernels of trw_kernels_wide.hpp, which write
 // the result directly.  make_plan() decides which of these a call shape gets and where their
@@ -143,8 +144,6 @@ Plan make_plan(int64_t n_nodes, int64_t nnz, int64_t n_walkers, int32_t L, bool 
         off += align_up((size_t)(n_nodes + 1 + 4) * sizeof(uint32_t), 256);  // +4: 16-byte gathers at the last node
         pl.off_col32 = off;
         off += align_up((size_t)nnz * sizeof(uint32_t) + 64, 256);
-        pl.off_stage = off;
-        off += align_up((size_t)pl.nlanes * pl.G * (size_t)(L + 1) * sizeof(uint32_t), 256);
         // Fat entries cost one pass over the graph per call too: worth it when the batch takes more steps
         // than the graph has entries (TRW_EXT=0/1 forces).
         if (uniform) {
@@ -182,6 +181,10 @@ Plan make_plan(int64_t n_nodes, int64_t nnz, int64_t n_walkers, int32_t L, bool 
                     off += align_up((size_t)nnz * 16 + 64, 256);
                 }
             }
+        }
+        if (uniform || !pl.hash) {  // biased_hash_kernel writes the caller's rows itself
+            pl.off_stage = off;
+            off += align_up((size_t)pl.nlanes * pl.G * (size_t)(L + 1) * sizeof(uint32_t), 256);
         }
     }
     pl.total = off;
@@ -494,11 +497,11 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col
         if (g_prof.count)
             biased_hash_kernel<true><<<(unsigned)blocks, kBlock, 0, stream>>>(
                 row32, col32, pl.ext ? (const uint32_t *)(ws + pl.off_ext) : nullptr, table, pl.hash_mask, targets,
-                n_nodes, n_walkers, walker_base, walk_length, (uint32_t)seed, bp, use_pos ? 1 : 0, stage, status);
+                n_nodes, n_walkers, walker_base, walk_length, (uint32_t)seed, bp, use_pos ? 1 : 0, out, status);
         else
             biased_hash_kernel<false><<<(unsigned)blocks, kBlock, 0, stream>>>(
                 row32, col32, pl.ext ? (const uint32_t *)(ws + pl.off_ext) : nullptr, table, pl.hash_mask, targets,
-                n_nodes, n_walkers, walker_base, walk_length, (uint32_t)seed, bp, use_pos ? 1 : 0, stage, status);
+                n_nodes, n_walkers, walker_base, walk_length, (uint32_t)seed, bp, use_pos ? 1 : 0, out, status);
     } else if (pl.narrow) {
 #define TRW_LAUNCH_BIASED(POS, COUNT)                                                                          \
     biased_walker_kernel<POS, COUNT><<<walker_grid, kBlock, 0, stream>>>(                                      \
@@ -525,10 +528,7 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col
     // ---- finish ----------------------------------------------------------------------------
     prof_mark(2, stream);
     const bool staged = pl.narrow && (uniform ? mode == TRW_RNG_GLIBC : mode == TRW_RNG_WALKER);
-    if (staged && !uniform && pl.hash) {  // biased_hash_kernel stages walker-major
-        widen_rows_kernel<<<(unsigned)((n_walkers + 63) / 64), kBlock, 0, stream>>>(stage, targets, n_nodes, n_walkers,
-                                                                                  walk_length + 1, out);
-    } else if (staged) {
+    if (staged && !(!uniform && pl.hash)) {  // biased_hash_kernel writes the int64 rows itself
         const dim3 grid((unsigned)((pl.nlanes + 63) / 64), (unsigned)pl.G);
         transpose_rows_kernel<<<grid, kBlock, 0, stream>>>(stage, targets, n_nodes, n_walkers, walk_length, pl.G,
                                                           pl.nlanes, out);

@@ -341,27 +341,6 @@ struct FastMod {
     }
 };
 
-// Row-major uint32 staging (stage[i*cols + c], what biased_hash_kernel writes) -> int64 rows.  A block
-// converts 64 consecutive rows, i.e. one contiguous run of 64*cols elements, 16-byte loads where aligned.
-__global__ void __launch_bounds__(kBlock)
-widen_rows_kernel(const uint32_t *__restrict__ stage, const int64_t *__restrict__ targets, int64_t n_nodes,
-                  int64_t n_walkers, int32_t cols, int64_t *__restrict__ out)
-{
-    const int64_t r0 = (int64_t)blockIdx.x * 64;
-    const int64_t rows = n_walkers - r0 < 64 ? n_walkers - r0 : 64;
-    const uint32_t total = (uint32_t)rows * (uint32_t)cols;
-    const uint32_t *src = stage + r0 * cols;
-    int64_t *dst = out + r0 * cols;
-    FastMod fm;
-    fm.init((uint32_t)cols);
-    for (uint32_t e = threadIdx.x; e < total; e += kBlock) {
-        const uint32_t c = fm.mod(e);
-        const int64_t tg = targets[r0 + (e - c) / (uint32_t)cols];
-        const bool dead = (uint64_t)tg >= (uint64_t)n_nodes;  // reported by the walk kernel
-        dst[e] = dead ? tg : (int64_t)src[e];
-    }
-}
-
 // First offset in [0, n) whose entry is >= x (n if none); rows sorted ascending.
 __device__ __forceinline__ uint32_t lower_bound32(const uint32_t *__restrict__ col32, uint32_t start, uint32_t n,
                                                   uint32_t x, uint32_t &probes)
@@ -668,7 +647,7 @@ __global__ void __launch_bounds__(kBlock)
 biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32,
                    const uint32_t *__restrict__ ext, const uint32_t *__restrict__ table, uint32_t mask, const int64_t *__restrict__ targets,
                    int64_t n_nodes, int64_t n_walkers, int64_t walker_base, int32_t L, uint32_t seed,
-                   BiasedParams bp, int32_t want_pos, uint32_t *__restrict__ stage, int64_t *__restrict__ status)
+                   BiasedParams bp, int32_t want_pos, int64_t *__restrict__ out, int64_t *__restrict__ status)
 {
     // Per-lane ring of upcoming draws, draw d of the lane's walker at ring[d % kRing][tid] (slot-major: a
     // lane always hits its own bank).  The ring is topped up for ALL lanes of the wave at once whenever one
@@ -705,7 +684,7 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
     uint32_t slot = 0, ku = 0, kv = 0, ru = 0, rejected = 0;
     uint32_t c_start = 0, c_deg = 0;  // row of the candidate being judged (fat entries only)
     const uint32_t *addr = row32;
-    uint32_t *sp = stage;
+    int64_t *sp = out;
 
     while (true) {
         // ---- hand out walkers to the lanes that need one (one atomic per wave) ----
@@ -723,13 +702,14 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                     state = LS_IDLE;
                 } else {
                     const int64_t tg = targets[walker];
-                    // this kernel stages walker-major: the 16 columns of a 64-byte line are written by one
-                    // lane within a few hundred iterations, so the line is completed in cache instead of
-                    // reaching DRAM as sixteen 32-byte partial writes
-                    sp = stage + walker * (int64_t)(L + 1);
-                    *sp++ = (uint32_t)tg;  // column 0
+                    // lanes advance at their own pace, so nothing is gained by staging lane-contiguously:
+                    // this kernel writes the caller's int64 row directly (8 columns per 64-byte line, all
+                    // written by one lane within a few hundred iterations)
+                    sp = out + walker * (int64_t)(L + 1);
+                    *sp++ = tg;  // column 0
                     if ((uint64_t)tg >= (uint64_t)n_nodes) {
-                        st |= TRW_ST_NODE_RANGE;  // widen_rows_kernel fills the row with the bad id
+                        st |= TRW_ST_NODE_RANGE;  // reported; the row is filled with the bad id
+                        for (int32_t c = 1; c <= L; ++c) *sp++ = tg;
                     } else {
                         gw = (uint64_t)walker_base + (uint64_t)walker;
                         d_cons = 0;
@@ -867,7 +847,7 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
 
         // ---- emit an accepted candidate and move to the next step ----
         if (ev_accept) {
-            *sp++ = cand;
+            *sp++ = (int64_t)cand;
             ++s;
             rejected = 0;
             if (s > L) {
