@@ -418,13 +418,16 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col
             csr_shadow_kernel<true><<<grid, kBlock, 0, stream>>>(row_ptr, col_idx, n_nodes, nnz, row32, col32,
                                                                  status);
     }
-    if (pl.narrow && pl.ext && (uniform ? mode == TRW_RNG_GLIBC : mode == TRW_RNG_WALKER))
+    if (pl.narrow && pl.ext && uniform && mode == TRW_RNG_GLIBC)
         csr_ext_kernel<<<stream_grid(nnz), kBlock, 0, stream>>>(row32, col32, nnz, (u32x4_a16 *)(ws + pl.off_ext));
     if (pl.narrow && pl.hash && mode == TRW_RNG_WALKER) {
         e = hipMemsetAsync(table, 0xFF, ((size_t)pl.hash_mask + 1) * 16, stream);
         if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(edge table)");
         edge_table_build_kernel<<<stream_grid((nnz + 7) / 8), kBlock, 0, stream>>>(row32, col32, n_nodes, nnz, table,
                                                                                  pl.hash_mask, status);
+        if (pl.ext)
+            csr_ext_rpos_kernel<<<stream_grid((nnz + 7) / 8), kBlock, 0, stream>>>(
+                row32, col32, n_nodes, nnz, table, pl.hash_mask, (u32x4_a16 *)(ws + pl.off_ext));
     }
     const unsigned lane_grid = (unsigned)((pl.nlanes + kBlock - 1) / kBlock);
     if (uniform && mode == TRW_RNG_GLIBC) {

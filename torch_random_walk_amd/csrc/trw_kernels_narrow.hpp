@@ -638,6 +638,58 @@ edge_table_build_kernel(const uint32_t *__restrict__ row32, const uint32_t *__re
     }
 }
 
+// Fat entries for the biased walk: ext[e] = {v, start(v), deg(v), rpos} for edge u -> v, where rpos says
+// where u sits in v's row -- exactly what the walker needs after accepting v from u ("where is t in
+// prev's row") -- so that step skips its table probe.  rpos = (multiplicity << 28) | first offset when
+// both fit (multiplicity <= 15, offset < 2^28), 0 = u is not in v's row, 1 = look it up in the table.
+// One thread per 8 consecutive entries, as edge_table_build_kernel; one table probe per entry.
+constexpr uint32_t kRposAbsent = 0u, kRposLookup = 1u;
+
+__global__ void __launch_bounds__(kBlock)
+csr_ext_rpos_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32, int64_t n_nodes,
+                    int64_t nnz, const uint32_t *__restrict__ table, uint32_t mask, u32x4_a16 *__restrict__ ext)
+{
+    constexpr int kPer = 8;
+    const int64_t chunks = (nnz + kPer - 1) / kPer;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x; c < chunks; c += stride) {
+        const uint32_t e0 = (uint32_t)(c * kPer);
+        uint32_t u = 0, n = (uint32_t)n_nodes;
+        while (n > 1) {  // the row that holds entry e0
+            const uint32_t half = n >> 1;
+            if (row32[u + half] <= e0) {
+                u += half;
+                n -= half;
+            } else {
+                n = half;
+            }
+        }
+        uint32_t row_hi = row32[u + 1];
+        for (int k = 0; k < kPer; ++k) {
+            const uint32_t e = e0 + k;
+            if (e >= (uint32_t)nnz) break;
+            while (e >= row_hi && u + 1 < (uint32_t)n_nodes) row_hi = row32[++u + 1];
+            const uint32_t v = col32[e];
+            uint32_t start, deg;
+            load_row32(row32, v, start, deg);
+            uint32_t rpos = kRposAbsent;
+            uint32_t slot = edge_hash(v, u) & mask;
+            while (true) {  // is u in v's row, and where?
+                const u32x4_a16 g = *reinterpret_cast<const u32x4_a16 *>(table + 4 * (size_t)slot);
+                if (g.x == 0xFFFFFFFFu) break;
+                if (g.x == v && g.y == u) {
+                    const uint32_t cnt = g.w + 1u;
+                    rpos = (cnt <= 15u && g.z < (1u << 28)) ? ((cnt << 28) | g.z) : kRposLookup;
+                    break;
+                }
+                slot = (slot + 1) & mask;
+            }
+            u32x4_a16 o = {v, start, deg, rpos};
+            ext[e] = o;
+        }
+    }
+}
+
 enum : uint32_t { LS_IDLE = 0, LS_START, LS_ROW, LS_POS, LS_TRIAL, LS_CAND, LS_MEMBER };
 
 constexpr int kRing = 16;  // draws buffered per lane in LDS (4 Philox blocks)
@@ -682,7 +734,7 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
     fm.z = 0;
     uint32_t d_cons = 0, d_prod = 0;  // draws consumed / produced for the current walker
     uint32_t slot = 0, ku = 0, kv = 0, ru = 0, rejected = 0;
-    uint32_t c_start = 0, c_deg = 0;  // row of the candidate being judged (fat entries only)
+    uint32_t c_start = 0, c_deg = 0, c_rpos = kRposLookup;  // the candidate's row and where prev sits in it (fat entries)
     const uint32_t *addr = row32;
     int64_t *sp = out;
 
@@ -791,6 +843,7 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
             cand = g.x;
             c_start = g.y;
             c_deg = g.z;
+            c_rpos = g.w;
             if (s == 1) {
                 ev_accept = true;
             } else {
@@ -878,12 +931,14 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                     p_start = c_start;
                     p_deg = c_deg;
                     fm.init(p_deg);
-                    if (use_pos) {
+                    if (use_pos && c_rpos == kRposLookup) {
                         ku = prev;
                         kv = t;
                         ev_probe = true;
                         probe_state = LS_POS;
-                    } else {
+                    } else {  // the entry already said where t sits in prev's row
+                        pos_lo = c_rpos & 0x0FFFFFFFu;
+                        pos_cnt = c_rpos >> 28;
                         state = LS_TRIAL;
                     }
                 } else {
