@@ -1,0 +1,108 @@
+"""Seeded fuzzing of the HIP paths against the oracle (pytest -m gpu): random small graphs with multi-edges,
+self-loops, hubs and dead ends; random p/q, walk lengths, batch sizes, walker bases, kernel variants.
+Every case is bit-exact or the test fails with the case's parameters in the message."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+PQS = [(1.0, 1.0), (0.25, 4.0), (4.0, 0.25), (0.7, 0.5), (1.0, 2.0), (3.0, 1.0), (1.0, 1.0 + 1e-9), (0.01, 50.0)]
+
+
+def _graph(rng, n, with_dead_ends):
+    """CSR with rows sorted, multi-edges and self-loops allowed; optionally some empty rows."""
+    m = int(rng.integers(n, 6 * n))
+    src = rng.integers(0, n, m)
+    dst = rng.integers(0, n, m)
+    hub = int(rng.integers(0, n))
+    k = int(rng.integers(1, max(2, n // 2)))
+    spokes = rng.integers(0, n, k)
+    src = np.concatenate([src, np.full(k, hub), spokes, rng.integers(0, n, 5).repeat(3)])
+    dst = np.concatenate([dst, spokes, np.full(k, hub), rng.integers(0, n, 5).repeat(3)])      # + multi-edges
+    if not with_dead_ends:
+        src = np.concatenate([src, np.arange(n)])
+        dst = np.concatenate([dst, (np.arange(n) + 1) % n])
+    else:
+        keep = src % 5 != 2
+        src, dst = src[keep], dst[keep]
+    order = np.lexsort((dst, src))
+    src, dst = src[order], dst[order]
+    row_ptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(src, minlength=n), out=row_ptr[1:])
+    return row_ptr, dst.astype(np.int64), src.astype(np.int64)
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_fuzz_csr_walk(case, monkeypatch):
+    from torch_rw import rw
+    rng = np.random.default_rng(1000 + case)
+    n = int(rng.integers(2, 400))
+    rp, ci, _ = _graph(rng, n, with_dead_ends=False)
+    N = int(rng.integers(1, 3000))
+    L = int(rng.integers(1, 45))
+    seed = int(rng.integers(-2**31, 2**31))
+    base = int(rng.choice([0, 1, 77, 2**32 + 3]))
+    p, q = PQS[int(rng.integers(0, len(PQS)))]
+    tg = rng.integers(0, n, N)
+    env = [{}, {"TRW_HASH": "0"}, {"TRW_HASH": "1", "TRW_EXT": "1"}, {"TRW_EXT": "1"}, {"TRW_FORCE_WIDE": "1"},
+           {"TRW_NO_POS": "1"}][case % 6]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    d = [torch.as_tensor(a).to(DEV) for a in (rp, ci, tg)]
+    msg = "case %d n=%d N=%d L=%d seed=%d base=%d p=%g q=%g env=%s" % (case, n, N, L, seed, base, p, q, env)
+    if p == 1.0 and q == 1.0:
+        ref = O.walk(rp, ci, tg, p, q, L, seed, rng_mode=O.RNG_GLIBC_INDEXED, walker_base=base)
+        got = rw.walk_ex(*d, p, q, L, seed, walker_base=base, rng_mode=rw.RNG_GLIBC)
+        assert (got.cpu().numpy() == ref).all(), msg
+    ref = O.walk(rp, ci, tg, p, q, L, seed, rng_mode=O.RNG_WALKER, walker_base=base)
+    got = rw.walk_ex(*d, p, q, L, seed, walker_base=base, rng_mode=rw.RNG_WALKER)
+    assert (got.cpu().numpy() == ref).all(), msg
+    if N * L <= 20000 and not (p == 1.0 and q == 1.0):
+        ref = O.walk(rp, ci, tg, p, q, L, seed, rng_mode=O.RNG_GLIBC_SEQ)
+        got = rw.walk_ex(*d, p, q, L, seed, rng_mode=rw.RNG_GLIBC)
+        assert (got.cpu().numpy() == ref).all(), msg + " (serial replay)"
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_fuzz_edge_list_and_triples(case, monkeypatch):
+    from torch_rw import rw, utils
+    rng = np.random.default_rng(5000 + case)
+    n = int(rng.integers(2, 300))
+    _, ci, src = _graph(rng, n, with_dead_ends=True)
+    shuffle = rng.permutation(len(src))                      # tails unsorted within a head, like the reference's builder
+    edges = torch.as_tensor(np.stack([src[shuffle], ci[shuffle]], 1))
+    index, edges_sorted = utils.build_node_edge_index(edges, torch.arange(n))
+    N = int(rng.integers(1, 1500))
+    L = int(rng.integers(1, 30))
+    seed = int(rng.integers(0, 2**31))
+    pad = n if case % 3 else int(rng.integers(0, n))
+    p, q = PQS[int(rng.integers(0, len(PQS)))]
+    restart = bool(case % 2)
+    tg = rng.integers(0, n, N)
+    tg[::11] = pad
+    if case % 4 == 1:
+        monkeypatch.setenv("TRW_HASH", "0")
+    d = [edges_sorted.to(DEV), index.to(DEV), torch.as_tensor(tg).to(DEV)]
+    msg = "case %d n=%d N=%d L=%d seed=%d pad=%d p=%g q=%g restart=%s" % (case, n, N, L, seed, pad, p, q, restart)
+    ref = O.walk_edge_list(edges_sorted.numpy(), index.numpy(), tg, p, q, L, seed, pad, restart=restart,
+                           rng_mode=O.RNG_WALKER, walker_base=5)
+    got = rw.walk_edge_list_ex(*d, p, q, L, seed, pad, restart=restart, walker_base=5, rng_mode=rw.RNG_WALKER)
+    assert (got.cpu().numpy() == ref).all(), msg
+    if N * L <= 20000:
+        ref = O.walk_edge_list(edges_sorted.numpy(), index.numpy(), tg, p, q, L, seed, pad, restart=restart,
+                               rng_mode=O.RNG_GLIBC_SEQ)
+        got = rw.walk_edge_list_ex(*d, p, q, L, seed, pad, restart=restart, rng_mode=rw.RNG_GLIBC)
+        assert (got.cpu().numpy() == ref).all(), msg + " (serial replay)"
+    # the same edges as a knowledge graph with random relations
+    rel = rng.integers(n, n + 7, len(src))
+    triples = torch.as_tensor(np.stack([src[shuffle], rel, ci[shuffle]], 1))
+    tindex, tsorted = utils.build_relation_tail_index(triples, torch.arange(n))
+    kpad = n + 7
+    tgk = np.where(tg == pad, kpad, tg)
+    ref = O.walk_triples(tsorted.numpy(), tindex.numpy(), tgk, L, kpad, seed, rng_mode=O.RNG_WALKER, walker_base=9)
+    got = rw.walk_triples_ex(tsorted.to(DEV), tindex.to(DEV), torch.as_tensor(tgk).to(DEV), L, kpad, seed,
+                             walker_base=9, rng_mode=rw.RNG_WALKER)
+    assert (got.cpu().numpy() == ref).all(), msg + " (triples)"
