@@ -32,11 +32,14 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this pool needs dmabuf IPC (set before HIP starts; the driver exports it already)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); a device copy sustains 4750 (machine probe)
 
 WORKLOADS = {
     "rmat10m_biased": dict(graph="rmat", nodes=10_000_000, edges=100_000_000, p=0.25, q=4.0, walks_per_node=1),
@@ -350,6 +353,32 @@ def main():
         except Exception:
             traffic = None
 
+    # The walk kernels are divergent gathers: what bounds them is the rate of L2-miss requests the memory
+    # system sustains (scripts/machine_probe.hip measures it on the box: the same for 4-, 8- and 16-byte
+    # gathers, falling slowly with the footprint), not bytes.  Quote the kernel's miss rate (PMC pass of
+    # the same command, profiles/pmc_traffic.json) against that measured ceiling next to the HBM roofline.
+    request_rate = None
+    try:
+        with open(pmc_path) as f:
+            misses = json.load(f).get(args.workload, {}).get("TCC_MISS")
+        ceiling, copy_gbs = None, None
+        with open(os.path.join(ROOT, "profiles", "r01_machine_probe.txt")) as f:
+            for ln in f:
+                tok = ln.split()
+                if ln.startswith("stream_copy"):
+                    copy_gbs = float(ln.split("per copy,")[1].split()[0])
+                elif len(tok) >= 5 and tok[1] == "MB" and int(tok[0]) >= 4096:
+                    best = max(float(x) for x in tok[2:])
+                    ceiling = best if ceiling is None else min(ceiling, best)  # the largest footprints
+        if misses and ceiling and k_ms > 0:
+            request_rate = dict(l2_misses_per_launch=misses, achieved_per_s=misses / (k_ms * 1e-3),
+                                ceiling_per_s=ceiling, frac=misses / (k_ms * 1e-3) / ceiling,
+                                measured_stream_copy_GBps=copy_gbs,
+                                source="profiles/pmc_traffic.json (TCC_MISS) / profiles/r01_machine_probe.txt "
+                                       "(dependent random gathers over >= 4 GB, 8 waves per SIMD)")
+    except Exception:
+        request_rate = None
+
     # ---- CPU baseline: the reference's algorithm on a bounded sample (rank 0, N = 1 only) ------
     cpu = None
     reference_accounting = None
@@ -479,6 +508,7 @@ def main():
                 "finish_ms": sum(finish_ms) / max(1, len(finish_ms)),
                 "kernel_steps_per_s": steps_per_launch / (k_ms * 1e-3) if k_ms > 0 else None,
                 "counters": counters,
+                "request_rate": request_rate,
                 "reference_accounting": reference_accounting,
             },
             "cpu_baseline": cpu,

@@ -559,6 +559,7 @@ biased_walker_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restr
 // Results are identical to biased_walker_kernel (same stream, same decisions).
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef int64_t i64x2_a16 __attribute__((ext_vector_type(2)));
 
 constexpr int kStNextWalker = 10;  // status slot: next unassigned walker (dynamic distribution)
 
@@ -693,6 +694,13 @@ csr_ext_rpos_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restri
 enum : uint32_t { LS_IDLE = 0, LS_START, LS_ROW, LS_POS, LS_TRIAL, LS_CAND, LS_MEMBER };
 
 constexpr int kRing = 16;  // draws buffered per lane in LDS (4 Philox blocks)
+// Rejection trials a lane may run back to back in one iteration while they need no memory.  The body of
+// the iteration is executed by the wave for the union of its lanes' states (~250 VALU instructions), so
+// an iteration spent on a memory-free trial alone is expensive.
+#ifndef TRW_TRIALS_PER_ITER
+#define TRW_TRIALS_PER_ITER 4
+#endif
+constexpr int kTrialsPerIter = TRW_TRIALS_PER_ITER;
 
 template <bool kCount>
 __global__ void __launch_bounds__(kBlock)
@@ -737,6 +745,33 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
     uint32_t c_start = 0, c_deg = 0, c_rpos = kRposLookup;  // the candidate's row and where prev sits in it (fat entries)
     const uint32_t *addr = row32;
     int64_t *sp = out;
+    // Write combining: the last (up to) four columns of the lane's row wait in registers until they fill a
+    // 32-byte-aligned group of the caller's row, the granule a partial HBM write costs anyway (one write
+    // request per four columns instead of one per column).
+    uint32_t wb0 = 0, wb1 = 0, wb2 = 0, wb3 = 0;
+    auto emit = [&](uint32_t v, int32_t col) {
+        const uint32_t k = (uint32_t)((uintptr_t)sp >> 3) & 3u;
+        wb0 = k == 0u ? v : wb0;
+        wb1 = k == 1u ? v : wb1;
+        wb2 = k == 2u ? v : wb2;
+        wb3 = k == 3u ? v : wb3;
+        ++sp;
+        if (k == 3u || col == L) {
+            const uint32_t have = min(k + 1u, (uint32_t)col + 1u);  // columns of THIS row in the group
+            int64_t *grp = sp - (k + 1u);
+            if (have == 4u) {
+                const i64x2_a16 lo2 = {(int64_t)wb0, (int64_t)wb1}, hi2 = {(int64_t)wb2, (int64_t)wb3};
+                *reinterpret_cast<i64x2_a16 *>(grp) = lo2;
+                *reinterpret_cast<i64x2_a16 *>(grp + 2) = hi2;
+            } else {
+                const uint32_t first = k + 1u - have;
+                if (first == 0u) grp[0] = (int64_t)wb0;
+                if (first <= 1u && k >= 1u) grp[1] = (int64_t)wb1;
+                if (first <= 2u && k >= 2u) grp[2] = (int64_t)wb2;
+                if (k >= 3u) grp[3] = (int64_t)wb3;
+            }
+        }
+    };
 
     while (true) {
         // ---- hand out walkers to the lanes that need one (one atomic per wave) ----
@@ -755,14 +790,13 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                 } else {
                     const int64_t tg = targets[walker];
                     // lanes advance at their own pace, so nothing is gained by staging lane-contiguously:
-                    // this kernel writes the caller's int64 row directly (8 columns per 64-byte line, all
-                    // written by one lane within a few hundred iterations)
+                    // this kernel writes the caller's int64 row directly, four columns at a time (emit)
                     sp = out + walker * (int64_t)(L + 1);
-                    *sp++ = tg;  // column 0
                     if ((uint64_t)tg >= (uint64_t)n_nodes) {
                         st |= TRW_ST_NODE_RANGE;  // reported; the row is filled with the bad id
-                        for (int32_t c = 1; c <= L; ++c) *sp++ = tg;
+                        for (int32_t c = 0; c <= L; ++c) *sp++ = tg;
                     } else {
+                        emit((uint32_t)tg, 0);  // column 0
                         gw = (uint64_t)walker_base + (uint64_t)walker;
                         d_cons = 0;
                         d_prod = 0;
@@ -785,7 +819,7 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
 
         // ---- top up the draw rings when some lane is about to run dry ----
         const bool live = state != LS_IDLE && state != LS_START;
-        if (__ballot(live && d_prod - d_cons < 2u)) {
+        if (__ballot(live && d_prod - d_cons < 2u * kTrialsPerIter)) {
             while (__ballot(live && d_prod - d_cons <= (uint32_t)(kRing - 4))) {
                 if (live && d_prod - d_cons <= (uint32_t)(kRing - 4)) {
                     uint32_t blk[4];
@@ -874,7 +908,7 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
         }
 
         // ---- one rejection trial for every lane that is between gathers ----
-        if (state == LS_TRIAL && !ev_accept && d_prod - d_cons >= 2u) {
+        for (int rep = 0; rep < kTrialsPerIter && state == LS_TRIAL && !ev_accept && d_prod - d_cons >= 2u; ++rep) {
             const uint32_t rc = my_ring[(d_cons & (kRing - 1)) * kBlock] >> 1;
             ru = my_ring[((d_cons + 1) & (kRing - 1)) * kBlock] >> 1;
             d_cons += 2;
@@ -900,7 +934,7 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
 
         // ---- emit an accepted candidate and move to the next step ----
         if (ev_accept) {
-            *sp++ = (int64_t)cand;
+            emit(cand, s);
             ++s;
             rejected = 0;
             if (s > L) {
