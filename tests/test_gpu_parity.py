@@ -358,3 +358,15 @@ def test_config3_rmat_biased_reduced_walkers(rw):
     tg = torch.arange(1_000_000, device=DEV)[:200_000]
     _check_big(rw, rp, ci, tg, 0.25, 4.0, 80, 10, O.RNG_WALKER, sample=300)
     _check_big(rw, rp, ci, tg, 1.0, 1.0, 80, 10, O.RNG_GLIBC_INDEXED, sample=300)
+
+
+def test_config3_rmat10m_full_size(rw):
+    """BASELINE config 3 at full size (the graph the north-star target is quoted on): R-MAT 10M nodes /
+    100M directed edges + ring, one walker per node, L=80 -- node2vec p=0.25 q=4 on the per-walker stream
+    and the uniform walk on glibc's stream.  Size-independent properties (deterministic, every step an edge,
+    shard invariance) plus sampled rows against the oracle."""
+    from torch_random_walk_amd import graphs
+    rp, ci = graphs.rmat(10_000_000, 100_000_000, seed=1, device=DEV)
+    tg = torch.arange(10_000_000, device=DEV)
+    _check_big(rw, rp, ci, tg, 0.25, 4.0, 80, 10, O.RNG_WALKER, sample=48)
+    _check_big(rw, rp, ci, tg, 1.0, 1.0, 80, 10, O.RNG_GLIBC_INDEXED, sample=48)
