@@ -16,8 +16,8 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 DOMINANT = {"rmat10m_biased": ("biased_hash_kernel", "biased_walker_kernel"),
-            "rmat10m_uniform": ("uniform_glibc_ext_kernel", "uniform_glibc_kernel"),
-            "er100k_uniform": ("uniform_glibc_kernel", "uniform_glibc_ext_kernel"),
+            "rmat10m_uniform": ("uniform_glibc_rows_kernel", "uniform_glibc_ext_kernel", "uniform_glibc_kernel"),
+            "er100k_uniform": ("uniform_glibc_rows_kernel", "uniform_glibc_kernel", "uniform_glibc_ext_kernel"),
             "kg5m_triples": ("triples_walker_kernel",), "elist_rmat1m_biased": ("elist_walk_kernel",),
             "elist_rmat1m_uniform": ("elist_walk_kernel",), "windows_1m": ("glibc_fill_mod_kernel",)}
 traffic_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")

@@ -237,6 +237,54 @@ def test_runs_on_the_callers_stream(rw):
     assert (out.cpu().numpy() == O.walk(rp, ci, np.arange(200), 1.0, 1.0, 30, 10)).all()
 
 
+@pytest.mark.parametrize("ext", ["0", "1"])
+def test_uniform_rows_any_alignment(rw, ext, monkeypatch):
+    """The uniform kernel writes the caller's rows one 64-byte line at a time, and which columns make up
+    a line depends on where the row starts: every row length modulo 8, every start offset of `out`
+    modulo 64 bytes, walker counts that do not fill the last wave, chained walkers -- and never a byte
+    outside the rows."""
+    from torch_random_walk_amd import _native
+    lib = _native.cabi()
+    monkeypatch.setenv("TRW_EXT", ext)
+    rp, ci = random_graph(200, 4, 33)
+    d_rp, d_ci = _dev(rp, ci)
+    stream = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(4)
+    for L, N, chain, shift in ((1, 1, 1, 0), (2, 65, 1, 1), (6, 130, 2, 2), (7, 64, 1, 3), (8, 300, 3, 4),
+                               (9, 257, 1, 5), (14, 191, 4, 6), (15, 500, 1, 7), (16, 63, 5, 1), (23, 1000, 2, 0),
+                               (33, 129, 7, 3), (80, 777, 1, 5), (81, 640, 4, 2), (127, 100, 1, 7)):
+        monkeypatch.setenv("TRW_GLIBC_CHAIN", str(chain))
+        tg = rng.integers(0, 200, N)
+        d_tg = torch.as_tensor(tg, device=DEV)
+        guard = 16
+        buf = torch.full((N * (L + 1) + 2 * guard + 8,), -7, dtype=torch.int64, device=DEV)
+        out = buf[guard + shift: guard + shift + N * (L + 1)]
+        nbytes = lib.trw_walk_csr_workspace_bytes(200, len(ci), N, L, 1.0, 1.0, 1)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+        rc = lib.trw_walk_csr_hip(d_rp.data_ptr(), 200, d_ci.data_ptr(), len(ci), d_tg.data_ptr(), N, 0, 1.0, 1.0,
+                                  L, 10, 1, out.data_ptr(), ws.data_ptr(), nbytes, stream)
+        assert rc == 0, lib.trw_last_error()
+        ref = O.walk(rp, ci, tg, 1.0, 1.0, L, 10)
+        assert (out.view(N, L + 1).cpu().numpy() == ref).all(), (L, N, chain, shift)
+        assert bool((buf[:guard + shift] == -7).all()) and bool((buf[guard + shift + N * (L + 1):] == -7).all())
+
+
+def test_uniform_rows_bad_targets_fill_their_rows(rw):
+    rp, ci = random_graph(100, 3, 2)
+    tg = np.arange(100).repeat(3)
+    tg[[5, 64, 299]] = [100, -1, 2**40]
+    d_rp, d_ci, d_tg = _dev(rp, ci, tg)
+    w = rw.walk_ex(d_rp, d_ci, d_tg, 1.0, 1.0, 20, 3, check=False).cpu().numpy()
+    ok = np.ones(300, dtype=bool)
+    ok[[5, 64, 299]] = False
+    for r in (5, 64, 299):
+        assert (w[r] == tg[r]).all()
+    good = tg.copy()
+    good[~ok] = 0
+    ref = O.walk(rp, ci, good, 1.0, 1.0, 20, 3)
+    assert (w[ok] == ref[ok]).all()
+
+
 # ---- through the bare C ABI ----------------------------------------------------------------
 
 def test_c_abi_direct_call(rw):
@@ -262,6 +310,8 @@ def test_c_abi_direct_call(rw):
 VARIANTS = [{"TRW_FORCE_WIDE": "1"},                      # int64 kernels
             {"TRW_EXT": "0"},                            # uniform: compact shadow, two gathers per step
             {"TRW_EXT": "1"},                            # uniform: fat entries, one gather per step
+            {"TRW_UNIFORM_DIRECT": "0"},                 # uniform: staging planes + transpose pass
+            {"TRW_UNIFORM_DIRECT": "0", "TRW_EXT": "1"},
             {"TRW_HASH": "0"},                           # bisection kernel, located-t shortcut
             {"TRW_HASH": "0", "TRW_NO_POS": "1"},        # bisection kernel, every candidate loaded
             {"TRW_HASH": "1"},                           # edge table + state machine

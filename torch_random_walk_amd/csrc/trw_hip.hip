@@ -114,6 +114,7 @@ struct Plan {
     int64_t nlanes = 0;
     bool hash = false;     // biased: edge hash table + state-machine kernel
     bool ext = false;      // uniform: fat entries {v, start(v), deg(v)}, one gather per step
+    bool direct = false;   // uniform: the walk kernel writes the int64 rows itself (no staging, no transpose)
     uint32_t hash_mask = 0;
     size_t off_win = 0, off_row32 = 0, off_col32 = 0, off_stage = 0, off_table = 0, off_ext = 0, total = 0;
 };
@@ -182,7 +183,10 @@ Plan make_plan(int64_t n_nodes, int64_t nnz, int64_t n_walkers, int32_t L, bool 
                 }
             }
         }
-        if (uniform || !pl.hash) {  // biased_hash_kernel writes the caller's rows itself
+        // (uniform_glibc_rows_kernel addresses a wave's 64 rows with a 32-bit byte offset)
+        pl.direct = uniform && (int64_t)64 * pl.G * ((int64_t)L + 1) < ((int64_t)1 << 29) &&
+                    env_long("TRW_UNIFORM_DIRECT", 0, 1, 1) == 1;
+        if ((uniform && !pl.direct) || (!uniform && !pl.hash)) {  // the other kernels write the caller's rows themselves
             pl.off_stage = off;
             off += align_up((size_t)pl.nlanes * pl.G * (size_t)(L + 1) * sizeof(uint32_t), 256);
         }
@@ -466,7 +470,15 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col
     prof_mark(1, stream);
     if (uniform) {
         if (mode == TRW_RNG_GLIBC) {
-            if (pl.narrow && pl.ext)
+            if (pl.narrow && pl.direct && pl.ext)
+                uniform_glibc_rows_kernel<true><<<lane_grid, kBlock, 0, stream>>>(
+                    row32, col32, (const u32x4_a16 *)(ws + pl.off_ext), targets, n_nodes, n_walkers, walk_length,
+                    pl.G, pl.nlanes, win, out, status);
+            else if (pl.narrow && pl.direct)
+                uniform_glibc_rows_kernel<false><<<lane_grid, kBlock, 0, stream>>>(
+                    row32, col32, nullptr, targets, n_nodes, n_walkers, walk_length, pl.G, pl.nlanes, win, out,
+                    status);
+            else if (pl.narrow && pl.ext)
                 uniform_glibc_ext_kernel<8><<<lane_grid, kBlock, 0, stream>>>(
                     row32, (const u32x4_a16 *)(ws + pl.off_ext), targets, n_nodes, n_walkers, walk_length, pl.G,
                     pl.nlanes, win, stage, status);
@@ -531,7 +543,7 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col
     // ---- finish ----------------------------------------------------------------------------
     prof_mark(2, stream);
     const bool staged = pl.narrow && (uniform ? mode == TRW_RNG_GLIBC : mode == TRW_RNG_WALKER);
-    if (staged && !(!uniform && pl.hash)) {  // biased_hash_kernel writes the int64 rows itself
+    if (staged && !(!uniform && pl.hash) && !(uniform && pl.direct)) {  // those kernels write the int64 rows themselves
         const dim3 grid((unsigned)((pl.nlanes + 63) / 64), (unsigned)pl.G);
         transpose_rows_kernel<<<grid, kBlock, 0, stream>>>(stage, targets, n_nodes, n_walkers, walk_length, pl.G,
                                                           pl.nlanes, out);

@@ -271,6 +271,169 @@ uniform_glibc_ext_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__
 }
 
 // ---------------------------------------------------------------------------
+// Lane-per-walker columns -> line-aligned int64 row stores, inside the walk kernel
+// ---------------------------------------------------------------------------
+// The lanes of a wave advance in lockstep (same column of 64 different rows).  Each lane parks its
+// columns in a 16-slot ring of a per-wave LDS tile; every 8 columns the wave writes, for each of its 64
+// rows, the one 64-byte line of the caller's [N, L+1] int64 tensor that has just become complete (8 lanes
+// per row, 8 rows per pass) -- rows start at any multiple of 8 bytes, so which columns make up a line
+// differs from row to row (`phase`).  Only full, aligned lines reach HBM (a row's first and last line
+// excepted).  This replaces the uint32 staging planes and the transpose pass.
+constexpr int kTileCols = 16;
+constexpr int kTileStride = kTileCols + 1;  // odd stride: conflict-free lane-per-row writes
+constexpr uint32_t kTileSkip = 0xFFFFFFFFu;  // not a node id (ids < 2^31): nothing to write for this row
+
+struct WaveRows {
+    uint32_t *t;  // this wave's tile, [64][kTileStride]
+    int lane;     // lane within the wave
+    __device__ __forceinline__ void put(int32_t col, uint32_t v) { t[lane * kTileStride + (col & (kTileCols - 1))] = v; }
+
+    // Call after column c of every row is in the tile, when (c & 7) == 7 or c is the last column.
+    // Rows: walker `walker0 + r * walker_stride` for wave lane r.  Everything but the lane's offset inside
+    // the wave's block of rows is wave-uniform and lives in scalar registers (the host guarantees
+    // 64 * walker_stride * cols * 8 < 2^32, so that offset is a 32-bit byte offset).
+    __device__ __forceinline__ void flush(int64_t walker0, int32_t walker_stride, int64_t n_walkers, int32_t cols,
+                                          int32_t c, int64_t *__restrict__ out) const
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int64_t w0 = walker0;  // wave-uniform by contract
+        int64_t left = n_walkers - w0;  // rows of this wave that exist: those with r * stride < left
+        left = left < 0 ? 0 : (left + walker_stride - 1) / walker_stride;
+        const int nrows = left > 64 ? 64 : (int)left;
+        int64_t *base = out + w0 * cols;
+        const uint32_t phase0 = (uint32_t)((uintptr_t)base >> 3);  // low 3 bits: where row 0 starts in its line
+        const uint32_t row_elems = (uint32_t)walker_stride * (uint32_t)cols;
+        // (opaque copy: keeps the compiler from hoisting every pass's per-lane offsets out of the walk loop
+        // into registers that the 31-word generator window needs)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int e = ln & 7;
+        const bool last = c == cols - 1;
+        // group j of a row = the columns of its j-th line: [8j - phase, 8j - phase + 8)
+        const int j0 = last ? (cols - 1) >> 3 : c >> 3;  // the groups completed before were written before
+        const int j1 = last ? j0 + 1 : j0;
+        for (int j = j0; j <= j1; ++j) {
+#pragma unroll 2
+            for (int pass = 0; pass < 8; ++pass) {
+                const int row = 8 * pass + (ln >> 3);
+                const uint32_t off0 = (uint32_t)row * row_elems;
+                const int32_t col = 8 * j - (int32_t)((phase0 + off0) & 7u) + e;
+                if (col >= 0 && col <= c && row < nrows) {
+                    const uint32_t v = t[row * kTileStride + (col & (kTileCols - 1))];
+                    if (v != kTileSkip) base[off0 + (uint32_t)col] = (int64_t)v;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+};
+
+// The uniform walk with its rows written by the walk kernel itself (WaveRows).  Same walkers per lane, same
+// draws as uniform_glibc_kernel / uniform_glibc_ext_kernel; the generator window is still indexed
+// statically, but four draws at a time through a 31-way wave-uniform switch, so that the step (with its
+// row-flush code) exists four times in the kernel instead of once per window position.
+#define TRW_GEN4(J)                                                                     \
+    case J: {                                                                           \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                              \
+            constexpr int base_ = J;                                                    \
+            const int jj_ = (base_ + i_) % kGlDeg;                                      \
+            const uint32_t v_ = w[jj_] + w[(jj_ + kGlDeg - kGlSep) % kGlDeg];           \
+            w[jj_] = v_;                                                                \
+            d[i_] = v_ >> 1;                                                            \
+        }                                                                               \
+    } break;
+
+template <bool kFat>
+__global__ void __launch_bounds__(kBlock, 8)
+uniform_glibc_rows_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32,
+                          const u32x4_a16 *__restrict__ ext, const int64_t *__restrict__ targets, int64_t n_nodes,
+                          int64_t n_walkers, int32_t L, int32_t G, int64_t nlanes, const uint32_t *__restrict__ win,
+                          int64_t *__restrict__ out, int64_t *__restrict__ status)
+{
+    __shared__ uint32_t tiles[(kBlock / 64) * 64 * kTileStride];
+    const int64_t lane = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (lane == 0) {
+        status[2] = TRW_RNG_GLIBC;
+        status[3] = kFat ? 3 : 1;
+    }
+    const bool in_range = lane < nlanes;  // the whole wave stays: every lane helps writing the wave's rows
+    WaveRows rows = {tiles + (threadIdx.x >> 6) * 64 * kTileStride, (int)(threadIdx.x & 63)};
+    // first walker of the wave's lane 0: wave-uniform, kept in scalar registers
+    const int64_t wave_walker0 = ((int64_t)blockIdx.x * kBlock + (__builtin_amdgcn_readfirstlane(threadIdx.x) & ~63u)) * G;
+
+    uint32_t w[kGlDeg];
+#pragma unroll
+    for (int j = 0; j < kGlDeg; ++j) w[j] = in_range ? win[(int64_t)j * nlanes + lane] : 0u;
+
+    uint32_t st = 0;
+    int64_t walker = lane * G;
+    int32_t s = 0;  // next column of the current walker; 0 = start a new walker
+    int32_t g = 0;  // which of the lane's G walkers
+    uint32_t cur = 0, start = 0, deg = 0;
+    bool live = false;
+    const int32_t total = G * L;
+
+    auto step = [&](uint32_t r) {
+        if (s == 0) {  // wave-uniform: every lane starts its next walker together
+            live = walker < n_walkers;
+            if (live) {
+                const int64_t tg = targets[walker];
+                if ((uint64_t)tg >= (uint64_t)n_nodes) {  // reported; the row is filled with the bad id
+                    st |= TRW_ST_NODE_RANGE;
+                    live = false;
+                    for (int32_t c = 0; c <= L; ++c) out[walker * (int64_t)(L + 1) + c] = tg;
+                }
+                cur = (uint32_t)tg;
+                if (kFat && live) load_row32(row32, cur, start, deg);  // the only row32 gather of the walk
+            }
+            rows.put(0, live ? cur : kTileSkip);
+            s = 1;
+        }
+        if (live) {
+            if (!kFat) load_row32(row32, cur, start, deg);
+            if (deg == 0) {
+                st |= TRW_ST_DEGREE0;  // rw_cpu.cpp:20 divides by zero here
+            } else if (kFat) {
+                const u32x4_a16 x = ext[start + r % deg];
+                cur = x.x;
+                start = x.y;
+                deg = x.z;
+            } else {
+                cur = col32[start + r % deg];
+            }
+        }
+        rows.put(s, live ? cur : kTileSkip);
+        if ((s & 7) == 7 || s == L) rows.flush(wave_walker0 + g, G, n_walkers, L + 1, s, out);
+        if (++s > L) {
+            s = 0;
+            ++walker;
+            ++g;
+        }
+    };
+
+    int32_t j0 = 0;  // window position of the next draw
+    for (int32_t base = 0; base < total; base += 4) {
+        uint32_t d[4];
+        switch (j0) {
+            TRW_GEN4(0) TRW_GEN4(1) TRW_GEN4(2) TRW_GEN4(3) TRW_GEN4(4) TRW_GEN4(5) TRW_GEN4(6) TRW_GEN4(7)
+            TRW_GEN4(8) TRW_GEN4(9) TRW_GEN4(10) TRW_GEN4(11) TRW_GEN4(12) TRW_GEN4(13) TRW_GEN4(14) TRW_GEN4(15)
+            TRW_GEN4(16) TRW_GEN4(17) TRW_GEN4(18) TRW_GEN4(19) TRW_GEN4(20) TRW_GEN4(21) TRW_GEN4(22) TRW_GEN4(23)
+            TRW_GEN4(24) TRW_GEN4(25) TRW_GEN4(26) TRW_GEN4(27) TRW_GEN4(28) TRW_GEN4(29) TRW_GEN4(30)
+        default: d[0] = d[1] = d[2] = d[3] = 0; break;
+        }
+        j0 += 4;
+        if (j0 >= kGlDeg) j0 -= kGlDeg;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (base + i < total) step(d[i]);  // wave-uniform
+    }
+    if (st) atomicOr((unsigned long long *)&status[0], (unsigned long long)st);
+}
+#undef TRW_GEN4
+
+// ---------------------------------------------------------------------------
 // Staging planes -> [N, L+1] int64 rows
 // ---------------------------------------------------------------------------
 // Walker i = lane*G + g keeps column c at stage[(g*(L+1)+c)*nlanes + lane].  A
