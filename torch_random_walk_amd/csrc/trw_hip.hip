@@ -240,7 +240,7 @@ unsigned stream_grid(int64_t items)
 namespace {
 struct TriplesPlan {
     bool narrow = false;
-    size_t off_rt32 = 0, off_ix32 = 0, off_stage = 0, total = 0;
+    size_t off_rt32 = 0, off_ix32 = 0, total = 0;
 };
 
 TriplesPlan make_triples_plan(int64_t n_triples, int64_t n_entities, int64_t n_walkers, int32_t L,
@@ -250,14 +250,13 @@ TriplesPlan make_triples_plan(int64_t n_triples, int64_t n_entities, int64_t n_w
     size_t off = kStatusBytes;
     const bool fits = n_entities < ((int64_t)1 << 31) && n_triples < ((int64_t)1 << 32) - 64 && padding_idx >= 0 &&
                       padding_idx < ((int64_t)1 << 31) && env_long("TRW_FORCE_WIDE", 0, 1, 0) == 0;
-    pl.narrow = fits && rng_mode != TRW_RNG_GLIBC && n_walkers > 0 && L >= 1;
+    // (L < 2^21: triples_walker_kernel addresses a wave's 64 rows with a 32-bit byte offset)
+    pl.narrow = fits && rng_mode != TRW_RNG_GLIBC && n_walkers > 0 && L >= 1 && L < (1 << 21);
     if (pl.narrow) {
         pl.off_rt32 = off;
         off += align_up((size_t)n_triples * 8 + 64, 256);
         pl.off_ix32 = off;
         off += align_up((size_t)n_entities * 8 + 64, 256);
-        pl.off_stage = off;
-        off += align_up((size_t)n_walkers * (2 * (size_t)L + 1) * sizeof(uint32_t), 256);
     }
     pl.total = off;
     return pl;
@@ -279,7 +278,7 @@ struct EdgeListPlan {
     bool narrow = false;
     bool hash = false;
     uint32_t hash_mask = 0;
-    size_t off_tail32 = 0, off_ix32 = 0, off_stage = 0, off_table = 0, total = 0;
+    size_t off_tail32 = 0, off_ix32 = 0, off_table = 0, total = 0;
 };
 
 EdgeListPlan make_elist_plan(int64_t n_edges, int64_t n_nodes, int64_t n_walkers, int32_t L, int64_t padding_idx,
@@ -289,14 +288,13 @@ EdgeListPlan make_elist_plan(int64_t n_edges, int64_t n_nodes, int64_t n_walkers
     size_t off = kStatusBytes;
     const bool fits = n_nodes < ((int64_t)1 << 31) && n_edges < ((int64_t)1 << 32) - 64 && padding_idx >= 0 &&
                       padding_idx < ((int64_t)1 << 31) && env_long("TRW_FORCE_WIDE", 0, 1, 0) == 0;
-    pl.narrow = fits && rng_mode != TRW_RNG_GLIBC && n_walkers > 0 && L >= 1;
+    // (L < 2^22: elist_walk_kernel addresses a wave's 64 rows with a 32-bit byte offset)
+    pl.narrow = fits && rng_mode != TRW_RNG_GLIBC && n_walkers > 0 && L >= 1 && L < (1 << 22);
     if (pl.narrow) {
         pl.off_tail32 = off;
         off += align_up((size_t)n_edges * 4 + 64, 256);
         pl.off_ix32 = off;
         off += align_up((size_t)n_nodes * 8 + 64, 256);
-        pl.off_stage = off;
-        off += align_up((size_t)n_walkers * ((size_t)L + 1) * sizeof(uint32_t), 256);
         if (!uniform) {  // same rule as the CSR walk: build the edge table when the batch will out-query the graph
             uint64_t cap = 1024;
             while (cap < 3 * (uint64_t)n_edges) cap <<= 1;
@@ -608,23 +606,14 @@ int trw_walk_triples_hip(const int64_t *triples, int64_t n_triples, const int64_
     } else if (pl.narrow) {
         triples_walker_kernel<<<walker_grid, kBlock, 0, stream>>>(
             (const u32x2_a8 *)(ws + pl.off_rt32), (const u32x2_a8 *)(ws + pl.off_ix32), targets, n_entities,
-            n_walkers, walker_base, walk_length, (uint32_t)padding_idx, (uint32_t)seed,
-            (uint32_t *)(ws + pl.off_stage), status);
+            n_walkers, walker_base, walk_length, (uint32_t)padding_idx, (uint32_t)seed, out, status);
     } else {
         triples_walker_wide_kernel<<<walker_grid, kBlock, 0, stream>>>(triples, n_triples, rt_index, targets,
                                                                       n_entities, n_walkers, walker_base, walk_length,
                                                                       padding_idx, (uint32_t)seed, out, status);
     }
     prof_mark(2, stream);
-    if (pl.narrow && mode == TRW_RNG_WALKER) {
-        const dim3 grid((unsigned)((n_walkers + 63) / 64), 1u);
-        // the start node is the only column that may be anything: a row whose start is neither an
-        // entity nor the padding id is filled with it (and was reported)
-        transpose_rows_kernel<<<grid, kBlock, 0, stream>>>((const uint32_t *)(ws + pl.off_stage), targets,
-                                                          padding_idx >= n_entities ? padding_idx + 1 : n_entities,
-                                                          n_walkers, 2 * walk_length, 1, n_walkers, out);
-    }
-    prof_mark(3, stream);
+    prof_mark(3, stream);  // triples_walker_kernel writes the rows itself: nothing to finish
     e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "kernel launch");
     return TRW_OK;
@@ -687,7 +676,6 @@ int trw_walk_edge_list_hip(const int64_t *edges, int64_t n_edges, const int64_t 
     EdgeListView<false> wide = {edges, node_edge_index, nullptr, nullptr, n_edges, n_nodes};
     EdgeListView<true> narrow = {nullptr, nullptr, (const uint32_t *)(ws + pl.off_tail32),
                                  (const u32x2_a8 *)(ws + pl.off_ix32), n_edges, n_nodes};
-    uint32_t *stage = (uint32_t *)(ws + pl.off_stage);
 
     prof_mark(0, stream);
     uint32_t *el_table = nullptr;
@@ -714,29 +702,23 @@ int trw_walk_edge_list_hip(const int64_t *edges, int64_t n_edges, const int64_t 
         if (uniform)
             elist_walk_kernel<false, true><<<walker_grid, kBlock, 0, stream>>>(
                 narrow, targets, n_walkers, walker_base, walk_length, padding_idx, restart, (uint32_t)seed, bp,
-                el_table, pl.hash_mask, stage, out, status);
+                el_table, pl.hash_mask, out, status);
         else
             elist_walk_kernel<true, true><<<walker_grid, kBlock, 0, stream>>>(
                 narrow, targets, n_walkers, walker_base, walk_length, padding_idx, restart, (uint32_t)seed, bp,
-                el_table, pl.hash_mask, stage, out, status);
+                el_table, pl.hash_mask, out, status);
     } else {
         if (uniform)
             elist_walk_kernel<false, false><<<walker_grid, kBlock, 0, stream>>>(
                 wide, targets, n_walkers, walker_base, walk_length, padding_idx, restart, (uint32_t)seed, bp, nullptr,
-                0u, stage, out, status);
+                0u, out, status);
         else
             elist_walk_kernel<true, false><<<walker_grid, kBlock, 0, stream>>>(
                 wide, targets, n_walkers, walker_base, walk_length, padding_idx, restart, (uint32_t)seed, bp, nullptr,
-                0u, stage, out, status);
+                0u, out, status);
     }
     prof_mark(2, stream);
-    if (pl.narrow && mode == TRW_RNG_WALKER) {
-        const dim3 grid((unsigned)((n_walkers + 63) / 64), 1u);
-        transpose_rows_kernel<<<grid, kBlock, 0, stream>>>(stage, targets,
-                                                          padding_idx >= n_nodes ? padding_idx + 1 : n_nodes,
-                                                          n_walkers, walk_length, 1, n_walkers, out);
-    }
-    prof_mark(3, stream);
+    prof_mark(3, stream);  // elist_walk_kernel writes the rows itself: nothing to finish
     e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "kernel launch");
     return TRW_OK;

@@ -11,7 +11,7 @@
 //
 //   elist_shadow_kernel     int64 edges/index -> uint32 tails + (first,last) pairs, validated
 //   elist_walk_kernel<B,N>  one walker per lane on the per-walker stream (B: biased, N: uint32 shadow
-//                           + staged output, else int64 in place)
+//                           + rows through WaveRows, else int64 in place)
 //   elist_glibc_seq_kernel  the reference's serial glibc stream replayed by one lane
 // Included by trw_hip.hip only.
 #pragma once
@@ -142,32 +142,46 @@ struct WalkerDraws {
     }
 };
 
+// The lanes of a wave step in lockstep (a rejection loop reconverges before the step's node is emitted);
+// kNarrow: their columns reach the caller's rows through the wave's LDS ring, one aligned 64-byte line per
+// row at a time (WaveRows, trw_kernels_narrow.hpp), so every lane of the wave stays to the end.
 template <bool kBiased, bool kNarrow>
 __global__ void __launch_bounds__(kBlock)
 elist_walk_kernel(EdgeListView<kNarrow> g, const int64_t *__restrict__ targets, int64_t n_walkers,
                   int64_t walker_base, int32_t L, int64_t pad, int32_t restart, uint32_t seed, BiasedParams bp,
-                  const uint32_t *__restrict__ table, uint32_t mask, uint32_t *__restrict__ stage,
-                  int64_t *__restrict__ out, int64_t *__restrict__ status)
+                  const uint32_t *__restrict__ table, uint32_t mask, int64_t *__restrict__ out,
+                  int64_t *__restrict__ status)
 {
+    __shared__ uint32_t tiles[kNarrow ? (kBlock / 64) * 64 * kTileStride : 1];
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i == 0) {
         status[2] = TRW_RNG_WALKER;
         status[3] = kNarrow ? 1 : 0;
     }
-    if (i >= n_walkers) return;
+    const bool exists = i < n_walkers;
+    if (!kNarrow && !exists) return;
+    WaveRows rows = {tiles + (kNarrow ? (threadIdx.x >> 6) * 64 * kTileStride : 0), (int)(threadIdx.x & 63)};
+    const int64_t wave_walker0 = (int64_t)blockIdx.x * kBlock + (__builtin_amdgcn_readfirstlane(threadIdx.x) & ~63u);
     uint32_t st = 0;
-    const int64_t target = targets[i];
+    const int64_t target = exists ? targets[i] : pad;
     const int64_t jump = restart ? target : pad;  // rw_cpu_edge_list.cpp:103-108
-    auto emit = [&](int32_t col, int64_t v) {
-        if (kNarrow) stage[(int64_t)col * n_walkers + i] = (uint32_t)v;
-        else out[i * (int64_t)(L + 1) + col] = v;
+    // a start node that is neither a node nor the padding id is reported and its row filled with it
+    const bool bad_start = exists && target != pad && (uint64_t)target >= (uint64_t)g.n_nodes;
+    const bool active = exists && !bad_start;
+    if (bad_start) {
+        st |= TRW_ST_NODE_RANGE;
+        if (kNarrow)
+            for (int32_t c = 0; c <= L; ++c) out[i * (int64_t)(L + 1) + c] = target;
+    }
+    auto emit = [&](int32_t col, int64_t v) {  // called by all lanes of the wave together
+        if (kNarrow) {
+            rows.put(col, active ? (uint32_t)v : kTileSkip);
+            if ((col & 7) == 7 || col == L) rows.flush(wave_walker0, 1, n_walkers, L + 1, col, out);
+        } else {
+            out[i * (int64_t)(L + 1) + col] = v;
+        }
     };
     emit(0, target);
-    bool bad_start = false;
-    if (target != pad && (uint64_t)target >= (uint64_t)g.n_nodes) {
-        st |= TRW_ST_NODE_RANGE;  // narrow: transpose_rows_kernel fills the row with the bad id
-        bad_start = true;
-    }
     WalkerDraws rng;
     rng.gw = (uint64_t)walker_base + (uint64_t)i;
     rng.seed = seed;
@@ -189,55 +203,59 @@ elist_walk_kernel(EdgeListView<kNarrow> g, const int64_t *__restrict__ targets, 
         return g.tail(e, pad, st);
     };
 
-    int64_t prev = target, p_first, p_last;
-    if (bad_start) {
-        for (int32_t s = 1; s <= L; ++s) emit(s, target);
-    } else if (!kBiased) {
+    int64_t prev = target, p_first = -1, p_last = -1;
+    if (!kBiased) {
         for (int32_t s = 1; s <= L; ++s) {
-            range_of(prev, p_first, p_last);
-            prev = sample(prev, p_first, p_last);
+            if (active) {
+                range_of(prev, p_first, p_last);
+                prev = sample(prev, p_first, p_last);
+            }
             emit(s, prev);
         }
     } else {
-        int64_t t = prev, t_first, t_last;
-        range_of(t, t_first, t_last);
-        prev = sample(t, t_first, t_last);  // step 1 (:188)
+        int64_t t = prev, t_first = -1, t_last = -1;
+        if (active) {
+            range_of(t, t_first, t_last);
+            prev = sample(t, t_first, t_last);  // step 1 (:188)
+        }
         emit(1, prev);
         for (int32_t s = 2; s <= L; ++s) {
-            range_of(prev, p_first, p_last);
-            int64_t selected;
-            uint32_t rejected = 0;
-            while (true) {
-                const int64_t x = sample(prev, p_first, p_last);   // 0 or 1 draw
-                const uint32_t ru = rng.next();                    // always 1 draw (:198)
-                bool accept = false;
-                selected = x;
-                if (x == t && ru < bp.t0) {                        // :204-209
-                    accept = true;
-                } else if (x == pad) {                             // :212-217
-                    accept = ru < bp.t0;
-                    selected = jump;
-                } else if (ru < bp.lo) {                           // below both thresholds: class is irrelevant
-                    accept = true;
-                } else if (ru < bp.hi) {                           // is_neighbor decides (:220-231)
-                    bool nb = false;
-                    if (t_first >= 0 && t_last > t_first) {
-                        if (table) {
-                            nb = elist_table_contains(table, mask, (uint32_t)t, (uint32_t)x);
-                        } else {
-                            for (int64_t e = t_first; e < t_last; ++e)  // [first, last): never the last edge
-                                if (g.tail(e, pad, st) == x) {
-                                    nb = true;
-                                    break;
-                                }
+            int64_t selected = prev;
+            if (active) {
+                range_of(prev, p_first, p_last);
+                uint32_t rejected = 0;
+                while (true) {
+                    const int64_t x = sample(prev, p_first, p_last);   // 0 or 1 draw
+                    const uint32_t ru = rng.next();                    // always 1 draw (:198)
+                    bool accept = false;
+                    selected = x;
+                    if (x == t && ru < bp.t0) {                        // :204-209
+                        accept = true;
+                    } else if (x == pad) {                             // :212-217
+                        accept = ru < bp.t0;
+                        selected = jump;
+                    } else if (ru < bp.lo) {                           // below both thresholds: class is irrelevant
+                        accept = true;
+                    } else if (ru < bp.hi) {                           // is_neighbor decides (:220-231)
+                        bool nb = false;
+                        if (t_first >= 0 && t_last > t_first) {
+                            if (table) {
+                                nb = elist_table_contains(table, mask, (uint32_t)t, (uint32_t)x);
+                            } else {
+                                for (int64_t e = t_first; e < t_last; ++e)  // [first, last): never the last edge
+                                    if (g.tail(e, pad, st) == x) {
+                                        nb = true;
+                                        break;
+                                    }
+                            }
                         }
+                        accept = ru < (nb ? bp.t1 : bp.t2);
                     }
-                    accept = ru < (nb ? bp.t1 : bp.t2);
-                }
-                if (accept) break;
-                if (++rejected >= kTrialCap) {
-                    st |= (uint32_t)kStTrialCap;
-                    break;
+                    if (accept) break;
+                    if (++rejected >= kTrialCap) {
+                        st |= (uint32_t)kStTrialCap;
+                        break;
+                    }
                 }
             }
             emit(s, selected);

@@ -11,7 +11,7 @@
 //                           (8 bytes per triple instead of 24), validated
 //   triples_walker_kernel   one walker per lane on the per-walker stream; per hop
 //                           one 8-byte gather of the index pair and one 8-byte
-//                           gather of (relation, tail); staged, coalesced output
+//                           gather of (relation, tail); rows written through WaveRows
 //   triples_glibc_seq_kernel the reference's serial glibc stream replayed by one lane
 // Included by trw_hip.hip only.
 #pragma once
@@ -58,34 +58,47 @@ triples_shadow_kernel(const int64_t *__restrict__ triples, int64_t n_triples, co
     if (st) atomicOr((unsigned long long *)&status[0], (unsigned long long)st);
 }
 
-// Column c of walker i goes to stage[c*n_walkers + i]; transpose_rows_kernel finishes.
+// The lanes of a wave hop in lockstep; their columns reach the caller's [N, 2L+1] rows through the wave's
+// LDS ring, one aligned 64-byte line per row at a time (WaveRows, trw_kernels_narrow.hpp).
 __global__ void __launch_bounds__(kBlock)
 triples_walker_kernel(const u32x2_a8 *__restrict__ rt32, const u32x2_a8 *__restrict__ ix32,
                       const int64_t *__restrict__ targets, int64_t n_entities, int64_t n_walkers,
-                      int64_t walker_base, int32_t L, uint32_t pad, uint32_t seed, uint32_t *__restrict__ stage,
+                      int64_t walker_base, int32_t L, uint32_t pad, uint32_t seed, int64_t *__restrict__ out,
                       int64_t *__restrict__ status)
 {
+    __shared__ uint32_t tiles[(kBlock / 64) * 64 * kTileStride];
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i == 0) {
         status[2] = TRW_RNG_WALKER;
         status[3] = 1;
     }
-    if (i >= n_walkers) return;
-    const int64_t tg = targets[i];
-    uint32_t *sp = stage + i;
-    *sp = (uint32_t)tg;
-    sp += n_walkers;
-    uint32_t node = (uint32_t)tg;
-    if (tg != (int64_t)pad && (uint64_t)tg >= (uint64_t)n_entities) {
-        atomicOr((unsigned long long *)&status[0], (unsigned long long)TRW_ST_NODE_RANGE);
-        node = pad;  // transpose_rows_kernel fills the row with the bad id
+    WaveRows rows = {tiles + (threadIdx.x >> 6) * 64 * kTileStride, (int)(threadIdx.x & 63)};
+    const int64_t wave_walker0 = (int64_t)blockIdx.x * kBlock + (__builtin_amdgcn_readfirstlane(threadIdx.x) & ~63u);
+    const int32_t cols = 2 * L + 1;
+    bool live = i < n_walkers;  // the whole wave stays: every lane helps writing the wave's rows
+    uint32_t node = pad;
+    if (live) {
+        const int64_t tg = targets[i];
+        node = (uint32_t)tg;
+        if (tg != (int64_t)pad && (uint64_t)tg >= (uint64_t)n_entities) {
+            atomicOr((unsigned long long *)&status[0], (unsigned long long)TRW_ST_NODE_RANGE);
+            node = pad;
+            // the start node is the only column that may be anything: a row whose start fits no id at
+            // all is filled with it
+            if ((uint64_t)tg >= (uint64_t)(pad >= (uint64_t)n_entities ? (int64_t)pad + 1 : n_entities)) {
+                live = false;
+                for (int32_t c = 0; c < cols; ++c) out[i * (int64_t)cols + c] = tg;
+            }
+        }
+        if (live) rows.put(0, (uint32_t)tg);
     }
+    if (!live) rows.put(0, kTileSkip);
     const uint64_t gw = (uint64_t)walker_base + (uint64_t)i;
     uint32_t blk[4] = {0, 0, 0, 0};
     uint32_t d = 0;  // draws this walker has consumed
     for (int32_t h = 0; h < L; ++h) {
         uint32_t rel = pad, tail = pad;
-        if (node != pad) {
+        if (live && node != pad) {
             const u32x2_a8 ix = ix32[node];
             if (ix.x != kNoEdge) {
                 uint32_t e = ix.x;
@@ -101,10 +114,11 @@ triples_walker_kernel(const u32x2_a8 *__restrict__ rt32, const u32x2_a8 *__restr
                 tail = rt.y;
             }
         }
-        *sp = rel;
-        sp += n_walkers;
-        *sp = tail;
-        sp += n_walkers;
+        const int32_t c = 2 * h + 1;
+        rows.put(c, live ? rel : kTileSkip);
+        if ((c & 7) == 7) rows.flush(wave_walker0, 1, n_walkers, cols, c, out);
+        rows.put(c + 1, live ? tail : kTileSkip);
+        if (((c + 1) & 7) == 7 || c + 1 == cols - 1) rows.flush(wave_walker0, 1, n_walkers, cols, c + 1, out);
         node = tail;
     }
 }
