@@ -310,10 +310,8 @@ def main():
         stw = (ctypes.c_int64 * 4)()
         assert lib.trw_walk_status(ws.data_ptr(), stream, stw) == 0 and stw[0] == 0
         assert torch.equal(out, walks), "direct C-ABI call produced different walks"
-        direct = os.environ.get("TRW_UNIFORM_DIRECT", "1") != "0"
-        kernel_name = {0: "uniform_glibc_wide_kernel",
-                       1: "uniform_glibc_rows_kernel<false>" if direct else "uniform_glibc_kernel",
-                       3: "uniform_glibc_rows_kernel<true>" if direct else "uniform_glibc_ext_kernel"}[int(stw[3])]
+        kernel_name = {0: "uniform_glibc_wide_kernel", 1: "uniform_glibc_rows_kernel<false>",
+                       3: "uniform_glibc_rows_kernel<true>"}[int(stw[3])]
         del out, ws
     else:
         lib.trw_profile_enable(2)

@@ -79,8 +79,7 @@ const char *trw_last_error(void);
 /* Bytes of device scratch trw_walk_csr_hip needs for this call shape
  * (>= 256): status block, per-lane RNG windows (uniform walks), the uint32
  * shadow of the CSR (4*(n_nodes+1+nnz) bytes), and by call shape the fat
- * entries (16*nnz), the edge table (16 * 2^k >= 48*nnz) or, for small biased
- * batches, uint32 staging planes (4*n_walkers*(walk_length+1) bytes). */
+ * entries (16*nnz) and the edge table (16 * 2^k >= 48*nnz). */
 size_t trw_walk_csr_workspace_bytes(int64_t n_nodes, int64_t nnz, int64_t n_walkers,
                                     int32_t walk_length, double p, double q, int32_t rng_mode);
 
@@ -250,8 +249,8 @@ void trw_glibc_window_at(int32_t seed, uint64_t pos, uint32_t window[31]);
  * last call's events and returns, in milliseconds, the device time of
  *   prepare  (uint32 shadow CSR + validation; glibc jump-ahead windows),
  *   walk     (the walk kernel itself -- the dominant kernel),
- *   finish   (staging planes -> [N, L+1] int64 rows; only the small-batch
- *            biased kernel still has one, every other kernel writes its rows).
+ *   finish   (always ~0: every walk kernel writes the caller's rows itself;
+ *            kept so that the three-phase report stays stable).
  * bit 1 -- the biased walker kernel also counts its work into the workspace
  * (a separately compiled variant, not the one that is timed);
  * trw_walk_counters() synchronises and returns

@@ -310,8 +310,6 @@ def test_c_abi_direct_call(rw):
 VARIANTS = [{"TRW_FORCE_WIDE": "1"},                      # int64 kernels
             {"TRW_EXT": "0"},                            # uniform: compact shadow, two gathers per step
             {"TRW_EXT": "1"},                            # uniform: fat entries, one gather per step
-            {"TRW_UNIFORM_DIRECT": "0"},                 # uniform: staging planes + transpose pass
-            {"TRW_UNIFORM_DIRECT": "0", "TRW_EXT": "1"},
             {"TRW_HASH": "0"},                           # bisection kernel, located-t shortcut
             {"TRW_HASH": "0", "TRW_NO_POS": "1"},        # bisection kernel, every candidate loaded
             {"TRW_HASH": "1"},                           # edge table + state machine

@@ -6,17 +6,15 @@
 // window builders).  This is integer gather work bounded by the memory system's random-access
 // rate; there is no contraction in it and therefore no MFMA.
 //
-// A CSR walk is three phases on the caller's stream:
+// A CSR walk is two phases on the caller's stream:
 //   prepare  csr_shadow_kernel (int64 CSR -> validated uint32 shadow); glibc_windows_kernel (per-lane
-//            jump-ahead into rand()'s stream, uniform walks); csr_ext_kernel (fat entries, large graphs);
-//            edge_table_build_kernel (biased walks, large batches)
-//   walk     uniform_glibc_kernel | uniform_glibc_ext_kernel | biased_hash_kernel | biased_walker_kernel
-//   finish   transpose_rows_kernel (uint32 staging planes -> [N, L+1] int64 rows; biased_hash_kernel
-//            writes its rows directly)
+//            jump-ahead into rand()'s stream, uniform walks); csr_ext_kernel / csr_ext_rpos_kernel (fat
+//            entries, large graphs); edge_table_build_kernel (biased walks, large batches)
+//   walk     uniform_glibc_rows_kernel | biased_hash_kernel | biased_walker_kernel -- each writes the
+//            caller's [N, L+1] int64 rows itself (there is no finish pass)
 // Graphs beyond 2^31 nodes / 2^32 entries, the uniform walk on the per-walker stream and the serial
-// reference-exact replay of a biased walk run the int64 kernels of trw_kernels_wide.hpp, which write
-// the result directly.  make_plan() decides which of these a call shape gets and where their
-// buffers live in the caller's workspace.
+// reference-exact replay of a biased walk run the int64 kernels of trw_kernels_wide.hpp.  make_plan()
+// decides which of these a call shape gets and where their buffers live in the caller's workspace.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -108,15 +106,14 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Where everything lives in the caller's workspace for one call shape.
 struct Plan {
-    bool narrow = false;   // uint32 shadow + staging (n_nodes < 2^31, nnz < 2^32)
+    bool narrow = false;   // uint32 shadow kernels (n_nodes < 2^31, nnz < 2^32)
     bool windows = false;  // glibc jump-ahead windows needed
     int32_t G = 1;         // walkers chained per lane (uniform glibc)
     int64_t nlanes = 0;
     bool hash = false;     // biased: edge hash table + state-machine kernel
     bool ext = false;      // uniform: fat entries {v, start(v), deg(v)}, one gather per step
-    bool direct = false;   // uniform: the walk kernel writes the int64 rows itself (no staging, no transpose)
     uint32_t hash_mask = 0;
-    size_t off_win = 0, off_row32 = 0, off_col32 = 0, off_stage = 0, off_table = 0, off_ext = 0, total = 0;
+    size_t off_win = 0, off_row32 = 0, off_col32 = 0, off_table = 0, off_ext = 0, total = 0;
 };
 
 Plan make_plan(int64_t n_nodes, int64_t nnz, int64_t n_walkers, int32_t L, bool uniform, int32_t rng_mode)
@@ -139,7 +136,9 @@ Plan make_plan(int64_t n_nodes, int64_t nnz, int64_t n_walkers, int32_t L, bool 
         off += align_up((size_t)pl.nlanes * kGlDeg * sizeof(uint32_t), 256);
     }
     // the narrow kernels serve: uniform on the glibc stream, biased on the walker stream
-    pl.narrow = fits && ((uniform && may_glibc) || (!uniform && may_walker));
+    // (uniform_glibc_rows_kernel addresses a wave's 64 rows with a 32-bit byte offset)
+    const bool rows_fit = (int64_t)64 * pl.G * ((int64_t)L + 1) < ((int64_t)1 << 29);
+    pl.narrow = fits && ((uniform && may_glibc && rows_fit) || (!uniform && may_walker));
     if (pl.narrow) {
         pl.off_row32 = off;
         off += align_up((size_t)(n_nodes + 1 + 4) * sizeof(uint32_t), 256);  // +4: 16-byte gathers at the last node
@@ -182,13 +181,6 @@ Plan make_plan(int64_t n_nodes, int64_t nnz, int64_t n_walkers, int32_t L, bool 
                     off += align_up((size_t)nnz * 16 + 64, 256);
                 }
             }
-        }
-        // (uniform_glibc_rows_kernel addresses a wave's 64 rows with a 32-bit byte offset)
-        pl.direct = uniform && (int64_t)64 * pl.G * ((int64_t)L + 1) < ((int64_t)1 << 29) &&
-                    env_long("TRW_UNIFORM_DIRECT", 0, 1, 1) == 1;
-        if ((uniform && !pl.direct) || (!uniform && !pl.hash)) {  // the other kernels write the caller's rows themselves
-            pl.off_stage = off;
-            off += align_up((size_t)pl.nlanes * pl.G * (size_t)(L + 1) * sizeof(uint32_t), 256);
         }
     }
     pl.total = off;
@@ -401,7 +393,6 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col
     uint32_t *win = (uint32_t *)(ws + pl.off_win);
     uint32_t *row32 = (uint32_t *)(ws + pl.off_row32);
     uint32_t *col32 = (uint32_t *)(ws + pl.off_col32);
-    uint32_t *stage = (uint32_t *)(ws + pl.off_stage);
     uint32_t *table = (uint32_t *)(ws + pl.off_table);
     const int64_t L = walk_length;
     const unsigned walker_grid = (unsigned)((n_walkers + kBlock - 1) / kBlock);
@@ -468,26 +459,14 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col
     prof_mark(1, stream);
     if (uniform) {
         if (mode == TRW_RNG_GLIBC) {
-            if (pl.narrow && pl.direct && pl.ext)
+            if (pl.narrow && pl.ext)
                 uniform_glibc_rows_kernel<true><<<lane_grid, kBlock, 0, stream>>>(
                     row32, col32, (const u32x4_a16 *)(ws + pl.off_ext), targets, n_nodes, n_walkers, walk_length,
                     pl.G, pl.nlanes, win, out, status);
-            else if (pl.narrow && pl.direct)
+            else if (pl.narrow)
                 uniform_glibc_rows_kernel<false><<<lane_grid, kBlock, 0, stream>>>(
                     row32, col32, nullptr, targets, n_nodes, n_walkers, walk_length, pl.G, pl.nlanes, win, out,
                     status);
-            else if (pl.narrow && pl.ext)
-                uniform_glibc_ext_kernel<8><<<lane_grid, kBlock, 0, stream>>>(
-                    row32, (const u32x4_a16 *)(ws + pl.off_ext), targets, n_nodes, n_walkers, walk_length, pl.G,
-                    pl.nlanes, win, stage, status);
-            else if (pl.narrow && env_long("TRW_UNIFORM_WAVES", 1, 8, 8) < 8)
-                uniform_glibc_kernel<1><<<lane_grid, kBlock, 0, stream>>>(row32, col32, targets, n_nodes, n_walkers,
-                                                                         walk_length, pl.G, pl.nlanes, win, stage,
-                                                                         status);
-            else if (pl.narrow)
-                uniform_glibc_kernel<8><<<lane_grid, kBlock, 0, stream>>>(row32, col32, targets, n_nodes, n_walkers,
-                                                                         walk_length, pl.G, pl.nlanes, win, stage,
-                                                                         status);
             else
                 uniform_glibc_wide_kernel<<<lane_grid, kBlock, 0, stream>>>(row_ptr, col_idx, targets, n_nodes, nnz,
                                                                            n_walkers, walk_length, pl.G, pl.nlanes,
@@ -518,7 +497,7 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col
     } else if (pl.narrow) {
 #define TRW_LAUNCH_BIASED(POS, COUNT)                                                                          \
     biased_walker_kernel<POS, COUNT><<<walker_grid, kBlock, 0, stream>>>(                                      \
-        row32, col32, targets, n_nodes, n_walkers, walker_base, walk_length, (uint32_t)seed, bp, stage, status)
+        row32, col32, targets, n_nodes, n_walkers, walker_base, walk_length, (uint32_t)seed, bp, out, status)
         if (use_pos) {
             if (g_prof.count) TRW_LAUNCH_BIASED(true, true);
             else TRW_LAUNCH_BIASED(true, false);
@@ -540,12 +519,7 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col
 
     // ---- finish ----------------------------------------------------------------------------
     prof_mark(2, stream);
-    const bool staged = pl.narrow && (uniform ? mode == TRW_RNG_GLIBC : mode == TRW_RNG_WALKER);
-    if (staged && !(!uniform && pl.hash) && !(uniform && pl.direct)) {  // those kernels write the int64 rows themselves
-        const dim3 grid((unsigned)((pl.nlanes + 63) / 64), (unsigned)pl.G);
-        transpose_rows_kernel<<<grid, kBlock, 0, stream>>>(stage, targets, n_nodes, n_walkers, walk_length, pl.G,
-                                                          pl.nlanes, out);
-    }
+    // every walk kernel writes the caller's rows itself: nothing to finish
     prof_mark(3, stream);
     e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "kernel launch");

@@ -1,20 +1,20 @@
-// trw_kernels_narrow.hpp -- the production kernels: 32-bit shadow CSR, staged output.
+// trw_kernels_narrow.hpp -- the production kernels: 32-bit shadow CSR, rows written line by line.
 //
 // What the profile of the int64 kernels showed (profiles/r01_*): both walks are
-// bound by the number of cache lines that miss L2 (5.5e10 64-byte fetches/s, i.e.
-// the memory system's random-access ceiling), and every 8-byte scattered store
-// cost 32 bytes of HBM write.  So these kernels are built to touch fewer lines:
+// bound by the number of cache lines that miss L2 (~5e10 64-byte requests/s, the
+// memory system's random-access ceiling, profiles/r01_machine_probe.txt), and every
+// 8-byte scattered store cost 32 bytes of HBM write.  So these kernels are built to
+// touch fewer lines:
 //
-//   csr_shadow_kernel     one streaming pass: int64 CSR -> uint32 shadow (half the
-//                         footprint, twice the entries per line), validates it and
-//                         counts order descents so the walk knows whether rows are sorted
-//   uniform_glibc_kernel  reference-exact uniform walk; lanes write their steps
-//                         lane-contiguously into a uint32 staging plane (one 256-byte
-//                         store per wave and step instead of 64 scattered ones)
-//   biased_walker_kernel  node2vec rejection sampling on the per-walker stream; most
-//                         trials are decided without touching memory (see below)
-//   transpose_rows_kernel staging planes -> the caller's [N, L+1] int64 rows through an
-//                         LDS tile, whole 512-byte row segments per wave store
+//   csr_shadow_kernel         one streaming pass: int64 CSR -> uint32 shadow (half the
+//                             footprint, twice the entries per line), validates it and
+//                             counts order descents so the walk knows whether rows are sorted
+//   csr_ext_kernel            fat entries {v, start(v), deg(v)}: one gather per step
+//   uniform_glibc_rows_kernel reference-exact uniform walk; the wave writes its 64 rows one
+//                             aligned 64-byte line at a time through an LDS ring (WaveRows)
+//   biased_hash_kernel        node2vec rejection sampling on the per-walker stream, large
+//                             batches: edge table + per-lane state machine
+//   biased_walker_kernel      the same walk for small batches (bisection instead of the table)
 //
 // Included by trw_hip.hip only.  Valid for n_nodes < 2^31 and nnz < 2^32.
 #pragma once
@@ -84,92 +84,6 @@ __device__ __forceinline__ void load_row32(const uint32_t *__restrict__ row32, u
 }
 
 // ---------------------------------------------------------------------------
-// Uniform walk, reference-exact draws (uniform_walk, rw_cpu.cpp:58-107)
-// ---------------------------------------------------------------------------
-// Lane l owns walkers [l*G, l*G+G): G*L consecutive words of the glibc stream,
-// produced in registers (one add per draw on a statically indexed 31-word
-// window, loop unrolled by the generator order).  Column k = g*(L+1)+s of the
-// lane goes to stage[k*nlanes + l]: the 64 lanes of a wave store 256 contiguous
-// bytes.  A step is two dependent gathers: row32[v],row32[v+1] then col32[...].
-template <int kMinWaves>  // register budget: 8 waves/SIMD caps the kernel at 64 VGPRs
-__global__ void __launch_bounds__(kBlock, kMinWaves)
-uniform_glibc_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32,
-                     const int64_t *__restrict__ targets, int64_t n_nodes, int64_t n_walkers, int32_t L, int32_t G,
-                     int64_t nlanes, const uint32_t *__restrict__ win, uint32_t *__restrict__ stage,
-                     int64_t *__restrict__ status)
-{
-    const int64_t lane = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (lane == 0) {
-        status[2] = TRW_RNG_GLIBC;
-        status[3] = 1;
-    }
-    if (lane >= nlanes) return;
-
-    uint32_t w[kGlDeg];
-#pragma unroll
-    for (int j = 0; j < kGlDeg; ++j) w[j] = win[(int64_t)j * nlanes + lane];
-
-    uint32_t st = 0;
-    int64_t walker = lane * G;
-    int32_t s = 0;  // next column of the current walker; 0 = start a new walker
-    uint32_t cur = 0;
-    uint32_t *sp = stage + lane;  // advances by nlanes per column written
-    bool live = false, mine = false;
-    const int32_t total = G * L;
-
-    auto step = [&](uint32_t r) {
-        if (s == 0) {  // wave-uniform: every lane starts its next walker together
-            mine = walker < n_walkers;
-            live = mine;
-            if (mine) {
-                const int64_t tg = targets[walker];
-                if ((uint64_t)tg >= (uint64_t)n_nodes) {  // reported; transpose_rows_kernel fills the row
-                    st |= TRW_ST_NODE_RANGE;
-                    live = false;
-                }
-                cur = (uint32_t)tg;
-                *sp = cur;
-            }
-            sp += nlanes;
-            s = 1;
-        }
-        if (live) {
-            uint32_t start, deg;
-            load_row32(row32, cur, start, deg);
-            if (deg == 0) {
-                st |= TRW_ST_DEGREE0;  // rw_cpu.cpp:20 divides by zero here
-            } else {
-                cur = col32[start + r % deg];
-            }
-        }
-        if (mine) *sp = cur;
-        sp += nlanes;
-        if (++s > L) {
-            s = 0;
-            ++walker;
-        }
-    };
-    int32_t d0 = 0;
-    for (; d0 + kGlDeg <= total; d0 += kGlDeg) {
-#pragma unroll
-        for (int j = 0; j < kGlDeg; ++j) {
-            const uint32_t v = w[j] + w[(j + kGlDeg - kGlSep) % kGlDeg];
-            w[j] = v;
-            step(v >> 1);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < kGlDeg - 1; ++j) {
-        if (d0 + j < total) {  // wave-uniform tail
-            const uint32_t v = w[j] + w[(j + kGlDeg - kGlSep) % kGlDeg];
-            w[j] = v;
-            step(v >> 1);
-        }
-    }
-    if (st) atomicOr((unsigned long long *)&status[0], (unsigned long long)st);
-}
-
-// ---------------------------------------------------------------------------
 // Uniform walk over "fat" entries: one gather per step
 // ---------------------------------------------------------------------------
 // ext[e] = {v, row32[v], deg(v), 0} for v = col32[e]: the entry a walker picks already carries the row of
@@ -190,86 +104,6 @@ csr_ext_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ 
     }
 }
 
-template <int kMinWaves>
-__global__ void __launch_bounds__(kBlock, kMinWaves)
-uniform_glibc_ext_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restrict__ ext,
-                         const int64_t *__restrict__ targets, int64_t n_nodes, int64_t n_walkers, int32_t L,
-                         int32_t G, int64_t nlanes, const uint32_t *__restrict__ win,
-                         uint32_t *__restrict__ stage, int64_t *__restrict__ status)
-{
-    const int64_t lane = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (lane == 0) {
-        status[2] = TRW_RNG_GLIBC;
-        status[3] = 3;
-    }
-    if (lane >= nlanes) return;
-
-    uint32_t w[kGlDeg];
-#pragma unroll
-    for (int j = 0; j < kGlDeg; ++j) w[j] = win[(int64_t)j * nlanes + lane];
-
-    uint32_t st = 0;
-    int64_t walker = lane * G;
-    int32_t s = 0;  // next column of the current walker; 0 = start a new walker
-    uint32_t cur = 0, start = 0, deg = 0;
-    uint32_t *sp = stage + lane;  // advances by nlanes per column written
-    bool live = false, mine = false;
-    const int32_t total = G * L;
-
-    auto step = [&](uint32_t r) {
-        if (s == 0) {  // wave-uniform: every lane starts its next walker together
-            mine = walker < n_walkers;
-            live = mine;
-            if (mine) {
-                const int64_t tg = targets[walker];
-                if ((uint64_t)tg >= (uint64_t)n_nodes) {  // reported; transpose_rows_kernel fills the row
-                    st |= TRW_ST_NODE_RANGE;
-                    live = false;
-                }
-                cur = (uint32_t)tg;
-                *sp = cur;
-                if (live) load_row32(row32, cur, start, deg);  // the only row32 gather of the walk
-            }
-            sp += nlanes;
-            s = 1;
-        }
-        if (live) {
-            if (deg == 0) {
-                st |= TRW_ST_DEGREE0;  // rw_cpu.cpp:20 divides by zero here
-            } else {
-                const u32x4_a16 x = ext[start + r % deg];
-                cur = x.x;
-                start = x.y;
-                deg = x.z;
-            }
-        }
-        if (mine) *sp = cur;
-        sp += nlanes;
-        if (++s > L) {
-            s = 0;
-            ++walker;
-        }
-    };
-    int32_t d0 = 0;
-    for (; d0 + kGlDeg <= total; d0 += kGlDeg) {
-#pragma unroll
-        for (int j = 0; j < kGlDeg; ++j) {
-            const uint32_t v = w[j] + w[(j + kGlDeg - kGlSep) % kGlDeg];
-            w[j] = v;
-            step(v >> 1);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < kGlDeg - 1; ++j) {
-        if (d0 + j < total) {  // wave-uniform tail
-            const uint32_t v = w[j] + w[(j + kGlDeg - kGlSep) % kGlDeg];
-            w[j] = v;
-            step(v >> 1);
-        }
-    }
-    if (st) atomicOr((unsigned long long *)&status[0], (unsigned long long)st);
-}
-
 // ---------------------------------------------------------------------------
 // Lane-per-walker columns -> line-aligned int64 row stores, inside the walk kernel
 // ---------------------------------------------------------------------------
@@ -278,7 +112,7 @@ uniform_glibc_ext_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__
 // rows, the one 64-byte line of the caller's [N, L+1] int64 tensor that has just become complete (8 lanes
 // per row, 8 rows per pass) -- rows start at any multiple of 8 bytes, so which columns make up a line
 // differs from row to row (`phase`).  Only full, aligned lines reach HBM (a row's first and last line
-// excepted).  This replaces the uint32 staging planes and the transpose pass.
+// excepted); 8 bytes of HBM traffic per column, no staging buffer and no transpose pass.
 constexpr int kTileCols = 16;
 constexpr int kTileStride = kTileCols + 1;  // odd stride: conflict-free lane-per-row writes
 constexpr uint32_t kTileSkip = 0xFFFFFFFFu;  // not a node id (ids < 2^31): nothing to write for this row
@@ -330,10 +164,48 @@ struct WaveRows {
     }
 };
 
-// The uniform walk with its rows written by the walk kernel itself (WaveRows).  Same walkers per lane, same
-// draws as uniform_glibc_kernel / uniform_glibc_ext_kernel; the generator window is still indexed
-// statically, but four draws at a time through a 31-way wave-uniform switch, so that the step (with its
-// row-flush code) exists four times in the kernel instead of once per window position.
+// For kernels whose lanes advance at their own pace (the biased walks): the last (up to) four columns of
+// the lane's row wait in registers until they fill a 32-byte-aligned group of the caller's row, the
+// granule a partial HBM write costs anyway (one write request per four columns instead of one per column).
+typedef int64_t i64x2_a16 __attribute__((ext_vector_type(2)));
+
+struct RowCombiner {
+    int64_t *sp;  // where the next column goes
+    uint32_t wb0, wb1, wb2, wb3;
+    __device__ __forceinline__ void emit(uint32_t v, int32_t col, int32_t last_col)
+    {
+        const uint32_t k = (uint32_t)((uintptr_t)sp >> 3) & 3u;
+        wb0 = k == 0u ? v : wb0;
+        wb1 = k == 1u ? v : wb1;
+        wb2 = k == 2u ? v : wb2;
+        wb3 = k == 3u ? v : wb3;
+        ++sp;
+        if (k == 3u || col == last_col) {
+            const uint32_t have = min(k + 1u, (uint32_t)col + 1u);  // columns of THIS row in the group
+            int64_t *grp = sp - (k + 1u);
+            if (have == 4u) {
+                const i64x2_a16 lo2 = {(int64_t)wb0, (int64_t)wb1}, hi2 = {(int64_t)wb2, (int64_t)wb3};
+                *reinterpret_cast<i64x2_a16 *>(grp) = lo2;
+                *reinterpret_cast<i64x2_a16 *>(grp + 2) = hi2;
+            } else {
+                const uint32_t first = k + 1u - have;
+                if (first == 0u) grp[0] = (int64_t)wb0;
+                if (first <= 1u && k >= 1u) grp[1] = (int64_t)wb1;
+                if (first <= 2u && k >= 2u) grp[2] = (int64_t)wb2;
+                if (k >= 3u) grp[3] = (int64_t)wb3;
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------
+// Uniform walk, reference-exact draws (uniform_walk, rw_cpu.cpp:58-107)
+// ---------------------------------------------------------------------------
+// Lane l owns walkers [l*G, l*G+G): G*L consecutive words of the glibc stream, produced in registers: one
+// add per draw on a 31-word window that is indexed statically, four draws at a time through a 31-way
+// wave-uniform switch (so the step, with its row-flush code, exists four times in the kernel instead of
+// once per window position).  kFat = false: a step is two dependent gathers, row32[v],row32[v+1] then
+// col32[...]; kFat = true: one 16-byte gather of a fat entry.  Rows are written through WaveRows.
 #define TRW_GEN4(J)                                                                     \
     case J: {                                                                           \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                              \
@@ -434,54 +306,6 @@ uniform_glibc_rows_kernel(const uint32_t *__restrict__ row32, const uint32_t *__
 #undef TRW_GEN4
 
 // ---------------------------------------------------------------------------
-// Staging planes -> [N, L+1] int64 rows
-// ---------------------------------------------------------------------------
-// Walker i = lane*G + g keeps column c at stage[(g*(L+1)+c)*nlanes + lane].  A
-// block moves 64 lanes x one g: planes are read 256 bytes per wave, rows are
-// written 512 bytes per wave, through a padded LDS tile (conflict-free both ways).
-__global__ void __launch_bounds__(kBlock)
-transpose_rows_kernel(const uint32_t *__restrict__ stage, const int64_t *__restrict__ targets, int64_t n_nodes,
-                      int64_t n_walkers, int32_t L, int32_t G, int64_t nlanes, int64_t *__restrict__ out)
-{
-    // tile[r][c]: lane r of the block, column c of the chunk; 66-word rows keep the 8-byte reads of the
-    // store phase aligned and conflict-free (the 2-way conflict of the 4-byte writes is free on CDNA4)
-    __shared__ uint32_t tile[64][66];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int64_t lane0 = (int64_t)blockIdx.x * 64;
-    const int32_t g = blockIdx.y;
-    const int32_t cols = L + 1;
-    const bool lane_ok = lane0 + lane < nlanes;
-    for (int32_t c0 = 0; c0 < cols; c0 += 64) {
-        const int32_t nc = cols - c0 < 64 ? cols - c0 : 64;
-        // plane reads: 16 independent 256-byte loads per wave in flight, then into the tile
-        uint32_t v[16];
-        const uint32_t *src = stage + ((int64_t)g * cols + c0 + wave) * nlanes + lane0 + lane;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = (lane_ok && wave + 4 * k < nc) ? src[(int64_t)(4 * k) * nlanes] : 0u;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) tile[lane][wave + 4 * k] = v[k];
-        __syncthreads();
-        // row writes: a half-wave per walker row, two columns (16 bytes) per lane
-        const int half = lane >> 5, j = lane & 31;
-#pragma unroll 4
-        for (int it = 0; it < 8; ++it) {
-            const int r = wave * 16 + 2 * it + half;
-            const int64_t i = (lane0 + r) * G + g;
-            if (lane0 + r < nlanes && i < n_walkers && 2 * j < nc) {
-                const int64_t tg = targets[i];
-                const bool dead = (uint64_t)tg >= (uint64_t)n_nodes;  // reported by the walk kernel
-                const uint2 ab = *reinterpret_cast<const uint2 *>(&tile[r][2 * j]);
-                int64_t *dst = out + i * cols + c0 + 2 * j;
-                dst[0] = dead ? tg : (int64_t)ab.x;
-                if (2 * j + 1 < nc) dst[1] = dead ? tg : (int64_t)ab.y;
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// ---------------------------------------------------------------------------
 // Biased (node2vec) walk on the per-walker stream (biased_walk, rw_cpu.cpp:109-201)
 // ---------------------------------------------------------------------------
 
@@ -564,7 +388,7 @@ template <bool kSorted, bool kPos, bool kCount>
 __device__ __forceinline__ void biased_walk_lane(const uint32_t *__restrict__ row32,
                                                  const uint32_t *__restrict__ col32, uint32_t target, int64_t i,
                                                  int64_t n_walkers, uint64_t gw, int32_t L, uint32_t seed,
-                                                 const BiasedParams &bp, uint32_t *__restrict__ stage, uint32_t &st,
+                                                 const BiasedParams &bp, RowCombiner &row, uint32_t &st,
                                                  uint32_t &n_trials, uint32_t &n_fetch, uint32_t &n_tests,
                                                  uint32_t &n_probes)
 {
@@ -578,9 +402,7 @@ __device__ __forceinline__ void biased_walk_lane(const uint32_t *__restrict__ ro
     uint32_t prev = t;
     if (t_deg == 0) st |= TRW_ST_DEGREE0;
     else prev = col32[t_start + (blk[0] >> 1) % t_deg];
-    uint32_t *sp = stage + n_walkers + i;  // column 1
-    *sp = prev;
-    sp += n_walkers;
+    row.emit(prev, 1, L);
 
     uint32_t p_start, p_deg;
     load_row32(row32, prev, p_start, p_deg);
@@ -642,8 +464,7 @@ __device__ __forceinline__ void biased_walk_lane(const uint32_t *__restrict__ ro
             accept = true;
         }
         if (accept) {
-            *sp = x;
-            sp += n_walkers;
+            row.emit(x, s, L);
             t = prev;
             t_start = p_start;
             t_deg = p_deg;
@@ -662,7 +483,7 @@ template <bool kPos, bool kCount>
 __global__ void __launch_bounds__(kBlock)
 biased_walker_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32,
                      const int64_t *__restrict__ targets, int64_t n_nodes, int64_t n_walkers, int64_t walker_base,
-                     int32_t L, uint32_t seed, BiasedParams bp, uint32_t *__restrict__ stage,
+                     int32_t L, uint32_t seed, BiasedParams bp, int64_t *__restrict__ out,
                      int64_t *__restrict__ status)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -675,17 +496,19 @@ biased_walker_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restr
     uint32_t n_trials = 0, n_fetch = 0, n_tests = 0, n_probes = 0;
     if (i < n_walkers) {
         const int64_t tg = targets[i];
-        stage[i] = (uint32_t)tg;  // column 0
+        RowCombiner row = {out + i * (int64_t)(L + 1), 0u, 0u, 0u, 0u};
         if ((uint64_t)tg >= (uint64_t)n_nodes) {
-            st |= TRW_ST_NODE_RANGE;  // transpose_rows_kernel fills the row with the bad id
+            st |= TRW_ST_NODE_RANGE;  // reported; the row is filled with the bad id
+            for (int32_t c = 0; c <= L; ++c) row.sp[c] = tg;
         } else {
+            row.emit((uint32_t)tg, 0, L);  // column 0
             const uint64_t gw = (uint64_t)walker_base + (uint64_t)i;
             if (sorted)
-                biased_walk_lane<true, kPos, kCount>(row32, col32, (uint32_t)tg, i, n_walkers, gw, L, seed, bp, stage,
+                biased_walk_lane<true, kPos, kCount>(row32, col32, (uint32_t)tg, i, n_walkers, gw, L, seed, bp, row,
                                                      st, n_trials, n_fetch, n_tests, n_probes);
             else
                 biased_walk_lane<false, false, kCount>(row32, col32, (uint32_t)tg, i, n_walkers, gw, L, seed, bp,
-                                                       stage, st, n_trials, n_fetch, n_tests, n_probes);
+                                                       row, st, n_trials, n_fetch, n_tests, n_probes);
         }
     }
     if (st) atomicOr((unsigned long long *)&status[0], (unsigned long long)st);
@@ -722,7 +545,6 @@ biased_walker_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restr
 // Results are identical to biased_walker_kernel (same stream, same decisions).
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-typedef int64_t i64x2_a16 __attribute__((ext_vector_type(2)));
 
 constexpr int kStNextWalker = 10;  // status slot: next unassigned walker (dynamic distribution)
 
@@ -907,34 +729,7 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
     uint32_t slot = 0, ku = 0, kv = 0, ru = 0, rejected = 0;
     uint32_t c_start = 0, c_deg = 0, c_rpos = kRposLookup;  // the candidate's row and where prev sits in it (fat entries)
     const uint32_t *addr = row32;
-    int64_t *sp = out;
-    // Write combining: the last (up to) four columns of the lane's row wait in registers until they fill a
-    // 32-byte-aligned group of the caller's row, the granule a partial HBM write costs anyway (one write
-    // request per four columns instead of one per column).
-    uint32_t wb0 = 0, wb1 = 0, wb2 = 0, wb3 = 0;
-    auto emit = [&](uint32_t v, int32_t col) {
-        const uint32_t k = (uint32_t)((uintptr_t)sp >> 3) & 3u;
-        wb0 = k == 0u ? v : wb0;
-        wb1 = k == 1u ? v : wb1;
-        wb2 = k == 2u ? v : wb2;
-        wb3 = k == 3u ? v : wb3;
-        ++sp;
-        if (k == 3u || col == L) {
-            const uint32_t have = min(k + 1u, (uint32_t)col + 1u);  // columns of THIS row in the group
-            int64_t *grp = sp - (k + 1u);
-            if (have == 4u) {
-                const i64x2_a16 lo2 = {(int64_t)wb0, (int64_t)wb1}, hi2 = {(int64_t)wb2, (int64_t)wb3};
-                *reinterpret_cast<i64x2_a16 *>(grp) = lo2;
-                *reinterpret_cast<i64x2_a16 *>(grp + 2) = hi2;
-            } else {
-                const uint32_t first = k + 1u - have;
-                if (first == 0u) grp[0] = (int64_t)wb0;
-                if (first <= 1u && k >= 1u) grp[1] = (int64_t)wb1;
-                if (first <= 2u && k >= 2u) grp[2] = (int64_t)wb2;
-                if (k >= 3u) grp[3] = (int64_t)wb3;
-            }
-        }
-    };
+    RowCombiner row = {out, 0u, 0u, 0u, 0u};  // the caller's int64 row, four columns per store
 
     while (true) {
         // ---- hand out walkers to the lanes that need one (one atomic per wave) ----
@@ -954,12 +749,12 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                     const int64_t tg = targets[walker];
                     // lanes advance at their own pace, so nothing is gained by staging lane-contiguously:
                     // this kernel writes the caller's int64 row directly, four columns at a time (emit)
-                    sp = out + walker * (int64_t)(L + 1);
+                    row.sp = out + walker * (int64_t)(L + 1);
                     if ((uint64_t)tg >= (uint64_t)n_nodes) {
                         st |= TRW_ST_NODE_RANGE;  // reported; the row is filled with the bad id
-                        for (int32_t c = 0; c <= L; ++c) *sp++ = tg;
+                        for (int32_t c = 0; c <= L; ++c) row.sp[c] = tg;
                     } else {
-                        emit((uint32_t)tg, 0);  // column 0
+                        row.emit((uint32_t)tg, 0, L);  // column 0
                         gw = (uint64_t)walker_base + (uint64_t)walker;
                         d_cons = 0;
                         d_prod = 0;
@@ -1097,7 +892,7 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
 
         // ---- emit an accepted candidate and move to the next step ----
         if (ev_accept) {
-            emit(cand, s);
+            row.emit(cand, s, L);
             ++s;
             rejected = 0;
             if (s > L) {
