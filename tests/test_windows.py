@@ -125,6 +125,32 @@ def test_gpu_to_windows_full_size_properties():
 
 
 @pytest.mark.gpu
+def test_gpu_to_windows_long_runs():
+    """Large jobs give every lane a longer run of the stream (fewer jump-aheads): 700k walks x 81 columns =
+    215 M negatives; spot draws everywhere, every lane boundary of the first waves, and a shard."""
+    from torch_rw import rw
+    g = torch.Generator(device=DEV).manual_seed(6)
+    walks = torch.randint(0, 999_983, (700_000, 81), generator=g, device=DEV)
+    t, p, n = rw.to_windows(walks, 5, 999_983, 77)
+    flat = n.reshape(-1)
+    total = flat.numel()
+    assert total == 700_000 * 77 * 4
+    ks = set(np.random.default_rng(3).integers(0, total, 150).tolist())
+    ks |= {0, total - 1}
+    for run in (124, 155, 186, 217):                      # whichever run length the library chose
+        ks |= {run * l + d for l in (1, 2, 63, 64, 65, 255, 256, 257) for d in (-1, 0, 1)}
+    for k in sorted(ks):
+        assert int(flat[k]) == int(O.glibc_stream(77, 1, start=k)[0]) % 999_983, k
+    # 64 consecutive lanes' worth of draws, contiguous
+    ref = O.glibc_stream(77, 20_000, start=0) % 999_983
+    assert (flat[:20_000].cpu().numpy() == ref).all()
+    st, sp, sn = rw.to_windows_ex(walks[650_000:], 5, 999_983, 77, walk_base=650_000)
+    assert torch.equal(sn, n[650_000 * 77:]) and torch.equal(sp, p[650_000 * 77:]) and torch.equal(st, t[650_000 * 77:])
+    assert torch.equal(t.view(700_000, 77), walks[:, 2:79])
+    assert torch.equal(p.view(700_000, 77, 4)[:, :, 1], walks[:, 1:78])
+
+
+@pytest.mark.gpu
 def test_gpu_cbow_modes_equal_oracle():
     from torch_rw import rw
     walks = np.random.default_rng(3).integers(0, 12, (900, 30))         # 12 nodes: many collisions

@@ -718,7 +718,7 @@ size_t trw_to_windows_workspace_bytes(int64_t num_walks, int64_t walk_cols, int3
 {
     if (num_walks <= 0 || walk_cols < 1 || window_size < 1 || window_size > walk_cols) return kStatusBytes;
     const int64_t draws = num_walks * (walk_cols - window_size + 1) * (int64_t)(window_size - 1);
-    const int64_t nlanes = (draws + kFillRun - 1) / kFillRun;
+    const int64_t nlanes = (draws + fill_run(draws) - 1) / fill_run(draws);
     return kStatusBytes + align_up((size_t)nlanes * kGlDeg * sizeof(uint32_t), 256);
 }
 
@@ -750,12 +750,12 @@ int trw_to_windows_hip(const int64_t *walks, int64_t num_walks, int64_t walk_col
 
     prof_mark(0, stream);
     uint32_t *win = (uint32_t *)((char *)workspace + kStatusBytes);
-    const int64_t nlanes = (draws + kFillRun - 1) / kFillRun;
+    const int64_t nlanes = (draws + fill_run(draws) - 1) / fill_run(draws);
     if (draws > 0) {
         SeedWindow sw;
         trw::seed_window(seed, sw.w);
         glibc_windows_kernel<<<(unsigned)((nlanes + kBlock - 1) / kBlock), kBlock, 0, stream>>>(
-            sw, (uint64_t)walk_base * (uint64_t)step_end * (uint64_t)width, (uint64_t)kFillRun, nlanes, win);
+            sw, (uint64_t)walk_base * (uint64_t)step_end * (uint64_t)width, (uint64_t)fill_run(draws), nlanes, win);
     }
     prof_mark(1, stream);
     windows_gather_kernel<<<stream_grid(total_windows), kBlock, 0, stream>>>(walks, num_walks, walk_cols, window_size,
@@ -831,7 +831,7 @@ size_t trw_to_windows_triples_workspace_bytes(int64_t num_walks, int64_t walk_co
 {
     if (num_walks <= 0 || walk_cols < 1 || window_size < 1) return kStatusBytes;
     const int64_t draws = num_walks * ((walk_cols - 1) / 2) * 2 * (int64_t)window_size;
-    const int64_t nlanes = (draws + kFillRun - 1) / kFillRun;
+    const int64_t nlanes = (draws + fill_run(draws) - 1) / fill_run(draws);
     return kStatusBytes + align_up((size_t)nlanes * kGlDeg * sizeof(uint32_t), 256);
 }
 
@@ -861,11 +861,11 @@ int trw_to_windows_triples_hip(const int64_t *walks, int64_t num_walks, int64_t 
     if (int rc = ensure_jump_table()) return rc;
     prof_mark(0, stream);
     uint32_t *win = (uint32_t *)((char *)workspace + kStatusBytes);
-    const int64_t nlanes = (draws + kFillRun - 1) / kFillRun;
+    const int64_t nlanes = (draws + fill_run(draws) - 1) / fill_run(draws);
     SeedWindow sw;
     trw::seed_window(seed, sw.w);
     glibc_windows_kernel<<<(unsigned)((nlanes + kBlock - 1) / kBlock), kBlock, 0, stream>>>(
-        sw, num_triples == 1 ? 0 : (uint64_t)walk_base * (uint64_t)per_walk * (uint64_t)slots, (uint64_t)kFillRun,
+        sw, num_triples == 1 ? 0 : (uint64_t)walk_base * (uint64_t)per_walk * (uint64_t)slots, (uint64_t)fill_run(draws),
         nlanes, win);
     prof_mark(1, stream);
     triples_windows_gather_kernel<<<stream_grid(total_windows), kBlock, 0, stream>>>(

@@ -14,9 +14,18 @@
 
 namespace {
 
-constexpr int kFillRun = 4 * kGlDeg;  // draws per lane of glibc_fill_mod_kernel (a multiple of the generator order)
+// Draws per lane of glibc_fill_mod_kernel: a multiple of the generator order, 4 turns for small jobs and up
+// to 32 for large ones (every lane costs one jump-ahead, ~6 31x31 polynomial products; ~1M lanes fill the chip).
+__host__ __device__ inline int64_t fill_run(int64_t draws)
+{
+    int64_t turns = draws / ((int64_t)kGlDeg << 20);
+    turns = turns < 4 ? 4 : (turns > 32 ? 32 : turns);
+    return turns * kGlDeg;
+}
 
 // centre[w] = middle node of window w; pos[w][*] = the window without its middle.
+// One thread per OUTPUT element, so that both outputs are written fully coalesced (512 bytes per wave
+// store); the walk entries are re-read ~window_size times each, from L1/L2.
 __global__ void __launch_bounds__(kBlock)
 windows_gather_kernel(const int64_t *__restrict__ walks, int64_t num_walks, int64_t cols, int32_t window_size,
                       int64_t *__restrict__ centre, int64_t *__restrict__ pos)
@@ -26,58 +35,77 @@ windows_gather_kernel(const int64_t *__restrict__ walks, int64_t num_walks, int6
     const int32_t mid = window_size / 2;
     const int32_t width = window_size - 1;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t w = (int64_t)blockIdx.x * kBlock + threadIdx.x; w < total; w += stride) {
+    const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    for (int64_t w = tid; w < total; w += stride) {
         const int64_t walk_idx = w / step_end;
-        const int64_t step = w - walk_idx * step_end;
-        const int64_t *src = walks + walk_idx * cols + step;
-        int64_t *dst = pos + w * width;
-        for (int32_t i = 0; i < window_size; ++i) {
-            const int64_t v = src[i];
-            if (i == mid) centre[w] = v;
-            else dst[i < mid ? i : i - 1] = v;
-        }
+        centre[w] = walks[walk_idx * cols + (w - walk_idx * step_end) + mid];
+    }
+    const int64_t elems = total * width;
+    for (int64_t f = tid; f < elems; f += stride) {
+        const int64_t w = f / width;
+        const int32_t i = (int32_t)(f - w * width);
+        const int64_t walk_idx = w / step_end;
+        pos[f] = walks[walk_idx * cols + (w - walk_idx * step_end) + (i < mid ? i : i + 1)];
     }
 }
 
 // out[k] = (draw k of the stream) % num_nodes for k in [0, total); lane l produces draws
-// [l*kFillRun, (l+1)*kFillRun) from the window glibc_windows_kernel left in win[.][l].
+// [l*run, (l+1)*run), run = fill_run(total), from the window glibc_windows_kernel left in win[.][l].
 // With `rows` set, draw k selects a row of that [num_nodes][3] table instead and out[k][0..2] gets the row
 // (the negatives of to_windows_triples, windows_cpu.cpp:279-290).
+// A lane's draws are consecutive outputs, so lanes writing their own values would scatter 8-byte stores
+// 992 bytes apart: every turn of the generator (31 draws per lane) goes through a per-wave LDS tile
+// instead and leaves as 248-byte contiguous runs, two per wave store.
 template <bool kRows>
 __global__ void __launch_bounds__(kBlock)
 glibc_fill_mod_kernel(const uint32_t *__restrict__ win, int64_t nlanes, int64_t total, int64_t num_nodes,
                       const int64_t *__restrict__ rows, int64_t *__restrict__ out)
 {
+    constexpr int kStride = kGlDeg + 2;  // 33: odd, conflict-free lane-per-row writes
+    __shared__ uint32_t tiles[(kBlock / 64) * 64 * kStride];
+    uint32_t *t = tiles + (threadIdx.x >> 6) * 64 * kStride;
+    const int ln = threadIdx.x & 63;
     const int64_t lane = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (lane >= nlanes) return;
+    const int64_t wave_lane0 = lane - ln;
+    const bool in_range = lane < nlanes;  // the whole wave stays: every lane helps writing the wave's runs
     uint32_t w[kGlDeg];
 #pragma unroll
-    for (int j = 0; j < kGlDeg; ++j) w[j] = win[(int64_t)j * nlanes + lane];
+    for (int j = 0; j < kGlDeg; ++j) w[j] = in_range ? win[(int64_t)j * nlanes + lane] : 0u;
     const bool small = num_nodes < ((int64_t)1 << 32);
     FastMod fm;
     fm.init(small ? (uint32_t)num_nodes : 1u);
-    int64_t k = lane * kFillRun;
-    int64_t *dst = out + k * (kRows ? 3 : 1);
-    for (int rep = 0; rep < kFillRun / kGlDeg; ++rep) {
+    const int64_t run = fill_run(total);
+    for (int rep = 0; rep < (int)(run / kGlDeg); ++rep) {
 #pragma unroll
         for (int j = 0; j < kGlDeg; ++j) {
             const uint32_t v = w[j] + w[(j + kGlDeg - kGlSep) % kGlDeg];
             w[j] = v;
             const uint32_t r = v >> 1;
-            if (k < total) {
-                const int64_t idx = small ? (int64_t)fm.mod(r) : (int64_t)r;  // r < 2^31 <= num_nodes otherwise
+            t[ln * kStride + j] = small ? fm.mod(r) : r;  // r < 2^31 <= num_nodes otherwise
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // half a wave per producing lane: 31 of its 32 threads carry one draw each
+        const int j = ln & 31;
+#pragma unroll 4
+        for (int pass = 0; pass < 32; ++pass) {
+            const int src = 2 * pass + (ln >> 5);
+            const int64_t k = (wave_lane0 + src) * run + rep * kGlDeg + j;
+            if (j < kGlDeg && k < total) {
+                const int64_t idx = (int64_t)t[src * kStride + j];
                 if (kRows) {
                     const int64_t *row = rows + idx * 3;
+                    int64_t *dst = out + k * 3;
                     dst[0] = row[0];
                     dst[1] = row[1];
                     dst[2] = row[2];
                 } else {
-                    *dst = idx;
+                    out[k] = idx;
                 }
             }
-            ++k;
-            dst += kRows ? 3 : 1;
         }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
