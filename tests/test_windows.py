@@ -246,3 +246,17 @@ def test_gpu_triples_windows_equal_oracle(ws, cols, ntr):
     pt, nt, w = O.to_windows_triples_cbow(walks, ws, 40, -7, triples, 11, rng_mode=O.RNG_WALKER, window_base=99)
     gpt, gnt, gw = rw.to_windows_triples_ex(d_w, ws, -7, d_t, 11, cbow=True, base=99, rng_mode=rw.RNG_WALKER)
     assert (gpt.cpu().numpy() == pt).all() and (gnt.cpu().numpy() == nt).all() and (gw.cpu().numpy() == w).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("num_walks,cols,ws", [(1, 700_003, 2),      # one walk's windows overflow the tiled kernel: per-window kernel
+                                               (3000, 161, 5),        # several walks per block, last block ragged
+                                               (37, 2001, 3)])        # one walk per block
+def test_gpu_triples_windows_shapes(num_walks, cols, ws):
+    from torch_rw import rw
+    rng = np.random.default_rng(cols)
+    walks = rng.integers(0, 1000, (num_walks, cols))
+    triples = rng.integers(0, 1000, (50, 3))
+    t, p, n = O.to_windows_triples(walks, ws, 1000, -1, triples, 3)
+    gt, gp, gn = rw.to_windows_triples(torch.as_tensor(walks).to(DEV), ws, 1000, -1, torch.as_tensor(triples).to(DEV), 3)
+    assert (gt.cpu().numpy() == t).all() and (gp.cpu().numpy() == p).all() and (gn.cpu().numpy() == n).all()

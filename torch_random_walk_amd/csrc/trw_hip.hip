@@ -827,6 +827,27 @@ static int triples_windows_check(const int64_t *walks, int64_t num_walks, int64_
     return TRW_OK;
 }
 
+namespace {
+// target triples + positive windows of the two triples window builders
+void launch_triples_gather(const int64_t *walks, int64_t num_walks, int64_t walk_cols, int32_t window_size,
+                           int64_t padding_idx, int64_t *target_triples, int64_t *pos_windows, hipStream_t stream)
+{
+    const int64_t per_walk = (walk_cols - 1) / 2;
+    const int64_t per_walk_elems = per_walk * 2 * (int64_t)window_size * 3;
+    if (num_walks <= 0 || per_walk <= 0) return;
+    if (per_walk_elems < ((int64_t)1 << 22) && num_walks < ((int64_t)1 << 31)) {
+        int64_t wpb = 32768 / per_walk_elems;  // ~32K elements (256 KB) per block
+        wpb = wpb < 1 ? 1 : wpb;
+        const int64_t blocks = (num_walks + wpb - 1) / wpb;
+        triples_windows_gather_kernel<<<(unsigned)blocks, kBlock, 0, stream>>>(
+            walks, num_walks, walk_cols, window_size, padding_idx, (int32_t)wpb, target_triples, pos_windows);
+    } else {
+        triples_windows_gather_long_kernel<<<stream_grid(num_walks * per_walk), kBlock, 0, stream>>>(
+            walks, num_walks, walk_cols, window_size, padding_idx, target_triples, pos_windows);
+    }
+}
+}  // namespace
+
 size_t trw_to_windows_triples_workspace_bytes(int64_t num_walks, int64_t walk_cols, int32_t window_size)
 {
     if (num_walks <= 0 || walk_cols < 1 || window_size < 1) return kStatusBytes;
@@ -868,8 +889,7 @@ int trw_to_windows_triples_hip(const int64_t *walks, int64_t num_walks, int64_t 
         sw, num_triples == 1 ? 0 : (uint64_t)walk_base * (uint64_t)per_walk * (uint64_t)slots, (uint64_t)fill_run(draws),
         nlanes, win);
     prof_mark(1, stream);
-    triples_windows_gather_kernel<<<stream_grid(total_windows), kBlock, 0, stream>>>(
-        walks, num_walks, walk_cols, window_size, padding_idx, target_triples, pos_windows);
+    launch_triples_gather(walks, num_walks, walk_cols, window_size, padding_idx, target_triples, pos_windows, stream);
     glibc_fill_mod_kernel<true><<<(unsigned)((nlanes + kBlock - 1) / kBlock), kBlock, 0, stream>>>(
         win, nlanes, draws, num_triples, triples, neg_windows);
     prof_mark(2, stream);
@@ -904,8 +924,7 @@ int trw_to_windows_triples_cbow_hip(const int64_t *walks, int64_t num_walks, int
     if (!pos_triples || !neg_triples || !pos_windows) return fail(TRW_E_ARG, "output pointer is null");
     prof_mark(0, stream);
     prof_mark(1, stream);
-    triples_windows_gather_kernel<<<stream_grid(total_windows), kBlock, 0, stream>>>(
-        walks, num_walks, walk_cols, window_size, padding_idx, pos_triples, pos_windows);
+    launch_triples_gather(walks, num_walks, walk_cols, window_size, padding_idx, pos_triples, pos_windows, stream);
     SeedWindow sw;
     trw::seed_window(seed, sw.w);
     if (mode == TRW_RNG_GLIBC)

@@ -109,11 +109,88 @@ glibc_fill_mod_kernel(const uint32_t *__restrict__ win, int64_t nlanes, int64_t 
     }
 }
 
-// Triples windows (windows_cpu.cpp:160-474).  One thread per window: the target triple and the
-// 2*window_size positive rows around it, with the reference's off-by-one left half and its
-// walk[rel] in the head slot of left rows kept as they are.
+// n / d and n % d for n < 2^22 and one small d: one multiply by the rounded reciprocal, one correction.
+struct SmallDiv {
+    float rcp;
+    uint32_t d;
+    __device__ __forceinline__ void init(uint32_t den)
+    {
+        d = den;
+        rcp = 1.0f / (float)den;
+    }
+    __device__ __forceinline__ void divmod(uint32_t n, uint32_t &q, uint32_t &r) const
+    {
+        q = (uint32_t)((float)n * rcp);
+        r = n - q * d;
+        if ((int32_t)r < 0) {
+            --q;
+            r += d;
+        } else if (r >= d) {
+            ++q;
+            r -= d;
+        }
+    }
+};
+
+// Triples windows (windows_cpu.cpp:160-474): the target triple and the 2*window_size positive rows around
+// it, with the reference's off-by-one left half and its walk[rel] in the head slot of left rows kept as
+// they are.  One thread per OUTPUT element: a block owns `walks_per_block` whole walks, whose windows are
+// one contiguous piece of both outputs, and writes it 2 KB per block store; the walk entries are re-read
+// from L1/L2.  (Host: walks_per_block * per_walk * 2*window_size*3 < 2^22.)
 __global__ void __launch_bounds__(kBlock)
 triples_windows_gather_kernel(const int64_t *__restrict__ walks, int64_t num_walks, int64_t cols,
+                              int32_t window_size, int64_t pad, int32_t walks_per_block,
+                              int64_t *__restrict__ target_triples, int64_t *__restrict__ pos_windows)
+{
+    const uint32_t per_walk = (uint32_t)((cols - 1) / 2);
+    const uint32_t elems = 2u * (uint32_t)window_size * 3u;  // per window
+    const int64_t walk0 = (int64_t)blockIdx.x * walks_per_block;
+    const int64_t left = num_walks - walk0;
+    const uint32_t nw = left < walks_per_block ? (uint32_t)left : (uint32_t)walks_per_block;
+    SmallDiv by_elems, by_walk, by3;
+    by_elems.init(elems);
+    by_walk.init(per_walk);
+    by3.init(3u);
+    const int64_t *walk_base = walks + walk0 * cols;
+    int64_t *pos = pos_windows + walk0 * (int64_t)per_walk * elems;
+    const uint32_t n_pos = nw * per_walk * elems;
+    for (uint32_t o = threadIdx.x; o < n_pos; o += kBlock) {
+        uint32_t wl, rem, walk_local, win, slot, c;
+        by_elems.divmod(o, wl, rem);
+        by_walk.divmod(wl, walk_local, win);
+        by3.divmod(rem, slot, c);
+        const int64_t *walk = walk_base + (int64_t)walk_local * cols;
+        const int64_t tri = 2 * (int64_t)win + 1;  // index of the target relation
+        int64_t v = pad;
+        if (slot < (uint32_t)window_size) {  // left rows (the reference also writes row window_size, overwritten by the right half)
+            const int64_t rel = tri - ((int64_t)slot + 1) * 2;
+            if (c == 0) {
+                if (rel - 1 >= 0) v = walk[rel];  // sic: walk[rel], windows_cpu.cpp:221
+            } else if (c == 1) {
+                if (rel >= 0) v = walk[rel];
+            } else {
+                if (rel + 1 >= 0) v = walk[rel + 1];
+            }
+        } else {
+            const int64_t idx = tri + ((int64_t)slot - window_size + 1) * 2 - 1 + c;
+            if (idx < cols) v = walk[idx];
+        }
+        pos[o] = v;
+    }
+    int64_t *tgt = target_triples + walk0 * (int64_t)per_walk * 3;
+    const uint32_t n_tgt = nw * per_walk * 3u;
+    for (uint32_t o = threadIdx.x; o < n_tgt; o += kBlock) {
+        uint32_t wl, c, walk_local, win;
+        by3.divmod(o, wl, c);
+        by_walk.divmod(wl, walk_local, win);
+        tgt[o] = walk_base[(int64_t)walk_local * cols + 2 * (int64_t)win + c];
+    }
+}
+
+// The same, one thread per window: walks so long that one walk's windows overflow the 32-bit element
+// index of the kernel above.
+__global__ void __launch_bounds__(kBlock)
+triples_windows_gather_long_kernel(const int64_t *__restrict__ walks, int64_t num_walks, int64_t cols,
                               int32_t window_size, int64_t pad, int64_t *__restrict__ target_triples,
                               int64_t *__restrict__ pos_windows)
 {
