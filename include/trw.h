@@ -12,7 +12,9 @@
  * constant jump table once).  Environment knobs (debug/tests): TRW_GLIBC_CHAIN=k
  * walkers chained per lane in the uniform kernel; TRW_FORCE_WIDE=1 use the int64
  * kernels; TRW_NO_POS=1 disable the located-t shortcut of the biased kernel;
- * TRW_HASH=0/1, TRW_EXT=0/1 force the edge table / the fat entries off or on.
+ * TRW_HASH=0/1, TRW_EXT=0/1 force the edge table / the fat entries off or on;
+ * TRW_HASH_SLACK=k table slots per edge (default 3); TRW_RESIDENT_BLOCKS=k
+ * workgroups per CU of the persistent biased kernel (default 5).
  * None of them changes a result.
  */
 #ifndef TRW_H

@@ -484,7 +484,10 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col
     } else if (pl.narrow && pl.hash) {
         // persistent lanes: walkers are dealt out by a device counter (status[kStNextWalker])
         int64_t blocks = (n_walkers + kBlock - 1) / kBlock;
-        const int64_t resident = (int64_t)device_cu_count() * 8;
+        // Workgroups per CU (TRW_RESIDENT_BLOCKS; 8 = every wave slot).  The memory system is saturated well
+        // before that: measured on R-MAT 10M/110M 138.5 ms at 8, 136.8 at 5, 135.9 at 4, 141.0 at 3 (and the
+        // same shape on the 1M graph), so 5 -- which also leaves wave slots to a collective on another stream.
+        const int64_t resident = (int64_t)device_cu_count() * env_long("TRW_RESIDENT_BLOCKS", 1, 8, 5);
         if (blocks > resident) blocks = resident;
         if (g_prof.count)
             biased_hash_kernel<true><<<(unsigned)blocks, kBlock, 0, stream>>>(
