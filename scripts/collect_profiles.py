@@ -3,7 +3,8 @@
 the rocprofv3 --kernel-trace --stats CSV, the condensed summary, and the per-launch HBM traffic
 of the dominant kernel (profiles/pmc_traffic.json, read by bench.py).
 
-usage: scripts/collect_profiles.py <tag> <workload> [<workload> ...]
+usage: scripts/collect_profiles.py <tag> <workload> [<workload> ...] [--dst DIR]
+(--dst: write there instead of profiles/ -- on the GPU box, where only gpurun_out/ travels back)
 """
 import csv
 import glob
@@ -14,17 +15,25 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1]
+argv = list(sys.argv)
+DST = os.path.join(ROOT, "profiles")
+if "--dst" in argv:
+    k = argv.index("--dst")
+    DST = os.path.abspath(argv[k + 1])
+    del argv[k:k + 2]
+tag = argv[1]
 DOMINANT = {"rmat10m_biased": ("biased_hash_kernel", "biased_walker_kernel"),
             "rmat10m_uniform": ("uniform_glibc_rows_kernel", "uniform_glibc_ext_kernel", "uniform_glibc_kernel"),
             "er100k_uniform": ("uniform_glibc_rows_kernel", "uniform_glibc_kernel", "uniform_glibc_ext_kernel"),
             "kg5m_triples": ("triples_walker_kernel",), "elist_rmat1m_biased": ("elist_walk_kernel",),
             "elist_rmat1m_uniform": ("elist_walk_kernel",), "windows_1m": ("glibc_fill_mod_kernel",)}
-traffic_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-traffic = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
-for wl in sys.argv[2:]:
+traffic_path = os.path.join(DST, "pmc_traffic.json")
+base_path = traffic_path if os.path.exists(traffic_path) else os.path.join(ROOT, "profiles", "pmc_traffic.json")
+traffic = json.load(open(base_path)) if os.path.exists(base_path) else {}
+os.makedirs(DST, exist_ok=True)
+for wl in argv[2:]:
     src = os.path.join(ROOT, "gpurun_out", "prof_%s_%s" % (tag, wl))
-    dst = os.path.join(ROOT, "profiles")
+    dst = DST
     os.makedirs(dst, exist_ok=True)
     for name in ("stats/stats_kernel_stats.csv", "summary.txt"):
         p = os.path.join(src, name)
@@ -59,4 +68,4 @@ for wl in sys.argv[2:]:
 with open(traffic_path, "w") as f:
     json.dump(traffic, f, indent=1, sort_keys=True)
     f.write("\n")
-print(json.dumps(traffic, indent=1))
+print(json.dumps({k: traffic[k] for k in argv[2:] if k in traffic}, indent=1))
