@@ -313,7 +313,9 @@ VARIANTS = [{"TRW_FORCE_WIDE": "1"},                      # int64 kernels
             {"TRW_HASH": "0"},                           # bisection kernel, located-t shortcut
             {"TRW_HASH": "0", "TRW_NO_POS": "1"},        # bisection kernel, every candidate loaded
             {"TRW_HASH": "1"},                           # edge table + state machine
-            {"TRW_HASH": "1", "TRW_NO_POS": "1"}]
+            {"TRW_HASH": "1", "TRW_NO_POS": "1"},
+            {"TRW_HASH": "1", "TRW_RESIDENT_BLOCKS": "1"},   # persistent kernel: workgroups per CU is launch geometry
+            {"TRW_HASH": "1", "TRW_RESIDENT_BLOCKS": "8", "TRW_HASH_SLACK": "2"}]
 
 
 @pytest.mark.parametrize("env", VARIANTS)
