@@ -422,6 +422,23 @@ def main():
                    sample="first %d start nodes of a seeded permutation of the batch, %d steps, %.1f s, "
                           "oracle libc srand/rand single thread (the reference's csrc/cpu algorithm; its "
                           "multi-threaded run is slower and non-deterministic, SURVEY 0.2)" % (sample, sample * L, dt))
+        if not (windows or elist or kg):
+            # the reference's multi-threaded policy beside the single thread (all host threads on the
+            # one locked libc rand(); non-deterministic output), a quarter of the time budget; the faster one is
+            # the baseline.
+            nthreads = min(os.cpu_count() or 1, 16)  # a GPU box's CPU share
+            probe_mt = max(2 * 32768 // (1 if uniform else L + 1), 2000)
+            _, dt_mt, used = O.walk_timed_mt(rp_h, ci_h, tg_cpu[perm[:probe_mt]].numpy(), p, q, L, args.seed, nthreads)
+            rate_mt = probe_mt * L / dt_mt
+            sample_mt = int(min(B, max(probe_mt, 0.25 * args.cpu_seconds * rate_mt / L)))
+            _, dt_mt, used = O.walk_timed_mt(rp_h, ci_h, tg_cpu[perm[:sample_mt]].numpy(), p, q, L, args.seed, nthreads)
+            rate_mt = sample_mt * L / dt_mt
+            cpu["single_thread"] = cpu["value"]
+            cpu["multi_thread"] = dict(value=rate_mt, threads=used, host_threads=nthreads,
+                                       sample="%d start nodes, %.1f s, at::parallel_for chunking, every thread on "
+                                              "libc's locked rand()" % (sample_mt, dt_mt))
+            if rate_mt > cpu["value"]:
+                cpu["value"], cpu["cores"] = rate_mt, used
         m = min(B, 2000)
         if windows:
             ref_n = O.to_windows(ww_h[:m], cfg["window_size"], n, args.seed)[2].reshape(m, -1)

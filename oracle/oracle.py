@@ -206,6 +206,27 @@ def walk_timed(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, rng_mode
     return out, dt
 
 
+def walk_timed_mt(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, n_threads):
+    """TIMING only: the reference's multi-threaded policy (at::parallel_for chunks, every thread on the one
+    locked libc rand()).  Returns (walks, seconds, threads the policy starts); the walks depend on the
+    thread interleaving and are only good for the edge property."""
+    rp, rp_p = _i64(row_ptr)
+    ci, ci_p = _i64(col_idx)
+    tg, tg_p = _i64(target_nodes)
+    n = int(tg.shape[0])
+    out = np.empty((n, int(walk_length) + 1), dtype=np.int64)
+    sec, used = ctypes.c_double(0.0), ctypes.c_int32(0)
+    f = lib().trw_oracle_walk_csr_mt
+    f.restype = ctypes.c_int
+    rc = f(rp_p, ctypes.c_int64(int(rp.shape[0]) - 1), ci_p, ctypes.c_int64(int(ci.shape[0])), tg_p, ctypes.c_int64(n),
+           ctypes.c_double(float(p)), ctypes.c_double(float(q)), ctypes.c_int32(int(walk_length)),
+           ctypes.c_int32(int(seed)), ctypes.c_int32(int(n_threads)),
+           out.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), ctypes.byref(sec), ctypes.byref(used))
+    if rc != 0:
+        raise OracleError(rc)
+    return out, float(sec.value), int(used.value)
+
+
 def walk_triples(triples_indexed, relation_tail_index, target_nodes, walk_length, padding_idx, seed,
                  rng_mode=RNG_GLIBC_SEQ, walker_base=0, return_draws=False, timed=False):
     """The reference's ``triples::walk_triples_cpu`` restated: ``[N, 2*walk_length+1]`` int64."""

@@ -285,6 +285,45 @@ static inline int is_neighbor(graph_t *g, int64_t new_node, int64_t previous_nod
     return 0;
 }
 
+/* One walker: uniform_walk's hot loop (rw_cpu.cpp:95-104) or biased_walk's (rw_cpu.cpp:159-198). */
+static void walk_one(graph_t *g, rng_t *rng, int uniform, const double prob[3], int64_t target_node,
+                     int64_t walk_size, int64_t *walk, trw_oracle_counters *cnt, uint64_t *scanned)
+{
+    walk[0] = target_node; /* rw_cpu.cpp:92 / :156 */
+    if (uniform) {
+        int64_t previous_node = target_node;
+        for (int64_t s = 1; s < walk_size; ++s) {
+            int64_t next_node = sample_neighbor(g, previous_node, rng);
+            walk[s] = next_node;
+            previous_node = next_node;
+        }
+        return;
+    }
+    walk[1] = sample_neighbor(g, target_node, rng);
+    int64_t previous_node = walk[1];
+    for (int64_t s = 2; s < walk_size; ++s) {
+        int64_t selected_node = -1;
+        int64_t t_node = walk[s - 2];
+        while (1) {
+            /* both draws are always consumed, candidate first */
+            int64_t new_node = sample_neighbor(g, previous_node, rng);
+            double random_prob = ((double)rng_next(rng) / (double)RAND_MAX);
+            cnt->trials_total++;
+            if (g->err) { selected_node = new_node; break; }
+            if (new_node == t_node) {
+                if (random_prob < prob[0]) { selected_node = new_node; break; }
+            } else {
+                cnt->membership_tests++;
+                if (is_neighbor(g, new_node, t_node, scanned)) {
+                    if (random_prob < prob[1]) { selected_node = new_node; break; }
+                } else if (random_prob < prob[2]) { selected_node = new_node; break; }
+            }
+        }
+        walk[s] = selected_node;
+        previous_node = selected_node;
+    }
+}
+
 int trw_oracle_walk_csr(const int64_t *row_ptr, int64_t n_nodes,
                         const int64_t *col_idx, int64_t nnz,
                         const int64_t *targets, int64_t n_walkers,
@@ -326,53 +365,97 @@ int trw_oracle_walk_csr(const int64_t *row_ptr, int64_t n_nodes,
     const int64_t walk_size = (int64_t)walk_length + 1; /* rw_cpu.cpp:216 */
 
     for (int64_t i = 0; i < n_walkers; ++i) {
-        int64_t *walk = out + i * walk_size;
         uint64_t draws_before = rng.ndraws;
         rng_begin_walker(&rng, (uint64_t)walker_base + (uint64_t)i, walk_length);
-
-        int64_t target_node = targets[i];
-        walk[0] = target_node; /* rw_cpu.cpp:92 / :156 */
-
-        if (uniform) {
-            /* uniform_walk hot loop, rw_cpu.cpp:95-104 */
-            int64_t previous_node = target_node;
-            for (int64_t s = 1; s < walk_size; ++s) {
-                int64_t next_node = sample_neighbor(&g, previous_node, &rng);
-                walk[s] = next_node;
-                previous_node = next_node;
-            }
-        } else {
-            /* biased_walk hot loop, rw_cpu.cpp:159-198 */
-            walk[1] = sample_neighbor(&g, target_node, &rng);
-            int64_t previous_node = walk[1];
-            for (int64_t s = 2; s < walk_size; ++s) {
-                int64_t selected_node = -1;
-                int64_t t_node = walk[s - 2];
-                while (1) {
-                    /* both draws are always consumed, candidate first */
-                    int64_t new_node = sample_neighbor(&g, previous_node, &rng);
-                    double random_prob = ((double)rng_next(&rng) / (double)RAND_MAX);
-                    cnt.trials_total++;
-                    if (g.err) { selected_node = new_node; break; }
-                    if (new_node == t_node) {
-                        if (random_prob < prob[0]) { selected_node = new_node; break; }
-                    } else {
-                        cnt.membership_tests++;
-                        if (is_neighbor(&g, new_node, t_node, scanned)) {
-                            if (random_prob < prob[1]) { selected_node = new_node; break; }
-                        } else if (random_prob < prob[2]) { selected_node = new_node; break; }
-                    }
-                }
-                walk[s] = selected_node;
-                previous_node = selected_node;
-            }
-        }
+        walk_one(&g, &rng, uniform, prob, targets[i], walk_size, out + i * walk_size, &cnt, scanned);
         if (draws_per_walker) draws_per_walker[i] = (int64_t)(rng.ndraws - draws_before);
         if (g.err) break;
     }
     cnt.draws_total = rng.ndraws;
     if (counters) *counters = cnt;
     return g.err;
+}
+
+/* ------------------------------------------------------------------------ */
+/* The reference's multi-threaded run, for TIMING only                         */
+/* ------------------------------------------------------------------------ */
+/* walk_cpu runs its loop under at::parallel_for(0, N, grain) with every thread drawing from the one
+ * process-global, lock-protected libc rand() (rw_cpu.cpp:62-63 grain 32768, :137 grain 32768/(L+1)):
+ * the output depends on the interleaving, so this entry point exists to time that execution policy on
+ * the host next to the single-thread run (bench.py's cpu_baseline), not to produce comparable walks. */
+#include <pthread.h>
+#include <time.h>
+
+typedef struct {
+    graph_t g;
+    const int64_t *targets;
+    int64_t begin, end, walk_size;
+    int uniform;
+    const double *prob;
+    int64_t *out;
+} mt_chunk;
+
+static void *mt_worker(void *arg)
+{
+    mt_chunk *c = (mt_chunk *)arg;
+    rng_t rng;
+    memset(&rng, 0, sizeof rng);
+    rng.mode = TRW_ORACLE_RNG_LIBC;
+    trw_oracle_counters cnt;
+    memset(&cnt, 0, sizeof cnt);
+    for (int64_t i = c->begin; i < c->end && !c->g.err; ++i)
+        walk_one(&c->g, &rng, c->uniform, c->prob, c->targets[i], c->walk_size, c->out + i * c->walk_size, &cnt, NULL);
+    return NULL;
+}
+
+int trw_oracle_walk_csr_mt(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col_idx, int64_t nnz,
+                           const int64_t *targets, int64_t n_walkers, double p, double q, int32_t walk_length,
+                           int32_t seed, int32_t n_threads, int64_t *out, double *seconds, int32_t *threads_used)
+{
+    if (!row_ptr || (!col_idx && nnz) || (!targets && n_walkers) || (!out && n_walkers)) return TRW_ORACLE_E_ARG;
+    if (n_nodes < 0 || nnz < 0 || n_walkers < 0 || walk_length < 1 || n_threads < 1 || n_threads > 1024)
+        return TRW_ORACLE_E_ARG;
+    const int uniform = (p == 1.0 && q == 1.0);
+    double prob[3];
+    trw_oracle_probs(p, q, prob);
+    const int64_t walk_size = (int64_t)walk_length + 1;
+    int64_t grain = uniform ? 32768 : 32768 / walk_size;
+    if (grain < 1) grain = 1;
+    /* at::parallel_for: serial when the range fits one grain, else at most ceil(N / grain) threads with
+     * equal contiguous chunks */
+    int64_t nt = 1;
+    if (n_walkers > grain && n_threads > 1) {
+        nt = (n_walkers + grain - 1) / grain;
+        if (nt > n_threads) nt = n_threads;
+    }
+    const int64_t chunk = (n_walkers + nt - 1) / nt;
+    mt_chunk chunks[1024];
+    pthread_t tid[1024];
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    srand((unsigned)seed);
+    for (int64_t k = 0; k < nt; ++k) {
+        mt_chunk *c = &chunks[k];
+        c->g = (graph_t){ row_ptr, col_idx, n_nodes, nnz, 0 };
+        c->targets = targets;
+        c->begin = k * chunk;
+        c->end = (k + 1) * chunk < n_walkers ? (k + 1) * chunk : n_walkers;
+        c->walk_size = walk_size;
+        c->uniform = uniform;
+        c->prob = prob;
+        c->out = out;
+        if (nt == 1) mt_worker(c);
+        else if (pthread_create(&tid[k], NULL, mt_worker, c) != 0) return TRW_ORACLE_E_ARG;
+    }
+    int err = 0;
+    for (int64_t k = 0; k < nt; ++k) {
+        if (nt > 1) pthread_join(tid[k], NULL);
+        if (chunks[k].g.err) err = chunks[k].g.err;
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (seconds) *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    if (threads_used) *threads_used = (int32_t)nt;
+    return err;
 }
 
 /* ------------------------------------------------------------------------ */

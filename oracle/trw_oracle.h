@@ -107,6 +107,13 @@ int trw_oracle_walk_csr(const int64_t *row_ptr, int64_t n_nodes,
                         trw_oracle_counters *counters,
                         int64_t *draws_per_walker);
 
+/* TIMING only: the reference's multi-threaded execution policy (at::parallel_for chunks, all threads on the
+ * one locked libc rand()); walks depend on the thread interleaving.  *seconds = wall time of the walk,
+ * *threads_used = threads at::parallel_for would have started.  NOT re-entrant. */
+int trw_oracle_walk_csr_mt(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col_idx, int64_t nnz,
+                           const int64_t *targets, int64_t n_walkers, double p, double q, int32_t walk_length,
+                           int32_t seed, int32_t n_threads, int64_t *out, double *seconds, int32_t *threads_used);
+
 /*
  * triples::walk_triples_cpu restated (csrc/cpu/rw_cpu_triples.cpp:105-127 ->
  * uniform_walk_triples :48-103, triples::sample_neighbor :11-46, sample_int
