@@ -266,3 +266,21 @@ def test_c_oracle_equals_plain_python_restatement(p, q):
         w, c = O.walk(rp, ci, tg, p, q, 9, seed, return_counters=True)
         py = _py_walk(rp.tolist(), ci.tolist(), tg, p, q, 9, O.libc_stream(seed, c["draws_total"] + 8))
         assert w.tolist() == py
+
+
+def test_multithreaded_timing_leg():
+    """trw_oracle_walk_csr_mt: one thread = the sequential libc walk; several threads = the reference's
+    at::parallel_for policy on one locked rand() -- interleaving-dependent walks that still follow edges."""
+    from tests.helpers import random_graph
+    rp, ci = random_graph(3000, 5, 4)
+    tg = np.arange(3000).repeat(30)                                   # 90 000 walkers: 3 chunks of the uniform grain
+    ref = O.walk(rp, ci, tg, 1.0, 1.0, 10, 7, rng_mode=O.RNG_LIBC)
+    w, sec, used = O.walk_timed_mt(rp, ci, tg, 1.0, 1.0, 10, 7, 1)
+    assert used == 1 and sec > 0 and (w == ref).all()
+    w, sec, used = O.walk_timed_mt(rp, ci, tg, 1.0, 1.0, 10, 7, 4)
+    assert used == 3 and (w[:, 0] == tg).all()
+    edges = set(zip(np.repeat(np.arange(3000), np.diff(rp)).tolist(), ci.tolist()))
+    for row in w[::997]:
+        assert all((a, b) in edges for a, b in zip(row[:-1].tolist(), row[1:].tolist()))
+    wb, _, used = O.walk_timed_mt(rp, ci, tg[:5000], 0.5, 2.0, 10, 7, 4)     # biased grain: 32768 // 11
+    assert used == 2 and (wb[:, 0] == tg[:5000]).all()
