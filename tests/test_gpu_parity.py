@@ -420,3 +420,30 @@ def test_config3_rmat10m_full_size(rw):
     tg = torch.arange(10_000_000, device=DEV)
     _check_big(rw, rp, ci, tg, 0.25, 4.0, 80, 10, O.RNG_WALKER, sample=48)
     _check_big(rw, rp, ci, tg, 1.0, 1.0, 80, 10, O.RNG_GLIBC_INDEXED, sample=48)
+
+
+def test_more_than_2_32_output_elements(rw):
+    """54 M walkers x 81 columns = 4.4e9 output elements (35 GB): every index on the way is 64-bit.
+    Sampled rows (first, last, around the 2^32-element mark) against the oracle; both walks."""
+    from torch_random_walk_amd import graphs
+    n = 100_000
+    rp, ci = graphs.erdos_renyi(n, 1_000_000, seed=3, device=DEV)
+    N, L = 54_000_000, 80
+    tg = torch.arange(N, device=DEV) % n
+    rp_h, ci_h = rp.cpu().numpy(), ci.cpu().numpy()
+    mark = (1 << 32) // (L + 1)
+    rows = np.unique(np.concatenate([[0, 1, N - 2, N - 1], np.arange(mark - 3, mark + 4),
+                                     np.random.default_rng(1).integers(0, N, 40)]))
+    rows_d = torch.as_tensor(rows, device=DEV)
+    for p, q, omode in ((1.0, 1.0, O.RNG_GLIBC_INDEXED), (0.5, 2.0, O.RNG_WALKER)):
+        w = rw.walk(rp, ci, tg, p, q, L, 10)
+        assert w.shape == (N, L + 1) and w.numel() > (1 << 32)
+        got = w[rows_d].cpu().numpy()
+        assert int(w[:, 0].ne(tg).sum()) == 0
+        lo, hi = int(w.min()), int(w.max())
+        del w
+        torch.cuda.empty_cache()
+        assert 0 <= lo and hi < n
+        for r, g in zip(rows, got):
+            ref = O.walk(rp_h, ci_h, np.array([r % n]), p, q, L, 10, rng_mode=omode, walker_base=int(r))
+            assert (ref[0] == g).all(), "row %d differs" % r
