@@ -9,7 +9,8 @@
  * is made; the caller owns every buffer.  Calls are asynchronous on
  * `hip_stream` (a hipStream_t, NULL = the null stream) unless stated otherwise
  * and allocate nothing after the first call on a device (which uploads a 190 KB
- * constant jump table once).  Environment knobs (debug/tests): TRW_GLIBC_CHAIN=k
+ * constant jump table once); after that a call enqueues kernels only (no
+ * memset/memcpy nodes, no synchronisation) and may be captured into a HIP graph.  Environment knobs (debug/tests): TRW_GLIBC_CHAIN=k
  * walkers chained per lane in the uniform kernel; TRW_FORCE_WIDE=1 use the int64
  * kernels; TRW_NO_POS=1 disable the located-t shortcut of the biased kernel;
  * TRW_HASH=0/1, TRW_EXT=0/1 force the edge table / the fat entries off or on;

@@ -179,3 +179,44 @@ def test_gpu_serial_replay_auto_rule_shards_and_errors():
         rw.walk_edge_list(d_e.to(torch.int32), d_i, d_t, 1.0, 1.0, 4, 1, pad)
     with pytest.raises(RuntimeError, match="outside"):
         rw.walk_edge_list(d_e, d_i, torch.tensor([401], device=DEV), 1.0, 1.0, 4, 1, pad)
+
+
+@pytest.mark.gpu
+def test_gpu_calls_replay_from_a_hip_graph():
+    """Edge-list (table path), triples and window-builder calls captured into one HIP graph and replayed:
+    everything a call clears it clears with its own kernels (see test_gpu_parity.test_walk_is_graph_capturable)."""
+    from torch_rw import rw
+    from tests.test_triples import _kg
+    edges, index = _random_edge_list(800, 5000, 11)
+    tg = np.random.default_rng(1).integers(0, 800, 6000)
+    d = [edges.to(DEV), index.to(DEV), torch.as_tensor(tg).to(DEV)]
+    ref_e = O.walk_edge_list(edges.numpy(), index.numpy(), tg, 0.25, 4.0, 30, 5, 800, restart=True, rng_mode=O.RNG_WALKER)
+    ts, tindex, ents, pad = _kg(2000, 9000, 11, 9)
+    ttg = np.random.default_rng(2).integers(0, 2000, 5000)
+    dt = [ts.to(DEV), tindex.to(DEV), torch.as_tensor(ttg).to(DEV)]
+    ref_t = O.walk_triples(ts.numpy(), tindex.numpy(), ttg, 20, pad, 3, rng_mode=O.RNG_WALKER)
+    walks = np.random.default_rng(3).integers(0, 500, (900, 31))
+    d_walks = torch.as_tensor(walks).to(DEV)
+    ref_w = O.to_windows(walks, 5, 500, 7)
+
+    def calls():
+        return (rw.walk_edge_list_ex(*d, 0.25, 4.0, 30, 5, 800, restart=True, rng_mode=rw.RNG_WALKER, check=False),
+                rw.walk_triples_ex(*dt, 20, pad, 3, rng_mode=rw.RNG_WALKER, check=False),
+                rw.to_windows(d_walks, 5, 500, 7))
+
+    calls()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        calls()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        we, wt, (t, p, n) = calls()
+    for _ in range(3):
+        for x in (we, wt, t, p, n):
+            x.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert (we.cpu().numpy() == ref_e).all() and (wt.cpu().numpy() == ref_t).all()
+        assert (t.cpu().numpy() == ref_w[0]).all() and (p.cpu().numpy() == ref_w[1]).all() and (n.cpu().numpy() == ref_w[2]).all()

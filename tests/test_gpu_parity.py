@@ -447,3 +447,36 @@ def test_more_than_2_32_output_elements(rw):
         for r, g in zip(rows, got):
             ref = O.walk(rp_h, ci_h, np.array([r % n]), p, q, L, 10, rng_mode=omode, walker_base=int(r))
             assert (ref[0] == g).all(), "row %d differs" % r
+
+
+def test_walk_is_graph_capturable(rw):
+    """A call is a handful of kernels on the caller's stream, nothing else (no memset nodes: on ROCm 7.2 a
+    captured hipMemsetAsync runs on the first launch of a graph only): it can be captured into a HIP graph
+    and replayed any number of times -- status block, walker counter and edge table are reset by kernels
+    of the call itself."""
+    rp, ci = hub_graph(2000, 6)
+    tg = np.random.default_rng(2).integers(0, 2000, 20_000)
+    d_rp, d_ci, d_tg = _dev(rp, ci, tg)
+    ref_b = O.walk(rp, ci, tg, 0.25, 4.0, 20, 10, rng_mode=O.RNG_WALKER)
+    ref_u = O.walk(rp, ci, tg, 1.0, 1.0, 20, 10)
+    rw.walk_ex(d_rp, d_ci, d_tg[:8], 1.0, 1.0, 20, 10)           # first call on the device uploads the jump table
+
+    def both():
+        return (rw.walk_ex(d_rp, d_ci, d_tg, 0.25, 4.0, 20, 10, rng_mode=rw.RNG_WALKER, check=False),
+                rw.walk_ex(d_rp, d_ci, d_tg, 1.0, 1.0, 20, 10, check=False))
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):                                      # warm the allocator on a side stream
+            both()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        wb, wu = both()
+    for _ in range(3):
+        wb.zero_()
+        wu.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert (wb.cpu().numpy() == ref_b).all() and (wu.cpu().numpy() == ref_u).all()

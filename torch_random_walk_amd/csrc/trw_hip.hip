@@ -227,6 +227,22 @@ unsigned stream_grid(int64_t items)
     return (unsigned)blocks;
 }
 
+// Buffers are cleared by a kernel of this library, never by hipMemsetAsync: a memset node captured into a
+// HIP graph runs on the first launch of the graph only (ROCm 7.2, observed; tests/test_gpu_parity.py
+// test_walk_is_graph_capturable), and a call has to be replayable.  `bytes` and `dst` are multiples of 16.
+__global__ void __launch_bounds__(kBlock) fill_kernel(uint4 *__restrict__ dst, uint32_t word, size_t n16)
+{
+    const uint4 v = {word, word, word, word};
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += stride) dst[i] = v;
+}
+
+void device_fill(void *dst, uint32_t word, size_t bytes, hipStream_t stream)
+{
+    const size_t n16 = bytes / 16;
+    fill_kernel<<<stream_grid((int64_t)n16), kBlock, 0, stream>>>((uint4 *)dst, word, n16);
+}
+
 }  // namespace
 
 namespace {
@@ -383,8 +399,8 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col
 
     hipStream_t stream = (hipStream_t)hip_stream;
     int64_t *status = (int64_t *)workspace;
-    hipError_t e = hipMemsetAsync(status, 0, kStatusBytes, stream);
-    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(status)");
+    hipError_t e = hipSuccess;
+    device_fill(status, 0u, kStatusBytes, stream);
     if (n_walkers == 0) return TRW_OK;
 
     const Plan pl = make_plan(n_nodes, nnz, n_walkers, walk_length, uniform, mode);
@@ -414,8 +430,7 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col
     if (pl.narrow && pl.ext && uniform && mode == TRW_RNG_GLIBC)
         csr_ext_kernel<<<stream_grid(nnz), kBlock, 0, stream>>>(row32, col32, nnz, (u32x4_a16 *)(ws + pl.off_ext));
     if (pl.narrow && pl.hash && mode == TRW_RNG_WALKER) {
-        e = hipMemsetAsync(table, 0xFF, ((size_t)pl.hash_mask + 1) * 16, stream);
-        if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(edge table)");
+        device_fill(table, 0xFFFFFFFFu, ((size_t)pl.hash_mask + 1) * 16, stream);
         edge_table_build_kernel<<<stream_grid((nnz + 7) / 8), kBlock, 0, stream>>>(row32, col32, n_nodes, nnz, table,
                                                                                  pl.hash_mask, status);
         if (pl.ext)
@@ -560,8 +575,8 @@ int trw_walk_triples_hip(const int64_t *triples, int64_t n_triples, const int64_
 
     hipStream_t stream = (hipStream_t)hip_stream;
     int64_t *status = (int64_t *)workspace;
-    hipError_t e = hipMemsetAsync(status, 0, kStatusBytes, stream);
-    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(status)");
+    hipError_t e = hipSuccess;
+    device_fill(status, 0u, kStatusBytes, stream);
     if (n_walkers == 0) return TRW_OK;
 
     const TriplesPlan pl = make_triples_plan(n_triples, n_entities, n_walkers, walk_length, padding_idx, mode);
@@ -631,8 +646,8 @@ int trw_walk_edge_list_hip(const int64_t *edges, int64_t n_edges, const int64_t 
 
     hipStream_t stream = (hipStream_t)hip_stream;
     int64_t *status = (int64_t *)workspace;
-    hipError_t e = hipMemsetAsync(status, 0, kStatusBytes, stream);
-    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(status)");
+    hipError_t e = hipSuccess;
+    device_fill(status, 0u, kStatusBytes, stream);
     if (n_walkers == 0) return TRW_OK;
 
     const EdgeListPlan pl = make_elist_plan(n_edges, n_nodes, n_walkers, walk_length, padding_idx, mode, uniform);
@@ -662,8 +677,7 @@ int trw_walk_edge_list_hip(const int64_t *edges, int64_t n_edges, const int64_t 
             (u32x2_a8 *)(ws + pl.off_ix32), status);
         if (pl.hash && mode == TRW_RNG_WALKER) {
             el_table = (uint32_t *)(ws + pl.off_table);
-            e = hipMemsetAsync(el_table, 0xFF, ((size_t)pl.hash_mask + 1) * 16, stream);
-            if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(edge table)");
+            device_fill(el_table, 0xFFFFFFFFu, ((size_t)pl.hash_mask + 1) * 16, stream);
             elist_table_build_kernel<<<stream_grid(n_edges), kBlock, 0, stream>>>(
                 edges, n_edges, n_nodes, (const uint32_t *)(ws + pl.off_tail32),
                 (const u32x2_a8 *)(ws + pl.off_ix32), el_table, pl.hash_mask);
@@ -736,8 +750,8 @@ int trw_to_windows_hip(const int64_t *walks, int64_t num_walks, int64_t walk_col
         return rc;
     hipStream_t stream = (hipStream_t)hip_stream;
     int64_t *status = (int64_t *)workspace;
-    hipError_t e = hipMemsetAsync(status, 0, kStatusBytes, stream);
-    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(status)");
+    hipError_t e = hipSuccess;
+    device_fill(status, 0u, kStatusBytes, stream);
     const int64_t step_end = walk_cols - window_size + 1;
     const int64_t total_windows = num_walks * step_end;
     if (total_windows == 0) return TRW_OK;
@@ -791,8 +805,8 @@ int trw_to_windows_cbow_hip(const int64_t *walks, int64_t num_walks, int64_t wal
         return fail(TRW_E_RNG_MODE, "TRW_RNG_GLIBC replays one serial stream: window_base must be 0");
     hipStream_t stream = (hipStream_t)hip_stream;
     int64_t *status = (int64_t *)workspace;
-    hipError_t e = hipMemsetAsync(status, 0, kStatusBytes, stream);
-    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(status)");
+    hipError_t e = hipSuccess;
+    device_fill(status, 0u, kStatusBytes, stream);
     if (total_windows == 0) return TRW_OK;
     if (!pos_nodes || !neg_nodes || (window_size > 1 && !windows)) return fail(TRW_E_ARG, "output pointer is null");
 
@@ -869,8 +883,8 @@ int trw_to_windows_triples_hip(const int64_t *walks, int64_t num_walks, int64_t 
                                        workspace, workspace_bytes))
         return rc;
     hipStream_t stream = (hipStream_t)hip_stream;
-    hipError_t e = hipMemsetAsync(workspace, 0, kStatusBytes, stream);
-    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(status)");
+    hipError_t e = hipSuccess;
+    device_fill(workspace, 0u, kStatusBytes, stream);
     const int64_t per_walk = (walk_cols - 1) / 2;
     const int64_t total_windows = num_walks * per_walk;
     if (total_windows == 0) return TRW_OK;
@@ -921,8 +935,8 @@ int trw_to_windows_triples_cbow_hip(const int64_t *walks, int64_t num_walks, int
         return fail(TRW_E_RNG_MODE, "TRW_RNG_GLIBC replays one serial stream: window_base must be 0");
     hipStream_t stream = (hipStream_t)hip_stream;
     int64_t *status = (int64_t *)workspace;
-    hipError_t e = hipMemsetAsync(status, 0, kStatusBytes, stream);
-    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(status)");
+    hipError_t e = hipSuccess;
+    device_fill(status, 0u, kStatusBytes, stream);
     if (total_windows == 0) return TRW_OK;
     if (!pos_triples || !neg_triples || !pos_windows) return fail(TRW_E_ARG, "output pointer is null");
     prof_mark(0, stream);
