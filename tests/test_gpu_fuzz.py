@@ -1,6 +1,8 @@
 """Seeded fuzzing of the HIP paths against the oracle (pytest -m gpu): random small graphs with multi-edges,
 self-loops, hubs and dead ends; random p/q, walk lengths, batch sizes, walker bases, kernel variants.
 Every case is bit-exact or the test fails with the case's parameters in the message."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -9,6 +11,7 @@ from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+ROUNDS = int(os.environ.get("TRW_FUZZ_ROUNDS", "1"))   # a campaign: TRW_FUZZ_ROUNDS=40 pytest -m gpu tests/test_gpu_fuzz.py
 PQS = [(1.0, 1.0), (0.25, 4.0), (4.0, 0.25), (0.7, 0.5), (1.0, 2.0), (3.0, 1.0), (1.0, 1.0 + 1e-9), (0.01, 50.0)]
 
 
@@ -35,7 +38,7 @@ def _graph(rng, n, with_dead_ends):
     return row_ptr, dst.astype(np.int64), src.astype(np.int64)
 
 
-@pytest.mark.parametrize("case", range(24))
+@pytest.mark.parametrize("case", range(24 * ROUNDS))
 def test_fuzz_csr_walk(case, monkeypatch):
     from torch_rw import rw
     rng = np.random.default_rng(1000 + case)
@@ -66,7 +69,7 @@ def test_fuzz_csr_walk(case, monkeypatch):
         assert (got.cpu().numpy() == ref).all(), msg + " (serial replay)"
 
 
-@pytest.mark.parametrize("case", range(12))
+@pytest.mark.parametrize("case", range(12 * ROUNDS))
 def test_fuzz_edge_list_and_triples(case, monkeypatch):
     from torch_rw import rw, utils
     rng = np.random.default_rng(5000 + case)
