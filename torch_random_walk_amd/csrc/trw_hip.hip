@@ -303,11 +303,15 @@ EdgeListPlan make_elist_plan(int64_t n_edges, int64_t n_nodes, int64_t n_walkers
         off += align_up((size_t)n_edges * 4 + 64, 256);
         pl.off_ix32 = off;
         off += align_up((size_t)n_nodes * 8 + 64, 256);
-        if (!uniform) {  // same rule as the CSR walk: build the edge table when the batch will out-query the graph
+        if (!uniform) {
+            // Build the edge table unless the batch is tiny next to the graph: without it is_neighbor is the
+            // reference's linear scan of an unsorted edge range (hubs: on R-MAT 1M/10M, 80 steps, 16 walkers
+            // took 168 ms that way, 256 walkers 500 ms, 1024 walkers 635 ms; 5.6 ms with the table, which costs
+            // ~0.15 ns per edge), so the bar is far lower than the CSR walk's, whose fallback is a bisection.
             uint64_t cap = 1024;
             while (cap < 3 * (uint64_t)n_edges) cap <<= 1;
             const long forced = env_long("TRW_HASH", 0, 1, -1);
-            const bool worth = (__int128)n_walkers * L >= (__int128)n_edges / 4;
+            const bool worth = (__int128)n_walkers * L * 65536 >= (__int128)n_edges;
             if (cap <= ((uint64_t)1 << 31) && (forced == 1 || (forced == -1 && worth))) {
                 pl.hash = true;
                 pl.hash_mask = (uint32_t)(cap - 1);
