@@ -297,7 +297,8 @@ EdgeListPlan make_elist_plan(int64_t n_edges, int64_t n_nodes, int64_t n_walkers
     const bool fits = n_nodes < ((int64_t)1 << 31) && n_edges < ((int64_t)1 << 32) - 64 && padding_idx >= 0 &&
                       padding_idx < ((int64_t)1 << 31) && env_long("TRW_FORCE_WIDE", 0, 1, 0) == 0;
     // (L < 2^22: elist_walk_kernel addresses a wave's 64 rows with a 32-bit byte offset)
-    pl.narrow = fits && rng_mode != TRW_RNG_GLIBC && n_walkers > 0 && L >= 1 && L < (1 << 22);
+    // The serial replay of a biased walk wants the shadow too: the edge table is built from it.
+    pl.narrow = fits && (rng_mode != TRW_RNG_GLIBC || !uniform) && n_walkers > 0 && L >= 1 && L < (1 << 22);
     if (pl.narrow) {
         pl.off_tail32 = off;
         off += align_up((size_t)n_edges * 4 + 64, 256);
@@ -679,7 +680,7 @@ int trw_walk_edge_list_hip(const int64_t *edges, int64_t n_edges, const int64_t 
         elist_shadow_kernel<<<stream_grid(n_edges > n_nodes ? n_edges : n_nodes), kBlock, 0, stream>>>(
             edges, n_edges, node_edge_index, n_nodes, padding_idx, (uint32_t *)(ws + pl.off_tail32),
             (u32x2_a8 *)(ws + pl.off_ix32), status);
-        if (pl.hash && mode == TRW_RNG_WALKER) {
+        if (pl.hash) {
             el_table = (uint32_t *)(ws + pl.off_table);
             device_fill(el_table, 0xFFFFFFFFu, ((size_t)pl.hash_mask + 1) * 16, stream);
             elist_table_build_kernel<<<stream_grid(n_edges), kBlock, 0, stream>>>(
@@ -692,7 +693,7 @@ int trw_walk_edge_list_hip(const int64_t *edges, int64_t n_edges, const int64_t 
         SeedWindow sw;
         trw::seed_window(seed, sw.w);
         elist_glibc_seq_kernel<<<1, 64, 0, stream>>>(wide, targets, n_walkers, walk_length, padding_idx, restart,
-                                                    uniform ? 0 : 1, sw, bp, out, status);
+                                                    uniform ? 0 : 1, sw, bp, el_table, pl.hash_mask, out, status);
     } else if (pl.narrow) {
         if (uniform)
             elist_walk_kernel<false, true><<<walker_grid, kBlock, 0, stream>>>(
