@@ -513,6 +513,7 @@ biased_glibc_seq_kernel(const int64_t *__restrict__ row_ptr, const int64_t *__re
             st |= TRW_ST_NODE_RANGE;
             break;  // the chain's draw positions are undefined past a fault
         }
+        const uint32_t th_lo = th.t1 < th.t2 ? th.t1 : th.t2, th_hi = th.t1 < th.t2 ? th.t2 : th.t1;
         int64_t t = target, t_start, t_deg;
         load_row(row_ptr, t, nnz, t_start, t_deg, st);
         int64_t prev = pick_neighbor(t, t_start, t_deg, next(), col_idx, n_nodes, nnz, st);
@@ -529,6 +530,8 @@ biased_glibc_seq_kernel(const int64_t *__restrict__ row_ptr, const int64_t *__re
                 if (st) break;
                 bool accept;
                 if (x == t) accept = ru < th.t0;
+                else if (ru < th_lo) accept = true;    // below both thresholds: is_neighbor cannot change the answer
+                else if (ru >= th_hi) accept = false;  // above both
                 else accept = ru < (row_contains(col_idx, t_start, t_deg, x, sorted, n_probes, n_refscan) ? th.t1 : th.t2);
                 if (accept) break;
                 if (++rejected >= kTrialCap) {
