@@ -151,7 +151,8 @@ Plan make_plan(int64_t n_nodes, int64_t nnz, int64_t n_walkers, int32_t L, bool 
             // measured: 15.1 vs 22.6 ms on a 480 MB shadow (R-MAT 10M/110M), 1.14 vs 0.82 ms on a 4.8 MB one
             // (ER 100k/1.1M, cache resident): the compact shadow wins while it fits the caches
             const bool big = (size_t)(n_nodes + nnz) * 4 > ((size_t)32 << 20);  // the XCDs' aggregate L2
-            const bool worth = big && (__int128)n_walkers * L >= (__int128)nnz * 2;
+            // R-MAT 10M/110M, L=80: 1M walkers 3.1 ms compact / 3.2 ms fat, 2.75M walkers 7.6 / 6.1, 10M 26.5 / 18.1
+            const bool worth = big && (__int128)n_walkers * L >= (__int128)nnz;
             if (forced == 1 || (forced == -1 && worth)) {
                 pl.ext = true;
                 pl.off_ext = off;
