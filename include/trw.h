@@ -15,7 +15,9 @@
  * kernels; TRW_NO_POS=1 disable the located-t shortcut of the biased kernel;
  * TRW_HASH=0/1, TRW_EXT=0/1 force the edge table / the fat entries off or on;
  * TRW_HASH_SLACK=k table slots per edge (default 3); TRW_RESIDENT_BLOCKS=k
- * workgroups per CU of the persistent biased kernel (default 5).
+ * workgroups per CU of the persistent biased kernel (default 5);
+ * TRW_COMMON_MAX=k longest row for which "shares no node with the neighbour's
+ * row" is worked out per edge (default 8, 0 = off).
  * None of them changes a result.
  */
 #ifndef TRW_H

@@ -443,7 +443,8 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col
                                                                                  pl.hash_mask, status);
         if (pl.ext)
             csr_ext_rpos_kernel<<<stream_grid((nnz + 7) / 8), kBlock, 0, stream>>>(
-                row32, col32, n_nodes, nnz, table, pl.hash_mask, (u32x4_a16 *)(ws + pl.off_ext));
+                row32, col32, n_nodes, nnz, table, pl.hash_mask, (uint32_t)env_long("TRW_COMMON_MAX", 0, 4096, 8),
+                (u32x4_a16 *)(ws + pl.off_ext));
     }
     const unsigned lane_grid = (unsigned)((pl.nlanes + kBlock - 1) / kBlock);
     if (uniform && mode == TRW_RNG_GLIBC) {

@@ -632,11 +632,35 @@ edge_table_build_kernel(const uint32_t *__restrict__ row32, const uint32_t *__re
 // prev's row") -- so that step skips its table probe.  rpos = (multiplicity << 28) | first offset when
 // both fit (multiplicity <= 15, offset < 2^28), 0 = u is not in v's row, 1 = look it up in the table.
 // One thread per 8 consecutive entries, as edge_table_build_kernel; one table probe per entry.
+//
+// The top bit of the deg field (kNoCommon; rows have fewer than 2^31 entries) says that the rows of u and v
+// share NO node.  A walker that took u -> v then stands on prev = v with t = u, and every candidate x != t
+// it draws from v's row is known not to be in t's row: the rejection trials that would ask is_neighbor
+// (draw in [lo, hi)) are decided without loading the candidate or probing the table.  On R-MAT 10M/110M
+// 58 % of the visited (t, prev) pairs are like that (scripts/triangle_stats.py); the flag is worked out
+// only where u's row has at most `common_max` entries (that many probes at most, early exit).  Measured
+// there with common_max = 8 (TRW_COMMON_MAX): candidate loads 3.82 -> 3.01 and membership tests 2.86 -> 2.05
+// per step, walk kernel 136 -> 129 ms for 1.6 ms more in this pass; 64 takes the kernel to 125 ms but costs
+// 24 ms here.
 constexpr uint32_t kRposAbsent = 0u, kRposLookup = 1u;
+constexpr uint32_t kNoCommon = 0x80000000u;
+
+// is (a -> b) an edge?  (one probe chain of the edge table)
+__device__ __forceinline__ bool edge_table_has(const uint32_t *__restrict__ table, uint32_t mask, uint32_t a, uint32_t b)
+{
+    uint32_t slot = edge_hash(a, b) & mask;
+    while (true) {
+        const u32x2_a4 g = *reinterpret_cast<const u32x2_a4 *>(table + 4 * (size_t)slot);
+        if (g.x == 0xFFFFFFFFu) return false;
+        if (g.x == a && g.y == b) return true;
+        slot = (slot + 1) & mask;
+    }
+}
 
 __global__ void __launch_bounds__(kBlock)
 csr_ext_rpos_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32, int64_t n_nodes,
-                    int64_t nnz, const uint32_t *__restrict__ table, uint32_t mask, u32x4_a16 *__restrict__ ext)
+                    int64_t nnz, const uint32_t *__restrict__ table, uint32_t mask, uint32_t common_max,
+                    u32x4_a16 *__restrict__ ext)
 {
     constexpr int kPer = 8;
     const int64_t chunks = (nnz + kPer - 1) / kPer;
@@ -653,11 +677,15 @@ csr_ext_rpos_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restri
                 n = half;
             }
         }
-        uint32_t row_hi = row32[u + 1];
+        uint32_t row_lo = row32[u], row_hi = row32[u + 1];
         for (int k = 0; k < kPer; ++k) {
             const uint32_t e = e0 + k;
             if (e >= (uint32_t)nnz) break;
-            while (e >= row_hi && u + 1 < (uint32_t)n_nodes) row_hi = row32[++u + 1];
+            while (e >= row_hi && u + 1 < (uint32_t)n_nodes) {
+                ++u;
+                row_lo = row_hi;
+                row_hi = row32[u + 1];
+            }
             const uint32_t v = col32[e];
             uint32_t start, deg;
             load_row32(row32, v, start, deg);
@@ -673,7 +701,20 @@ csr_ext_rpos_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restri
                 }
                 slot = (slot + 1) & mask;
             }
-            u32x4_a16 o = {v, start, deg, rpos};
+            // Do the rows of u and v share a node?  Asked only where u's row is short (walk it, probe v's row):
+            // that is the cheap side to ask from (u's row is this thread's own stretch of col32) and the one that
+            // pays -- a short row of v means few distinct candidates and probes, which the caches absorb anyway.
+            uint32_t flag = 0u;
+            const uint32_t deg_u = row_hi - row_lo;
+            if (deg_u <= common_max && deg < kNoCommon) {
+                flag = kNoCommon;
+                for (uint32_t i = 0; i < deg_u; ++i)
+                    if (edge_table_has(table, mask, v, col32[row_lo + i])) {
+                        flag = 0u;
+                        break;
+                    }
+            }
+            u32x4_a16 o = {v, start, deg | flag, rpos};
             ext[e] = o;
         }
     }
@@ -731,6 +772,7 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
     uint32_t d_cons = 0, d_prod = 0;  // draws consumed / produced for the current walker
     uint32_t slot = 0, ku = 0, kv = 0, ru = 0, rejected = 0;
     uint32_t c_start = 0, c_deg = 0, c_rpos = kRposLookup;  // the candidate's row and where prev sits in it (fat entries)
+    bool no_common = false;  // rows of t and prev share no node (kNoCommon of the entry the walker came through)
     const uint32_t *addr = row32;
     RowCombiner row = {out, 0u, 0u, 0u, 0u};  // the caller's int64 row, four columns per store
 
@@ -837,7 +879,7 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
         } else if (state == LS_CAND) {  // g.x = the candidate node (g.y, g.z = its row when fat)
             cand = g.x;
             c_start = g.y;
-            c_deg = g.z;
+            c_deg = g.z;  // fat entries: kNoCommon rides in the top bit, taken off where the row is adopted
             c_rpos = g.w;
             if (s == 1) {
                 ev_accept = true;
@@ -875,11 +917,18 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
             d_cons += 2;
             if (kCount) ++n_trials;
             const uint32_t idx = fm.mod(rc);
-            if (use_pos && ru >= bp.hi) {
-                // no candidate but t itself can pass this draw; t sits at offsets [pos_lo, pos_lo+pos_cnt)
-                if (ru < bp.t0 && idx - pos_lo < pos_cnt) {
+            if (use_pos && (ru >= bp.hi || (no_common && ru >= bp.lo))) {
+                // What the candidate is does not matter beyond "is it t" -- t sits at offsets
+                // [pos_lo, pos_lo+pos_cnt) -- because is_neighbor cannot change the answer: the draw is above
+                // both thresholds, or t's row and prev's share no node, so every other candidate is a non-neighbour.
+                const bool at_t = idx - pos_lo < pos_cnt;
+                if (at_t && ru < bp.t0) {
                     cand = t;
                     ev_accept = ev_known = true;
+                } else if (!at_t && ru < bp.t2) {  // a non-neighbour passes (t2 > t1 only): fetch it, it is accepted
+                    addr = cand_base + ((size_t)(p_start + idx) << cand_shift);
+                    ru = 0;
+                    state = LS_CAND;
                 } else if (++rejected >= kTrialCap) {
                     st |= (uint32_t)kStTrialCap;
                     addr = cand_base + ((size_t)(p_start + idx) << cand_shift);  // take whatever this trial drew
@@ -922,9 +971,11 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                 t_start = p_start;
                 t_deg = p_deg;
                 prev = cand;
-                if (fat && c_deg != 0 && !(st & TRW_ST_DEGREE0)) {  // the candidate brought its row along
+                no_common = false;
+                if (fat && (c_deg & ~kNoCommon) != 0 && !(st & TRW_ST_DEGREE0)) {  // the candidate brought its row along
                     p_start = c_start;
-                    p_deg = c_deg;
+                    p_deg = c_deg & ~kNoCommon;
+                    no_common = (c_deg & kNoCommon) != 0;
                     fm.init(p_deg);
                     if (use_pos && c_rpos == kRposLookup) {
                         ku = prev;
