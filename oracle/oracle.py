@@ -44,7 +44,8 @@ def build(force=False):
             and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
         return _LIB_PATH
     subprocess.check_call(
-        ["gcc", "-O2", "-fPIC", "-Wall", "-Wextra", "-std=c11", "-shared", "-o", _LIB_PATH, src, "-lm"],
+        # same flags as oracle/Makefile (gnu11 + pthread: the multi-threaded timing leg uses pthreads/clock_gettime)
+        ["gcc", "-O2", "-fPIC", "-Wall", "-Wextra", "-std=gnu11", "-pthread", "-shared", "-o", _LIB_PATH, src, "-lm"],
         cwd=_HERE)
     return _LIB_PATH
 
