@@ -482,3 +482,37 @@ def test_walk_is_graph_capturable(rw):
         g.replay()
         torch.cuda.synchronize()
         assert (wb.cpu().numpy() == ref_b).all() and (wu.cpu().numpy() == ref_u).all()
+
+
+def test_concurrent_calls_from_two_threads(rw):
+    """The library keeps no per-call state outside the caller's workspace: two host threads walking on their
+    own streams at the same time (biased + uniform, table + fat paths) get what they would get alone."""
+    import threading
+    rp, ci = hub_graph(3000, 7)
+    d_rp, d_ci = _dev(rp, ci)
+    jobs = []
+    for k, (p, q, N) in enumerate(((0.25, 4.0, 30_000), (1.0, 1.0, 50_000), (4.0, 0.25, 20_000), (1.0, 1.0, 777))):
+        tg = np.random.default_rng(k).integers(0, 3000, N)
+        mode, omode = (rw.RNG_GLIBC, O.RNG_GLIBC_SEQ) if p == 1.0 else (rw.RNG_WALKER, O.RNG_WALKER)
+        jobs.append((p, q, tg, torch.as_tensor(tg).to(DEV), mode, O.walk(rp, ci, tg, p, q, 25, 3 + k, rng_mode=omode), 3 + k))
+    rw.walk_ex(d_rp, d_ci, jobs[1][3][:4], 1.0, 1.0, 25, 1)        # jump table upload happens once, up front
+    errors = []
+
+    def worker(which):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for rep in range(6):
+                    p, q, tg, d_tg, mode, ref, seed = jobs[(which + rep) % len(jobs)]
+                    got = rw.walk_ex(d_rp, d_ci, d_tg, p, q, 25, seed, rng_mode=mode)
+                    if not (got.cpu().numpy() == ref).all():
+                        errors.append("thread %d rep %d differs" % (which, rep))
+        except Exception as e:      # noqa: BLE001
+            errors.append("thread %d: %r" % (which, e))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
