@@ -720,7 +720,7 @@ csr_ext_rpos_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restri
     }
 }
 
-enum : uint32_t { LS_IDLE = 0, LS_START, LS_ROW, LS_POS, LS_TRIAL, LS_CAND, LS_MEMBER };
+enum : uint32_t { LS_IDLE = 0, LS_START, LS_ROW, LS_POS, LS_TRIAL, LS_CAND, LS_MEMBER, LS_ACCEPT };
 
 constexpr int kRing = 16;  // draws buffered per lane in LDS (4 Philox blocks)
 // Rejection trials a lane may run back to back in one iteration while they need no memory.  The body of
@@ -730,6 +730,17 @@ constexpr int kRing = 16;  // draws buffered per lane in LDS (4 Philox blocks)
 #define TRW_TRIALS_PER_ITER 4
 #endif
 constexpr int kTrialsPerIter = TRW_TRIALS_PER_ITER;
+// A state's block (probe, candidate, trials, accept) is skipped while fewer than TRW_VOTE lanes of the wave are
+// waiting for it; every (TRW_VOTE_TICK+1)-th iteration runs everything.  Each pass through a block then serves
+// more lanes: the wave executes the union of its lanes' blocks, and instruction issue -- not memory -- is what
+// this kernel runs out of (measured on R-MAT 10M/110M: 128.7 ms with 0, 123-124 ms for 8..16 lanes and a tick
+// of 4..16, 128.8 ms again at 32).  Same walks either way: a lane's state only waits.
+#ifndef TRW_VOTE
+#define TRW_VOTE 12
+#endif
+#ifndef TRW_VOTE_TICK
+#define TRW_VOTE_TICK 7
+#endif
 
 template <bool kCount>
 __global__ void __launch_bounds__(kBlock)
@@ -774,6 +785,10 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
     uint32_t c_start = 0, c_deg = 0, c_rpos = kRposLookup;  // the candidate's row and where prev sits in it (fat entries)
     bool no_common = false;  // rows of t and prev share no node (kNoCommon of the entry the walker came through)
     const uint32_t *addr = row32;
+    u32x4_a4 g = {0u, 0u, 0u, 0u};  // the lane's gather: issued when it enters a gather state, consumed by that state's block
+    bool fresh = false;             // a gather state was entered (or its probe moved on): issue the load
+    uint32_t acc_cand = 0, iter = 0;
+    bool acc_known = false;
     RowCombiner row = {out, 0u, 0u, 0u, 0u};  // the caller's int64 row, four columns per store
 
     while (true) {
@@ -808,6 +823,7 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                         prev = (uint32_t)tg;  // step 1 leaves the start node
                         t = prev;
                         addr = row32 + prev;
+                        fresh = true;
                         state = LS_ROW;
                     }
                 }
@@ -816,9 +832,24 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
         if (__ballot(state != LS_IDLE) == 0) break;
 
         // ---- the one gather of this iteration ----
-        u32x4_a4 g = {0u, 0u, 0u, 0u};
-        if (state == LS_ROW || state == LS_POS || state == LS_CAND || state == LS_MEMBER)
+        if (fresh) {
             g = *reinterpret_cast<const u32x4_a4 *>(addr);
+            fresh = false;
+        }
+        // which blocks run this time
+        bool run_probe = true, run_cand = true, run_trial = true, run_acc = true;
+        if (TRW_VOTE > 0) {
+            const int n_probe = __popcll(__ballot(state == LS_POS || state == LS_MEMBER));
+            const int n_cand = __popcll(__ballot(state == LS_CAND));
+            const int n_trial = __popcll(__ballot(state == LS_TRIAL));
+            const int n_acc = __popcll(__ballot(state == LS_ACCEPT));
+            const bool tick = (iter++ & (uint32_t)TRW_VOTE_TICK) == 0u;
+            run_probe = tick || n_probe >= TRW_VOTE;
+            run_cand = tick || n_cand >= TRW_VOTE;
+            run_trial = tick || n_trial >= TRW_VOTE;
+            run_acc = tick || n_acc >= TRW_VOTE;
+            if (!(run_probe || run_cand || run_trial || run_acc)) run_probe = run_cand = run_trial = run_acc = true;
+        }
 
         // ---- top up the draw rings when some lane is about to run dry ----
         const bool live = state != LS_IDLE && state != LS_START;
@@ -848,6 +879,7 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                 const uint32_t r0 = my_ring[0] >> 1;
                 d_cons = 1;
                 addr = cand_base + ((size_t)(p_start + r0 % p_deg) << cand_shift);
+                fresh = true;
                 ru = 0;
                 state = LS_CAND;
             } else {
@@ -860,13 +892,14 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                     state = LS_TRIAL;
                 }
             }
-        } else if (state == LS_POS || state == LS_MEMBER) {  // g = {u, v, lo, cnt-1} of one slot
+        } else if (run_probe && (state == LS_POS || state == LS_MEMBER)) {  // g = {u, v, lo, cnt-1} of one slot
             if (kCount) ++n_probes;
             const bool empty = g.x == 0xFFFFFFFFu;
             const bool match = g.x == ku && g.y == kv;
             if (!empty && !match) {
                 slot = (slot + 1) & mask;
                 addr = table + 4 * (size_t)slot;
+                fresh = true;
             } else if (state == LS_POS) {  // where t sits in prev's row
                 pos_lo = match ? g.z : 0u;
                 pos_cnt = match ? g.w + 1u : 0u;
@@ -876,7 +909,7 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                 if (ru < (match ? bp.t1 : bp.t2)) ev_accept = true;
                 else ev_reject = true;
             }
-        } else if (state == LS_CAND) {  // g.x = the candidate node (g.y, g.z = its row when fat)
+        } else if (run_cand && state == LS_CAND) {  // g.x = the candidate node (g.y, g.z = its row when fat)
             cand = g.x;
             c_start = g.y;
             c_deg = g.z;  // fat entries: kNoCommon rides in the top bit, taken off where the row is adopted
@@ -911,7 +944,7 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
         }
 
         // ---- one rejection trial for every lane that is between gathers ----
-        for (int rep = 0; rep < kTrialsPerIter && state == LS_TRIAL && !ev_accept && d_prod - d_cons >= 2u; ++rep) {
+        for (int rep = 0; run_trial && rep < kTrialsPerIter && state == LS_TRIAL && !ev_accept && d_prod - d_cons >= 2u; ++rep) {
             const uint32_t rc = my_ring[(d_cons & (kRing - 1)) * kBlock] >> 1;
             ru = my_ring[((d_cons + 1) & (kRing - 1)) * kBlock] >> 1;
             d_cons += 2;
@@ -927,22 +960,35 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                     ev_accept = ev_known = true;
                 } else if (!at_t && ru < bp.t2) {  // a non-neighbour passes (t2 > t1 only): fetch it, it is accepted
                     addr = cand_base + ((size_t)(p_start + idx) << cand_shift);
+                    fresh = true;
                     ru = 0;
                     state = LS_CAND;
                 } else if (++rejected >= kTrialCap) {
                     st |= (uint32_t)kStTrialCap;
                     addr = cand_base + ((size_t)(p_start + idx) << cand_shift);  // take whatever this trial drew
+                    fresh = true;
                     ru = 0;
                     rejected = 0;
                     state = LS_CAND;
                 }
             } else {
                 addr = cand_base + ((size_t)(p_start + idx) << cand_shift);
+                fresh = true;
                 state = LS_CAND;
             }
         }
 
         // ---- emit an accepted candidate and move to the next step ----
+        if (TRW_VOTE > 0) {  // accepts wait for company too
+            if (ev_accept) {
+                state = LS_ACCEPT;
+                acc_cand = cand;
+                acc_known = ev_known;
+            }
+            ev_accept = run_acc && state == LS_ACCEPT;
+            cand = acc_cand;
+            ev_known = acc_known;
+        }
         if (ev_accept) {
             row.emit(cand, s, L);
             ++s;
@@ -989,6 +1035,7 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                     }
                 } else {
                     addr = row32 + prev;
+                    fresh = true;
                     state = LS_ROW;
                 }
             }
@@ -998,6 +1045,7 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
         if (ev_probe) {
             slot = edge_hash(ku, kv) & mask;
             addr = table + 4 * (size_t)slot;
+            fresh = true;
             state = probe_state;
         }
     }
