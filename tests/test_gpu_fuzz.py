@@ -109,3 +109,40 @@ def test_fuzz_edge_list_and_triples(case, monkeypatch):
     got = rw.walk_triples_ex(tsorted.to(DEV), tindex.to(DEV), torch.as_tensor(tgk).to(DEV), L, kpad, seed,
                              walker_base=9, rng_mode=rw.RNG_WALKER)
     assert (got.cpu().numpy() == ref).all(), msg + " (triples)"
+
+
+@pytest.mark.parametrize("case", range(8 * ROUNDS))
+def test_fuzz_windows(case):
+    """All four window builders on random shapes, against the oracle (glibc stream for the fixed-count
+    negatives, both modes for the redrawn ones; shards by walk/window base)."""
+    from torch_rw import rw
+    rng = np.random.default_rng(9000 + case)
+    cols = int(rng.integers(1, 60))
+    ws = int(rng.integers(1, cols + 1))
+    num_walks = int(rng.integers(1, 400))
+    num_nodes = int(rng.choice([1, 2, 7, 1000, 10**6, 2**33]))
+    seed = int(rng.integers(-2**31, 2**31))
+    walks = rng.integers(0, min(num_nodes, 10**6), (num_walks, cols))
+    d_w = torch.as_tensor(walks).to(DEV)
+    msg = "case %d cols=%d ws=%d walks=%d nodes=%d seed=%d" % (case, cols, ws, num_walks, num_nodes, seed)
+    t, p, n = O.to_windows(walks, ws, num_nodes, seed)
+    gt, gp, gn = rw.to_windows(d_w, ws, num_nodes, seed)
+    assert (gt.cpu().numpy() == t).all() and (gp.cpu().numpy() == p).all() and (gn.cpu().numpy() == n).all(), msg
+    cut = int(rng.integers(0, num_walks))
+    steps = cols - ws + 1
+    st, sp, sn = rw.to_windows_ex(d_w[cut:], ws, num_nodes, seed, walk_base=cut)
+    assert (sn.cpu().numpy() == n[cut * steps:]).all() and (sp.cpu().numpy() == p[cut * steps:]).all(), msg + " (shard)"
+    if ws >= 2:
+        pn, nn, w = O.to_windows_cbow(walks, ws, num_nodes, seed, rng_mode=O.RNG_WALKER, window_base=5)
+        gpn, gnn, gw = rw.to_windows_cbow_ex(d_w, ws, num_nodes, seed, window_base=5, rng_mode=rw.RNG_WALKER)
+        assert (gpn.cpu().numpy() == pn).all() and (gnn.cpu().numpy() == nn).all() and (gw.cpu().numpy() == w).all(), msg + " (cbow)"
+    # triples windows over the same matrix read as a triples walk (odd width), random pool
+    tcols = cols if cols % 2 == 1 else cols - 1
+    if tcols >= 3:
+        tws = int(rng.integers(1, 6))
+        pool = rng.integers(0, 50, (int(rng.integers(1, 40)), 3))
+        tw = walks[:, :tcols] % 50
+        tt, tp, tn = O.to_windows_triples(tw, tws, 50, -1, pool, seed)
+        g = rw.to_windows_triples(torch.as_tensor(tw).to(DEV), tws, 50, -1, torch.as_tensor(pool).to(DEV), seed)
+        assert (g[0].cpu().numpy() == tt).all() and (g[1].cpu().numpy() == tp).all() and (g[2].cpu().numpy() == tn).all(), \
+            msg + " (triples tws=%d pool=%d)" % (tws, len(pool))
