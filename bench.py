@@ -182,10 +182,15 @@ def main():
     mode = rw.RNG_WALKER if (kg or elist or not uniform) else rw.RNG_GLIBC
     gather = (world > 1) and not args.no_gather
     full = None
+    fulls, step_no = [], [0]
+    # the CSR walk can write straight into the root's slice of the gathered result (walk_ex(out=...)); two result
+    # buffers alternate because the gather of step k is still landing while step k+1 walks
+    direct_root = gather and rank == 0 and not (windows or elist or kg)
     if gather and rank == 0:
         if windows:
             cols = (L + 1 - cfg["window_size"] + 1) * (cfg["window_size"] - 1)
-        full = torch.empty((world * B, cols), dtype=torch.int64, device="cpu" if dry else dev)
+        fulls = [torch.empty((world * B, cols), dtype=torch.int64, device=dev) for _ in range(2 if direct_root else 1)]
+        full = fulls[0]
 
     def walk(tg, base, check):
         if windows:   # "walkers" are walks here; the result the bench tracks is the negatives tensor
@@ -201,28 +206,45 @@ def main():
         return rw.walk_ex(row_ptr, col_idx, tg, p, q, L, args.seed, walker_base=base, rng_mode=mode, check=check)
 
     def walk_once():
+        if direct_root:
+            dst = fulls[step_no[0] % 2]
+            return rw.walk_ex(row_ptr, col_idx, targets, p, q, L, args.seed, walker_base=walker_base, rng_mode=mode,
+                              check=False, out=dst[:B])
         return walk(targets, walker_base, False)
 
     class _Pending:
-        def __init__(self, works, keep):
-            self.works, self.keep = works, keep
+        def __init__(self, works, keep, after=None):
+            self.works, self.keep, self.after = works, keep, after
 
         def wait(self):
             for w in self.works:
                 w.wait()
+            if self.after is not None:   # gloo dry run: the blocks came through host memory
+                self.after()
+                self.after = None
 
     def gather_async(walks):
         """The one collective of the path: every rank's [B, cols] block lands in its slice of rank 0's
         buffer.  Issued as one RCCL group of point-to-point transfers (what a gather is on xGMI: each
         peer -> root pair rides its own link), straight into the destination slices -- no staging copy."""
-        if dry:
-            walks = walks.cpu()
+        nonlocal full
+        after = None
         if rank == 0:
-            full[:B].copy_(walks, non_blocking=True)
-            ops = [dist.P2POp(dist.irecv, full[r * B:(r + 1) * B], r) for r in range(1, world)]
+            full = fulls[step_no[0] % 2] if direct_root else fulls[0]
+            step_no[0] += 1
+            if not direct_root:
+                full[:B].copy_(walks, non_blocking=True)
+            dst = full
+            if dry:   # gloo moves host memory: receive there, copy in when the transfers are done
+                dst = torch.empty((world * B, full.shape[1]), dtype=torch.int64)
+                tgt = full
+
+                def after(dst=dst, tgt=tgt):
+                    tgt[B:].copy_(dst[B:])
+            ops = [dist.P2POp(dist.irecv, dst[r * B:(r + 1) * B], r) for r in range(1, world)]
         else:
-            ops = [dist.P2POp(dist.isend, walks, 0)]
-        return _Pending(dist.batch_isend_irecv(ops) if ops else [], walks)
+            ops = [dist.P2POp(dist.isend, walks.cpu() if dry else walks, 0)]
+        return _Pending(dist.batch_isend_irecv(ops) if ops else [], walks, after)
 
     for _ in range(args.warmup):
         walks = walk_once()

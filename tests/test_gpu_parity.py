@@ -516,3 +516,20 @@ def test_concurrent_calls_from_two_threads(rw):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_walk_into_a_callers_tensor(rw):
+    """walk_ex(out=...): a shard walks straight into its slice of the gathered result."""
+    rp, ci = hub_graph(500, 5)
+    tg = np.random.default_rng(3).integers(0, 500, 3000)
+    d_rp, d_ci, d_tg = _dev(rp, ci, tg)
+    for p, q, mode, omode in ((1.0, 1.0, rw.RNG_GLIBC, O.RNG_GLIBC_INDEXED), (0.25, 4.0, rw.RNG_WALKER, O.RNG_WALKER)):
+        full = torch.full((3000, 21), -1, dtype=torch.int64, device=DEV)
+        a = rw.walk_ex(d_rp, d_ci, d_tg[:1000], p, q, 20, 10, walker_base=0, rng_mode=mode, out=full[:1000])
+        b = rw.walk_ex(d_rp, d_ci, d_tg[1000:], p, q, 20, 10, walker_base=1000, rng_mode=mode, out=full[1000:])
+        assert a.data_ptr() == full.data_ptr() and b.data_ptr() == full[1000:].data_ptr()
+        assert (full.cpu().numpy() == O.walk(rp, ci, tg, p, q, 20, 10, rng_mode=omode)).all()
+    with pytest.raises(RuntimeError, match="out must be"):
+        rw.walk_ex(d_rp, d_ci, d_tg, 1.0, 1.0, 20, 10, out=torch.empty((3000, 20), dtype=torch.int64, device=DEV))
+    with pytest.raises(RuntimeError, match="out must be"):
+        rw.walk_ex(d_rp, d_ci, d_tg, 1.0, 1.0, 20, 10, out=torch.empty((3000, 42), dtype=torch.int64, device=DEV)[:, ::2])

@@ -47,10 +47,12 @@ std::string status_text(int64_t bits)
     return s;
 }
 
-// walk_ex: the reference's seven arguments plus the two this library adds.
+// walk_ex: the reference's seven arguments plus what this library adds (global walker base, RNG mode,
+// status check, and an optional destination: a contiguous int64 [N, L+1] tensor to walk into -- e.g. a
+// shard's slice of the gathered result).
 torch::Tensor walk_ex(const torch::Tensor &row_ptr, const torch::Tensor &col_idx, const torch::Tensor &target_nodes,
                       double p, double q, int64_t walk_length, int64_t seed, int64_t walker_base, int64_t rng_mode,
-                      bool check)
+                      bool check, const c10::optional<torch::Tensor> &out)
 {
     check_index_tensor(row_ptr, "row_ptr");
     check_index_tensor(col_idx, "col_idx");
@@ -73,8 +75,16 @@ torch::Tensor walk_ex(const torch::Tensor &row_ptr, const torch::Tensor &col_idx
     const int64_t nnz = ci.numel();
     const int64_t n_walkers = tg.numel();
 
-    // rw_cuda.cu:201-203: a fresh [N, L+1] int64 tensor on the inputs' device
-    auto walks = torch::empty({n_walkers, walk_length + 1}, rp.options());
+    // rw_cuda.cu:201-203: a fresh [N, L+1] int64 tensor on the inputs' device, unless the caller brought one
+    torch::Tensor walks;
+    if (out.has_value() && out->defined()) {
+        walks = *out;
+        TORCH_CHECK(walks.scalar_type() == torch::kInt64 && walks.device() == rp.device() && walks.is_contiguous() &&
+                        walks.dim() == 2 && walks.size(0) == n_walkers && walks.size(1) == walk_length + 1,
+                    "out must be a contiguous int64 [len(target_nodes), walk_length + 1] tensor on the inputs' device");
+    } else {
+        walks = torch::empty({n_walkers, walk_length + 1}, rp.options());
+    }
 
     const size_t ws_bytes =
         trw_walk_csr_workspace_bytes(n_nodes, nnz, n_walkers, (int32_t)walk_length, p, q, (int32_t)rng_mode);
@@ -105,7 +115,8 @@ torch::Tensor walk_ex(const torch::Tensor &row_ptr, const torch::Tensor &col_idx
 torch::Tensor walk(const torch::Tensor &row_ptr, const torch::Tensor &column_idx, const torch::Tensor &target_nodes,
                    const double p, const double q, const int walk_length, const int seed)
 {
-    return walk_ex(row_ptr, column_idx, target_nodes, p, q, walk_length, seed, 0, g_rng_mode.load(), g_check.load());
+    return walk_ex(row_ptr, column_idx, target_nodes, p, q, walk_length, seed, 0, g_rng_mode.load(), g_check.load(),
+                   c10::nullopt);
 }
 
 // walk_triples: reference dispatcher csrc/rw_init.cpp:47-75, same argument order.
@@ -364,7 +375,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("walk_ex", &walk_ex, "walk with an explicit global walker base, RNG mode and status check",
           pybind11::arg("row_ptr"), pybind11::arg("col_idx"), pybind11::arg("target_nodes"), pybind11::arg("p"),
           pybind11::arg("q"), pybind11::arg("walk_length"), pybind11::arg("seed"), pybind11::arg("walker_base") = 0,
-          pybind11::arg("rng_mode") = (int64_t)TRW_RNG_AUTO, pybind11::arg("check") = true);
+          pybind11::arg("rng_mode") = (int64_t)TRW_RNG_AUTO, pybind11::arg("check") = true,
+          pybind11::arg("out") = pybind11::none());
     m.def("to_windows", &to_windows, "to_windows", pybind11::arg("walks"), pybind11::arg("window_size"),
           pybind11::arg("num_nodes"), pybind11::arg("seed"));
     m.def("to_windows_cbow", &to_windows_cbow, "to_windows", pybind11::arg("walks"), pybind11::arg("window_size"),

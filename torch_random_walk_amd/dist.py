@@ -39,10 +39,17 @@ def walk_sharded(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, group=
     if rng_mode is None:
         rng_mode = rw.RNG_GLIBC if (p == 1.0 and q == 1.0) else rw.RNG_WALKER
     fn = walk_fn or rw.walk_ex
-    mine = fn(row_ptr, col_idx, target_nodes[lo:hi], p, q, walk_length, seed, walker_base=lo, rng_mode=rng_mode)
+    cols = walk_length + 1
+    full = None
+    if world > 1 and gather == "root" and rank == 0 and walk_fn is None:
+        # the root walks straight into its slice of the result: no copy of its own block
+        full = torch.empty((world * block, cols), dtype=torch.int64, device=target_nodes.device)
+        mine = fn(row_ptr, col_idx, target_nodes[lo:hi], p, q, walk_length, seed, walker_base=lo, rng_mode=rng_mode,
+                  out=full[lo:hi])
+    else:
+        mine = fn(row_ptr, col_idx, target_nodes[lo:hi], p, q, walk_length, seed, walker_base=lo, rng_mode=rng_mode)
     if world == 1 or gather == "none":
         return mine
-    cols = walk_length + 1
     padded = mine
     if hi - lo < block:  # equal-sized pieces for the collective; the pad rows are dropped below
         padded = torch.zeros((block, cols), dtype=mine.dtype, device=mine.device)
@@ -55,8 +62,9 @@ def walk_sharded(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, group=
         # a gather on xGMI is world-1 independent peer -> root transfers; issued as one group of
         # point-to-point operations they land directly in the root's result, no staging copy
         if rank == 0:
-            full = torch.empty((world * block, cols), dtype=mine.dtype, device=mine.device)
-            full[: hi - lo] = mine
+            if full is None:
+                full = torch.empty((world * block, cols), dtype=mine.dtype, device=mine.device)
+                full[: hi - lo] = mine
             ops = []
             for r in range(1, world):
                 r_lo, r_hi, _ = shard_bounds(n, world, r)

@@ -19,14 +19,16 @@ def walk(row_ptr, col_idx, target_nodes, p, q, walk_length, seed):
 
 
 def walk_ex(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, walker_base=0, rng_mode=RNG_AUTO,
-            check=True):
+            check=True, out=None):
     """``walk`` with an explicit global index for ``target_nodes[0]`` and RNG mode.
 
     A shard that passes the global offset of its slice reproduces exactly the rows
-    the unsharded call would have produced (include/trw.h, TRW_RNG_*).
+    the unsharded call would have produced (include/trw.h, TRW_RNG_*).  ``out``: a contiguous
+    int64 ``[len(target_nodes), walk_length + 1]`` tensor to walk into (e.g. the shard's slice of
+    the gathered result) instead of a fresh one.
     """
     return torch_rw_native.walk_ex(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, walker_base,
-                                   rng_mode, check)
+                                   rng_mode, check, out)
 
 
 def set_rng_mode(mode):
