@@ -49,6 +49,8 @@ WORKLOADS = {
     # nodes (at 8 GPUs: the whole graph once), CSR replicated
     "papers100m_uniform": dict(graph="rmat", nodes=111_000_000, edges=1_600_000_000, p=1.0, q=1.0, walks_per_node=1,
                                shard_of=8),
+    # the same graph with ALL its start nodes on one GPU (72 GB of walks next to the 14 GB graph): what 288 GB allows
+    "papers100m_full": dict(graph="rmat", nodes=111_000_000, edges=1_600_000_000, p=1.0, q=1.0, walks_per_node=1),
     # BASELINE configs[4]: knowledge-graph triples path (the reference's triples walk is uniform only,
     # torch_rw/rw.py:18 / rw_cpu_triples.cpp:105-127 -- there is no biased triples walk to reproduce)
     "kg5m_triples": dict(graph="kg", nodes=1_000_000, edges=5_000_000, relations=1000, p=1.0, q=1.0,
@@ -246,7 +248,9 @@ def main():
             ops = [dist.P2POp(dist.isend, walks.cpu() if dry else walks, 0)]
         return _Pending(dist.batch_isend_irecv(ops) if ops else [], walks, after)
 
+    walks = None
     for _ in range(args.warmup):
+        walks = None   # let the allocator hand the same block out again (matters when a result is tens of GB)
         walks = walk_once()
         if gather:
             gather_async(walks).wait()
@@ -263,6 +267,7 @@ def main():
     t0 = time.perf_counter()
     pending = None
     for _ in range(args.steps):
+        walks = None
         walks = walk_once()
         if gather:
             work = gather_async(walks)
@@ -552,6 +557,7 @@ def main():
             },
             "cpu_baseline": cpu,
             "graph_build_s": t_graph,
+            "peak_hbm_gb": torch.cuda.max_memory_allocated() / 1e9,   # rank 0: graph + workspace + results (+ generator temporaries)
         }
         print(json.dumps(line), flush=True)
     if world > 1:
