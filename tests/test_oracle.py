@@ -284,3 +284,19 @@ def test_multithreaded_timing_leg():
         assert all((a, b) in edges for a, b in zip(row[:-1].tolist(), row[1:].tolist()))
     wb, _, used = O.walk_timed_mt(rp, ci, tg[:5000], 0.5, 2.0, 10, 7, 4)     # biased grain: 32768 // 11
     assert used == 2 and (wb[:, 0] == tg[:5000]).all()
+
+
+def test_oracle_regression_vectors():
+    """The oracle still produces, walk for walk, what it produced when its pins were last green
+    (tests/golden/make_oracle_regression.py)."""
+    import importlib.util
+    import json
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_oracle_regression",
+                                                  os.path.join(here, "golden", "make_oracle_regression.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = json.load(open(os.path.join(here, "golden", "oracle_regression.json")))
+    got = {name: mod.digest(fn()) for name, fn in mod.cases()}
+    assert got == want
