@@ -66,6 +66,18 @@ WORKLOADS = {
 }
 
 
+def _self_launch(n):
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +95,12 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Plain `python bench.py --gpus N`: start the N ranks ourselves, one process per GPU, as a child
+        # `python -m torch.distributed.run` -- before this process has touched torch or the GPU (a process
+        # that has initialised HIP must never exec or fork GPU work), and pass the child's exit code on.
+        sys.exit(_self_launch(args.gpus))
+
     import torch
     import torch.distributed as dist
 
@@ -90,9 +108,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
+        sys.exit("bench.py --gpus %d does not match WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     dry = args.backend == "gloo"
     if dry:

@@ -67,6 +67,10 @@ extern "C" {
 #define TRW_E_HIP        (-3)  /* a HIP runtime call or kernel launch failed          */
 #define TRW_E_RNG_MODE   (-4)  /* rng_mode not usable for this call                   */
 #define TRW_E_RANGE      (-5)  /* stream position beyond 2^48 draws                   */
+#define TRW_E_DATA       (-6)  /* host leg only: the graph or the start nodes are
+                                  faulty (trw_last_error() names the TRW_ST_* bits;
+                                  the device legs report those through the status
+                                  block instead, they cannot stop a launch)           */
 /* device-side status bits, returned by trw_walk_status() */
 #define TRW_ST_DEGREE0    1    /* a walker stood on a node with no out-edges (the
                                   reference divides by zero there, rw_cpu.cpp:20)  */
@@ -121,6 +125,29 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes,
                      int64_t *out,
                      void *workspace, size_t workspace_bytes,
                      void *hip_stream);
+
+/*
+ * The host leg of the same walk.  Replaces the reference's
+ *     torch::Tensor walk_cpu(row_ptr, column_idx, target_nodes, p, q, walk_length, seed)
+ * (csrc/cpu/rw_cpu.h:5-11, called from csrc/rw_init.cpp:22-23 for CPU tensors).  All pointers are HOST
+ * pointers; the call returns when the rows are written.  Arguments as trw_walk_csr_hip; no workspace.
+ *   rng_mode   TRW_RNG_AUTO / TRW_RNG_GLIBC: the reference's one glibc rand() stream, i.e. exactly
+ *              what csrc/cpu produces on one thread.  Uniform walks are split over `n_threads` host
+ *              threads by jump-ahead (same rows for any thread count); a biased walk's stream is a
+ *              serial chain and runs on the calling thread (walker_base must be 0).
+ *              TRW_RNG_WALKER: the per-walker Philox stream of the HIP kernels, on `n_threads` threads
+ *              (row for row what trw_walk_csr_hip writes in that mode).
+ *   n_threads  host threads to use (< 1 is taken as 1)
+ * Data faults (degree-0 node, node id out of range, broken row_ptr, runaway rejection loop) stop the
+ * call: TRW_E_DATA, trw_last_error() says which.
+ */
+int trw_walk_csr_cpu(const int64_t *row_ptr, int64_t n_nodes,
+                     const int64_t *col_idx, int64_t nnz,
+                     const int64_t *targets, int64_t n_walkers,
+                     int64_t walker_base,
+                     double p, double q, int32_t walk_length, int32_t seed,
+                     int32_t rng_mode,
+                     int64_t *out, int32_t n_threads);
 
 /*
  * The triples (knowledge-graph) walk.  Replaces the reference's

@@ -1,0 +1,165 @@
+"""The N > 1 path on the HIP kernels (pytest -m gpu): shards through `walk_sharded` with two real ranks,
+bench.py's own launcher, and BASELINE configs[3] (111 M nodes / 1.6 B edges) walked shard by shard."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = "cuda:0"
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+_WORKER = r"""
+import os, sys, torch
+import torch.distributed as dist
+sys.path.insert(0, {root!r})
+rank, world, port, gather, p, q, outdir = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], \
+    float(sys.argv[5]), float(sys.argv[6]), sys.argv[7]
+from torch_random_walk_amd import graphs
+from torch_random_walk_amd.dist import walk_sharded
+torch.cuda.set_device(0)                      # one card on this box: both ranks share it
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+rp, ci = graphs.rmat(3000, 30000, seed=4, device="cuda:0")
+tg = torch.arange(3000, device="cuda:0").repeat(7)[:20001]        # not divisible by the world size
+res = walk_sharded(rp, ci, tg, p, q, 33, 42, gather=gather)       # walk_fn=None: the HIP path
+assert res.is_cuda
+torch.save(res.cpu(), os.path.join(outdir, "r%d.pt" % rank))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("gather", ["root", "all"])
+@pytest.mark.parametrize("p,q", [(1.0, 1.0), (0.25, 4.0)])
+def test_sharded_walk_two_ranks_on_the_hip_path(tmp_path, gather, p, q):
+    """world_size 2, both ranks on cuda:0 with the HIP kernels doing the walking (the gloo transport
+    stages the blocks through the host; under RCCL the same code hands device tensors over): the assembled
+    result equals the single call and the oracle."""
+    from torch_random_walk_amd import graphs
+    from torch_rw import rw
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    port = _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", str(port), gather, str(p), str(q),
+                               str(tmp_path)], env=env) for r in range(2)]
+    codes = [pr.wait(timeout=600) for pr in procs]
+    assert codes == [0, 0]
+    rp, ci = graphs.rmat(3000, 30000, seed=4, device=DEV)
+    tg = torch.arange(3000, device=DEV).repeat(7)[:20001]
+    mode = rw.RNG_GLIBC if (p == 1.0 and q == 1.0) else rw.RNG_WALKER
+    single = rw.walk_ex(rp, ci, tg, p, q, 33, 42, rng_mode=mode).cpu()
+    omode = O.RNG_GLIBC_SEQ if (p == 1.0 and q == 1.0) else O.RNG_WALKER
+    ref = torch.from_numpy(O.walk(rp.cpu().numpy(), ci.cpu().numpy(), tg.cpu().numpy(), p, q, 33, 42, rng_mode=omode))
+    assert torch.equal(single, ref)
+    r0 = torch.load(os.path.join(tmp_path, "r0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "r1.pt"))
+    assert torch.equal(r0, single)
+    if gather == "all":
+        assert torch.equal(r1, single)
+    else:
+        assert torch.equal(r1, single[10001:])
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` from a plain shell (no torchrun around it): the parent starts the ranks
+    before it has touched the GPU and relays the one JSON line; gloo here because the box has one card."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                          "--workload", "rmat1m_biased", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0
+    assert line["config"]["global_walkers"] == 2 * line["config"]["walkers_per_gpu"]
+
+
+def _sparse_host_csr(rp, ci, nodes):
+    """Host CSR with the same node count in which only `nodes` keep their rows (the others are empty, so an
+    oracle walk that left the GPU's path would stop with a degree-0 error): lets the oracle check rows of a
+    14 GB graph without moving the graph."""
+    n = rp.numel() - 1
+    nodes_d = torch.as_tensor(nodes, device=rp.device)
+    starts, ends = rp[nodes_d], rp[nodes_d + 1]
+    deg = torch.zeros(n, dtype=torch.int64, device=rp.device)
+    deg[nodes_d] = ends - starts
+    rp_s = torch.zeros(n + 1, dtype=torch.int64, device=rp.device)
+    torch.cumsum(deg, 0, out=rp_s[1:])
+    order = torch.argsort(nodes_d).tolist()
+    starts_h, ends_h = starts.tolist(), ends.tolist()
+    pieces = [ci[starts_h[k]:ends_h[k]] for k in order]
+    ci_s = torch.cat(pieces) if pieces else torch.empty(0, dtype=torch.int64, device=rp.device)
+    return rp_s.cpu().numpy(), ci_s.cpu().numpy()
+
+
+def test_config4_papers100m_sharded_equals_unsharded():
+    """BASELINE configs[3]: ogbn-papers100M-scale synthetic CSR (111 M nodes / 1.6 B edges + ring), p=q=1,
+    L=80, every node a start node, the batch split into the 8 walker_base shards the 8-GPU job uses --
+    walked here one shard after another on the single card, each straight into its slice of the gathered
+    result (`walk_ex(out=...)`).  The assembled blocks equal ONE unsharded call (a different kernel
+    family: the big call walks fat entries, a shard the compact shadow), every step of every walk is an
+    edge, and sampled rows (first, last, both sides of every shard boundary) equal the oracle's
+    reference-exact glibc stream."""
+    from torch_random_walk_amd import graphs
+    from torch_random_walk_amd.dist import shard_bounds
+    from torch_rw import rw
+    n, L, seed, world = 111_000_000, 80, 10, 8
+    rp, ci = graphs.rmat(n, 1_600_000_000, seed=1, device=DEV)
+    assert int(rp[-1]) == ci.numel() == 1_600_000_000 + n
+    tg = torch.arange(n, device=DEV)
+    full = rw.walk_ex(rp, ci, tg, 1.0, 1.0, L, seed, rng_mode=rw.RNG_GLIBC)        # 72 GB
+    assert tuple(full.shape) == (n, L + 1)
+    torch.cuda.empty_cache()
+
+    # -- shard blocks == slices of the unsharded call ------------------------------------------------
+    keys = torch.repeat_interleave(torch.arange(n, device=DEV), rp[1:] - rp[:-1]).mul_(n).add_(ci)
+    assert bool((keys[1:] >= keys[:-1]).all())           # rows sorted: the key list needs no sort
+    bounds = [shard_bounds(n, world, r) for r in range(world)]
+    assert bounds[0][0] == 0 and bounds[-1][1] == n
+    for r, (lo, hi, block) in enumerate(bounds):
+        blk = torch.empty((hi - lo, L + 1), dtype=torch.int64, device=DEV)
+        got = rw.walk_ex(rp, ci, tg[lo:hi], 1.0, 1.0, L, seed, walker_base=lo, rng_mode=rw.RNG_GLIBC, out=blk)
+        assert got.data_ptr() == blk.data_ptr()
+        assert torch.equal(blk, full[lo:hi]), "shard %d differs from the unsharded call" % r
+        assert torch.equal(blk[:, 0], tg[lo:hi])
+        for s in range(L):                               # every step is an edge of the graph
+            qk = blk[:, s] * n + blk[:, s + 1]
+            pos = torch.searchsorted(keys, qk).clamp_(max=keys.numel() - 1)
+            assert bool((keys[pos] == qk).all()), "shard %d column %d leaves the graph" % (r, s + 1)
+        del blk, got
+    del keys
+    torch.cuda.empty_cache()
+
+    # -- sampled rows against the oracle -------------------------------------------------------------
+    rows = {0, 1, n - 2, n - 1}
+    for lo, hi, _ in bounds:
+        rows.update(x for x in (lo - 1, lo, lo + 1, hi - 1) if 0 <= x < n)
+    rows.update(np.random.default_rng(0).integers(0, n, 24).tolist())
+    rows = np.array(sorted(rows))
+    assert len(rows) >= 48
+    got = full[torch.as_tensor(rows, device=DEV)].cpu().numpy()
+    rp_s, ci_s = _sparse_host_csr(rp, ci, np.unique(got))
+    for r, g in zip(rows, got):
+        ref = O.walk(rp_s, ci_s, np.array([r]), 1.0, 1.0, L, seed, rng_mode=O.RNG_GLIBC_INDEXED, walker_base=int(r))
+        assert (ref[0] == g).all(), "row %d differs from the oracle" % r

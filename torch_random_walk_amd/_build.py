@@ -20,18 +20,35 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIP_LIB = os.path.join(HERE, "libtrw_hip.so")
 EXT_LIB = os.path.join(HERE, "torch_rw_native" + sysconfig.get_config_var("EXT_SUFFIX"))
 
-HIP_SOURCES = [os.path.join(CSRC, "trw_hip.hip")]
+HIP_SOURCES = [os.path.join(CSRC, "trw_hip.hip"), os.path.join(CSRC, "trw_cpu.cpp")]
 HIP_DEPS = HIP_SOURCES + [os.path.join(CSRC, f) for f in ("glibc_jump.hpp", "trw_kernels_wide.hpp",
                                                            "trw_kernels_narrow.hpp", "trw_kernels_triples.hpp", "trw_kernels_edgelist.hpp", "trw_kernels_windows.hpp")] + [os.path.join(INCLUDE, "trw.h")]
 EXT_SOURCES = [os.path.join(CSRC, "torch_rw_native.cpp")]
 EXT_DEPS = EXT_SOURCES + [os.path.join(INCLUDE, "trw.h")]
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
+def _digest(deps, extra=""):
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for d in deps:
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stale(target, deps, extra=""):
+    """Fresh <=> the stamp written next to `target` holds the digest of its sources' CONTENTS (mtimes do
+    not survive a snapshot to another box; the stamp travels with the binary)."""
+    stamp = target + ".stamp"
+    if not (os.path.exists(target) and os.path.exists(stamp)):
         return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(stamp) as f:
+        return f.read().strip() != _digest(deps, extra)
+
+
+def _write_stamp(target, deps, extra=""):
+    with open(target + ".stamp", "w") as f:
+        f.write(_digest(deps, extra))
 
 
 def _run(cmd):
@@ -40,18 +57,19 @@ def _run(cmd):
 
 
 def build_hip(force=False, extra_flags=()):
-    if not force and not _stale(HIP_LIB, HIP_DEPS):
+    if not force and not _stale(HIP_LIB, HIP_DEPS, " ".join(extra_flags)):
         return HIP_LIB
     hipcc = os.path.join(ROCM, "bin", "hipcc")
     tmp = HIP_LIB + ".tmp"
     _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
           "-Wno-unused-function", *extra_flags, "-o", tmp, *HIP_SOURCES])
     os.replace(tmp, HIP_LIB)
+    _write_stamp(HIP_LIB, HIP_DEPS, " ".join(extra_flags))
     return HIP_LIB
 
 
 def build_ext(force=False):
-    if not force and not _stale(EXT_LIB, EXT_DEPS + [HIP_LIB]):
+    if not force and not _stale(EXT_LIB, EXT_DEPS):
         return EXT_LIB
     import torch
     from torch.utils import cpp_extension
@@ -69,6 +87,7 @@ def build_ext(force=False):
           "-ltorch_hip", "-ltorch_python",
           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + torch_lib])
     os.replace(tmp, EXT_LIB)
+    _write_stamp(EXT_LIB, EXT_DEPS)
     return EXT_LIB
 
 

@@ -48,6 +48,15 @@ int fail_hip(hipError_t e, const char *what)
     return fail(TRW_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
 
+}  // namespace
+
+namespace trw_cpu {
+// the host leg (trw_cpu.cpp) reports through the same thread-local text
+void set_last_error(const std::string &msg) { t_last_error = msg; }
+}  // namespace trw_cpu
+
+namespace {
+
 const std::vector<uint32_t> &host_jump_table()
 {
     static const std::vector<uint32_t> tab = trw::build_jump_table();
