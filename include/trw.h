@@ -265,6 +265,17 @@ int trw_to_windows_triples_cbow_hip(const int64_t *walks, int64_t num_walks, int
  * 3 shadow + fat entries (uniform walk, one gather per step).  Returns TRW_OK or TRW_E_HIP. */
 int trw_walk_status(const void *workspace, void *hip_stream, int64_t status[4]);
 
+/* Deferred form of the same check, for callers that must not synchronise (the reference's GPU entry
+ * point launches and returns, csrc/cuda/rw_cuda.cu:223-245).
+ * trw_status_post: enqueues on `hip_stream` an asynchronous copy of the status block of the call that just
+ *   used `workspace` into a pinned host slot, followed by an event; never waits.  Does nothing while the
+ *   stream is being captured into a HIP graph.
+ * trw_status_collect: ORs into *bits the TRW_ST_* bits of every posted read-back that has completed since
+ *   the last collect (wait != 0: first waits for all of them) -- each is reported once, process-wide --
+ *   and returns how many read-backs are still in flight (>= 0) or a negative error code. */
+int trw_status_post(const void *workspace, void *hip_stream);
+int trw_status_collect(int wait, int64_t *bits);
+
 /* Integer form of the reference's accept test (rw_cpu.cpp:169-194):
  * (double)r / (double)RAND_MAX < prob  <=>  r < trw_accept_threshold(prob).
  * Host helper, exported so tests can pin it against the fp64 expression. */

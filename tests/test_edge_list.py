@@ -178,7 +178,10 @@ def test_gpu_serial_replay_auto_rule_shards_and_errors():
     with pytest.raises(RuntimeError, match="expected scalar type Long"):
         rw.walk_edge_list(d_e.to(torch.int32), d_i, d_t, 1.0, 1.0, 4, 1, pad)
     with pytest.raises(RuntimeError, match="outside"):
-        rw.walk_edge_list(d_e, d_i, torch.tensor([401], device=DEV), 1.0, 1.0, 4, 1, pad)
+        rw.walk_edge_list_ex(d_e, d_i, torch.tensor([401], device=DEV), 1.0, 1.0, 4, 1, pad, check=True)
+    rw.walk_edge_list(d_e, d_i, torch.tensor([401], device=DEV), 1.0, 1.0, 4, 1, pad)     # default: reported later
+    with pytest.raises(RuntimeError, match="outside"):
+        rw.check_status()
 
 
 @pytest.mark.gpu

@@ -215,16 +215,60 @@ def test_errors_are_python_exceptions(rw, hash_path, monkeypatch):
     ci0 = np.array([1, 0], dtype=np.int64)
     for p, q in ((1.0, 1.0), (0.5, 2.0)):
         with pytest.raises(RuntimeError, match="no out-edges"):
-            rw.walk(*_dev(rp0, ci0, [0, 2]), p, q, 4, 1)
+            rw.walk_ex(*_dev(rp0, ci0, [0, 2]), p, q, 4, 1, check=True)      # strict: synchronise, raise now
     # start node outside the graph
     with pytest.raises(RuntimeError, match="outside"):
-        rw.walk(d_rp, d_ci, torch.tensor([0, 50], device=DEV), 1.0, 1.0, 4, 1)
+        rw.walk_ex(d_rp, d_ci, torch.tensor([0, 50], device=DEV), 1.0, 1.0, 4, 1, check=True)
     with pytest.raises(RuntimeError, match="outside"):
-        rw.walk(d_rp, d_ci, torch.tensor([-1], device=DEV), 0.5, 2.0, 4, 1)
+        rw.walk_ex(d_rp, d_ci, torch.tensor([-1], device=DEV), 0.5, 2.0, 4, 1, check=True)
     # the launch is asynchronous and unchecked when asked to be (the reference's behaviour)
     out = rw.walk_ex(d_rp, d_ci, torch.tensor([0, 50], device=DEV), 1.0, 1.0, 4, 1, check=False)
     torch.cuda.synchronize()
     assert out[1].tolist() == [50] * 5
+    rw.check_status()                                                        # nothing pending from the above
+
+
+def test_default_call_does_not_synchronise_and_reports_faults_later(rw):
+    """The default surface launches and returns like the reference's GPU entry point (rw_cuda.cu:223-245):
+    a device-side data fault is read back asynchronously and raised by a LATER torch_rw call, or by
+    check_status(); the faulty call itself returns its (defined) rows."""
+    assert rw.get_check() == rw.CHECK_DEFERRED
+    rw.check_status()
+    rp0 = np.array([0, 1, 1, 2], dtype=np.int64)
+    ci0 = np.array([1, 0], dtype=np.int64)
+    good = _dev(*random_graph(50, 3, 81), np.arange(50))
+    for p, q in ((1.0, 1.0), (0.5, 2.0)):
+        # proof of "no synchronisation": a long kernel queued ahead on the same stream is still running when the
+        # call has returned
+        bad = _dev(rp0, ci0, [0, 2])
+        spin = torch.zeros(1 << 28, dtype=torch.float32, device=DEV)
+        done = torch.cuda.Event()
+        torch.cuda.synchronize()
+        for _ in range(40):
+            spin.add_(1.0)
+        w = rw.walk(*bad, p, q, 4, 1)                                        # faulty, returns at once
+        done.record()
+        assert not done.query(), "walk() waited for the stream"
+        del spin
+        torch.cuda.synchronize()
+        assert w[0].tolist()[:2] == [0, 1]                                   # the rows of a faulty walker are defined
+        with pytest.raises(RuntimeError, match="no out-edges"):
+            rw.check_status()                                                # waits for the read-back, raises once
+        rw.check_status()                                                    # reported once
+        rw.walk(*good, p, q, 4, 1)
+        # ... or the next call raises it
+        rw.walk(*bad, p, q, 4, 1)
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match="earlier torch_rw call.*no out-edges"):
+            rw.walk(*good, p, q, 4, 1)
+        rw.walk(*good, p, q, 4, 1)
+    rw.set_check(True)
+    try:
+        with pytest.raises(RuntimeError, match="outside"):
+            rw.walk(good[0], good[1], torch.tensor([50], device=DEV), 1.0, 1.0, 4, 1)
+    finally:
+        rw.set_check("deferred")
+    rw.check_status()
 
 
 def test_runs_on_the_callers_stream(rw):

@@ -41,11 +41,13 @@ def test_to_csr_matches_reference_fixture(golden):
     assert nodes.tolist() == golden["graph"]["nodes"]
 
 
-def test_cpu_tensors_are_refused_loudly():
+def test_cpu_tensors_take_the_host_leg_of_the_dispatcher():
+    """rw_init.cpp:20-24: the device of row_ptr picks the leg; CPU tensors walk on the host
+    (parity of that leg: tests/test_cpu_leg.py), mixed devices are an error, not a silent copy."""
     from torch_rw import rw
     rp, ci, tg = torch.tensor([0, 1, 2]), torch.tensor([1, 0]), torch.tensor([0, 1])
-    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
-        rw.walk(row_ptr=rp, col_idx=ci, target_nodes=tg, p=1.0, q=1.0, walk_length=3, seed=1)
+    w = rw.walk(row_ptr=rp, col_idx=ci, target_nodes=tg, p=1.0, q=1.0, walk_length=3, seed=1)
+    assert w.device.type == "cpu" and w.tolist() == [[0, 1, 0, 1], [1, 0, 1, 0]]
 
 
 def test_generators_have_the_promised_shape():

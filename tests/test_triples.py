@@ -164,7 +164,10 @@ def test_gpu_shards_errors_and_full_size():
     with pytest.raises(RuntimeError, match="expected scalar type Long"):
         rw.walk_triples(d_ts.to(torch.int32), d_ix, tg, 4, pad, 1)
     with pytest.raises(RuntimeError, match="outside"):
-        rw.walk_triples(d_ts, d_ix, torch.tensor([3001], device=DEV), 4, pad, 1)      # not an entity, not padding
+        rw.walk_triples_ex(d_ts, d_ix, torch.tensor([3001], device=DEV), 4, pad, 1, check=True)   # not an entity, not padding
+    rw.walk_triples(d_ts, d_ix, torch.tensor([3001], device=DEV), 4, pad, 1)          # default: reported later
+    with pytest.raises(RuntimeError, match="outside"):
+        rw.check_status()
     # BASELINE config 5 shape: 5M triples / 1M entities / 1000 relations, one walker per entity, L=80
     triples, ents5, pad5 = graphs.synthetic_kg(1_000_000, 5_000_000, 1000, seed=1, device=DEV)
     index5, ts5 = utils.build_relation_tail_index(triples, ents5)

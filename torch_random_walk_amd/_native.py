@@ -49,6 +49,12 @@ def cabi():
         L.trw_walk_edge_list_hip.argtypes = [vp, i64, vp, i64, vp, i64, i64, dbl, dbl, i32, i32, i64, i32, i32, vp,
                                              vp, ctypes.c_size_t, vp]
         L.trw_walk_edge_list_hip.restype = ctypes.c_int
+        L.trw_walk_csr_cpu.argtypes = [vp, i64, vp, i64, vp, i64, i64, dbl, dbl, i32, i32, i32, vp, i32]
+        L.trw_walk_csr_cpu.restype = ctypes.c_int
+        L.trw_status_post.argtypes = [vp, vp]
+        L.trw_status_post.restype = ctypes.c_int
+        L.trw_status_collect.argtypes = [ctypes.c_int, ctypes.POINTER(i64)]
+        L.trw_status_collect.restype = ctypes.c_int
         L.trw_walk_status.argtypes = [vp, vp, ctypes.POINTER(i64)]
         L.trw_walk_status.restype = ctypes.c_int
         L.trw_accept_threshold.argtypes = [dbl]

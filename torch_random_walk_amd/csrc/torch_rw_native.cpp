@@ -7,14 +7,22 @@
 // memory (output + scratch through the caching allocator), the device guard and
 // the current stream.
 //
-// CPU tensors are refused: this build is the MI355X path and carries no CPU
-// walker to fall back to.
+// Device dispatch as in the reference (rw_init.cpp:20-24): tensors on the GPU go to the HIP kernels,
+// CPU tensors of the CSR walk to the library's host leg (trw_walk_csr_cpu).  Neither is a fallback for
+// the other: a GPU tensor never runs on the host.
+//
+// Data faults found on the device (degree-0 node, ids out of range, ...) are reported without a host
+// synchronisation by default, like any asynchronous GPU error: the status block of a call is read back
+// asynchronously and the error is raised by the NEXT torch_rw call (or by check_status()) once that
+// read-back has landed.  set_check(True) / check=True is the strict mode: synchronise and raise at once.
 #include <torch/extension.h>
 
 // PyTorch-ROCm presents its HIP devices under the "cuda" device type; these are the guard and
 // stream accessors that go with that.
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+
+#include <ATen/Parallel.h>
 
 #include <atomic>
 #include <string>
@@ -24,13 +32,17 @@
 namespace {
 
 std::atomic<int> g_rng_mode{TRW_RNG_AUTO};
-std::atomic<bool> g_check{true};
+enum : int { kCheckOff = 0, kCheckStrict = 1, kCheckDeferred = 2 };
+std::atomic<int> g_check{kCheckDeferred};
 
-void check_index_tensor(const torch::Tensor &t, const char *name)
+void check_index_tensor(const torch::Tensor &t, const char *name, bool want_cuda = true)
 {
-    // reference: CHECK_CUDA (csrc/cuda/utils.cuh:7, used at rw_cuda.cu:194-196)
-    TORCH_CHECK(t.is_cuda(), name,
-                " must be a CUDA tensor (torch_rw_native here is the MI355X HIP build; it has no CPU walker)");
+    // reference: CHECK_CUDA / CHECK_CPU (csrc/cuda/utils.cuh:7-8, used at rw_cuda.cu:194-196, rw_cpu.cpp:211-213)
+    if (want_cuda) {
+        TORCH_CHECK(t.is_cuda(), name, " must be a CUDA tensor (the other tensors of this call are on the GPU)");
+    } else {
+        TORCH_CHECK(!t.is_cuda(), name, " must be a CPU tensor (the other tensors of this call are on the host)");
+    }
     // reference: the int64 accessor raises this text for any other dtype
     TORCH_CHECK(t.scalar_type() == torch::kInt64, "expected scalar type Long but found ",
                 c10::toString(t.scalar_type()), " (", name, ")");
@@ -47,22 +59,89 @@ std::string status_text(int64_t bits)
     return s;
 }
 
+// Deferred mode, on entry: raise what earlier calls' read-backs have reported by now (never waits).
+void raise_pending()
+{
+    int64_t bits = 0;
+    const int rc = trw_status_collect(0, &bits);
+    TORCH_CHECK(rc >= 0, "torch_rw status collect failed (", rc, "): ", trw_last_error());
+    TORCH_CHECK(bits == 0, "an earlier torch_rw call reported: ", status_text(bits), "status bits ", bits);
+}
+
+// After the kernels of a call are enqueued: look at its status block the way `mode` asks.
+void finish_status(const torch::Tensor &workspace, void *stream, int mode, const char *what)
+{
+    if (mode == kCheckStrict) {
+        int64_t status[4] = {0, 0, 0, 0};
+        int rc;
+        {
+            pybind11::gil_scoped_release nogil;
+            rc = trw_walk_status(workspace.data_ptr(), stream, status);
+        }
+        TORCH_CHECK(rc == TRW_OK, "torch_rw status read failed (", rc, "): ", trw_last_error());
+        TORCH_CHECK(status[0] == 0, "torch_rw ", what, ": ", status_text(status[0]), "status bits ", status[0]);
+    } else if (mode == kCheckDeferred) {
+        const int rc = trw_status_post(workspace.data_ptr(), stream);
+        TORCH_CHECK(rc == TRW_OK, "torch_rw status post failed (", rc, "): ", trw_last_error());
+    }
+}
+
+int resolve_check(int64_t check) { return check < 0 ? g_check.load() : (int)check; }
+
+// The host leg: what the reference's dispatcher does with CPU tensors (rw_init.cpp:22-23 -> walk_cpu).
+torch::Tensor walk_cpu_leg(const torch::Tensor &row_ptr, const torch::Tensor &col_idx,
+                           const torch::Tensor &target_nodes, double p, double q, int64_t walk_length, int64_t seed,
+                           int64_t walker_base, int64_t rng_mode, const c10::optional<torch::Tensor> &out)
+{
+    check_index_tensor(row_ptr, "row_ptr", false);
+    check_index_tensor(col_idx, "col_idx", false);
+    check_index_tensor(target_nodes, "target_nodes", false);
+    TORCH_CHECK(row_ptr.numel() >= 1, "row_ptr must have num_nodes + 1 entries");
+    const auto rp = row_ptr.contiguous();
+    const auto ci = col_idx.contiguous();
+    const auto tg = target_nodes.contiguous();
+    const int64_t n_walkers = tg.numel();
+    torch::Tensor walks;
+    if (out.has_value() && out->defined()) {
+        walks = *out;
+        TORCH_CHECK(walks.scalar_type() == torch::kInt64 && !walks.is_cuda() && walks.is_contiguous() &&
+                        walks.dim() == 2 && walks.size(0) == n_walkers && walks.size(1) == walk_length + 1,
+                    "out must be a contiguous int64 [len(target_nodes), walk_length + 1] tensor on the inputs' device");
+    } else {
+        walks = torch::empty({n_walkers, walk_length + 1}, rp.options());  // rw_cpu.cpp:216-217
+    }
+    const int threads = at::get_num_threads();
+    int rc;
+    {
+        pybind11::gil_scoped_release nogil;  // the reference holds the GIL here; nothing below needs it
+        rc = trw_walk_csr_cpu(rp.data_ptr<int64_t>(), rp.numel() - 1, ci.data_ptr<int64_t>(), ci.numel(),
+                              tg.data_ptr<int64_t>(), n_walkers, walker_base, p, q, (int32_t)walk_length,
+                              (int32_t)seed, (int32_t)rng_mode, walks.data_ptr<int64_t>(), threads);
+    }
+    TORCH_CHECK(rc == TRW_OK, "torch_rw walk failed (", rc, "): ", trw_last_error());
+    return walks;
+}
+
 // walk_ex: the reference's seven arguments plus what this library adds (global walker base, RNG mode,
 // status check, and an optional destination: a contiguous int64 [N, L+1] tensor to walk into -- e.g. a
 // shard's slice of the gathered result).
 torch::Tensor walk_ex(const torch::Tensor &row_ptr, const torch::Tensor &col_idx, const torch::Tensor &target_nodes,
                       double p, double q, int64_t walk_length, int64_t seed, int64_t walker_base, int64_t rng_mode,
-                      bool check, const c10::optional<torch::Tensor> &out)
+                      int64_t check, const c10::optional<torch::Tensor> &out)
 {
+    TORCH_CHECK(walk_length >= 1, "walk_length must be >= 1, got ", walk_length);
+    TORCH_CHECK(walk_length < (int64_t(1) << 31) && seed >= INT32_MIN && seed <= INT32_MAX,
+                "walk_length/seed must fit the reference's int arguments");
+    if (!row_ptr.is_cuda())  // rw_init.cpp:20: the device of row_ptr decides
+        return walk_cpu_leg(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, walker_base, rng_mode, out);
+    const int check_mode = resolve_check(check);
+    if (check_mode == kCheckDeferred) raise_pending();
     check_index_tensor(row_ptr, "row_ptr");
     check_index_tensor(col_idx, "col_idx");
     check_index_tensor(target_nodes, "target_nodes");
     TORCH_CHECK(row_ptr.device() == col_idx.device() && row_ptr.device() == target_nodes.device(),
                 "row_ptr, col_idx and target_nodes must be on the same device");
     TORCH_CHECK(row_ptr.numel() >= 1, "row_ptr must have num_nodes + 1 entries");
-    TORCH_CHECK(walk_length >= 1, "walk_length must be >= 1, got ", walk_length);
-    TORCH_CHECK(walk_length < (int64_t(1) << 31) && seed >= INT32_MIN && seed <= INT32_MAX,
-                "walk_length/seed must fit the reference's int arguments");
 
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(row_ptr.device());
     const auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(row_ptr.device().index());
@@ -98,16 +177,7 @@ torch::Tensor walk_ex(const torch::Tensor &row_ptr, const torch::Tensor &col_idx
                               walks.data_ptr<int64_t>(), workspace.data_ptr(), ws_bytes, (void *)stream.stream());
     }
     TORCH_CHECK(rc == TRW_OK, "torch_rw walk failed (", rc, "): ", trw_last_error());
-
-    if (check) {
-        int64_t status[4] = {0, 0, 0, 0};
-        {
-            pybind11::gil_scoped_release nogil;
-            rc = trw_walk_status(workspace.data_ptr(), (void *)stream.stream(), status);
-        }
-        TORCH_CHECK(rc == TRW_OK, "torch_rw status read failed (", rc, "): ", trw_last_error());
-        TORCH_CHECK(status[0] == 0, "torch_rw walk: ", status_text(status[0]), "status bits ", status[0]);
-    }
+    finish_status(workspace, (void *)stream.stream(), check_mode, "walk");
     return walks;
 }
 
@@ -115,16 +185,17 @@ torch::Tensor walk_ex(const torch::Tensor &row_ptr, const torch::Tensor &col_idx
 torch::Tensor walk(const torch::Tensor &row_ptr, const torch::Tensor &column_idx, const torch::Tensor &target_nodes,
                    const double p, const double q, const int walk_length, const int seed)
 {
-    return walk_ex(row_ptr, column_idx, target_nodes, p, q, walk_length, seed, 0, g_rng_mode.load(), g_check.load(),
-                   c10::nullopt);
+    return walk_ex(row_ptr, column_idx, target_nodes, p, q, walk_length, seed, 0, g_rng_mode.load(), -1, c10::nullopt);
 }
 
 // walk_triples: reference dispatcher csrc/rw_init.cpp:47-75, same argument order.
 torch::Tensor walk_triples_ex(const torch::Tensor &triples_indexed, const torch::Tensor &relation_tail_index,
                               const torch::Tensor &target_nodes, int64_t walk_length, int64_t padding_idx,
-                              bool restart, int64_t seed, int64_t walker_base, int64_t rng_mode, bool check)
+                              bool restart, int64_t seed, int64_t walker_base, int64_t rng_mode, int64_t check)
 {
     (void)restart;  // accepted and never read by the reference either (rw_cpu_triples.cpp:48-55)
+    const int check_mode = resolve_check(check);
+    if (check_mode == kCheckDeferred) raise_pending();
     check_index_tensor(target_nodes, "target_nodes");
     for (const auto *t : {&triples_indexed, &relation_tail_index}) {
         TORCH_CHECK(t->is_cuda(), "triples_indexed and relation_tail_index must be CUDA tensors (torch_rw_native here "
@@ -162,15 +233,7 @@ torch::Tensor walk_triples_ex(const torch::Tensor &triples_indexed, const torch:
                                   ws_bytes, (void *)stream.stream());
     }
     TORCH_CHECK(rc == TRW_OK, "torch_rw walk_triples failed (", rc, "): ", trw_last_error());
-    if (check) {
-        int64_t status[4] = {0, 0, 0, 0};
-        {
-            pybind11::gil_scoped_release nogil;
-            rc = trw_walk_status(workspace.data_ptr(), (void *)stream.stream(), status);
-        }
-        TORCH_CHECK(rc == TRW_OK, "torch_rw status read failed (", rc, "): ", trw_last_error());
-        TORCH_CHECK(status[0] == 0, "torch_rw walk_triples: ", status_text(status[0]), "status bits ", status[0]);
-    }
+    finish_status(workspace, (void *)stream.stream(), check_mode, "walk_triples");
     return walks;
 }
 
@@ -179,15 +242,17 @@ torch::Tensor walk_triples(const torch::Tensor &triples_indexed, const torch::Te
                            const bool restart, const int seed)
 {
     return walk_triples_ex(triples_indexed, relation_tail_index, target_nodes, walk_length, padding_idx, restart, seed,
-                           0, g_rng_mode.load(), g_check.load());
+                           0, g_rng_mode.load(), -1);
 }
 
 // walk_edge_list: reference dispatcher csrc/rw_init.cpp:27-45, same argument order.
 torch::Tensor walk_edge_list_ex(const torch::Tensor &edge_list_indexed, const torch::Tensor &node_edges_idx,
                                 const torch::Tensor &target_nodes, double p, double q, int64_t walk_length,
                                 int64_t seed, int64_t padding_idx, bool restart, int64_t walker_base,
-                                int64_t rng_mode, bool check)
+                                int64_t rng_mode, int64_t check)
 {
+    const int check_mode = resolve_check(check);
+    if (check_mode == kCheckDeferred) raise_pending();
     check_index_tensor(target_nodes, "target_nodes");
     for (const auto *t : {&edge_list_indexed, &node_edges_idx}) {
         TORCH_CHECK(t->is_cuda(), "edge_list_indexed and node_edge_index must be CUDA tensors (torch_rw_native here "
@@ -222,15 +287,7 @@ torch::Tensor walk_edge_list_ex(const torch::Tensor &edge_list_indexed, const to
                                     (void *)stream.stream());
     }
     TORCH_CHECK(rc == TRW_OK, "torch_rw walk_edge_list failed (", rc, "): ", trw_last_error());
-    if (check) {
-        int64_t status[4] = {0, 0, 0, 0};
-        {
-            pybind11::gil_scoped_release nogil;
-            rc = trw_walk_status(workspace.data_ptr(), (void *)stream.stream(), status);
-        }
-        TORCH_CHECK(rc == TRW_OK, "torch_rw status read failed (", rc, "): ", trw_last_error());
-        TORCH_CHECK(status[0] == 0, "torch_rw walk_edge_list: ", status_text(status[0]), "status bits ", status[0]);
-    }
+    finish_status(workspace, (void *)stream.stream(), check_mode, "walk_edge_list");
     return walks;
 }
 
@@ -239,7 +296,7 @@ torch::Tensor walk_edge_list(const torch::Tensor &edge_list_indexed, const torch
                              const int seed, const int64_t padding_idx, const bool restart)
 {
     return walk_edge_list_ex(edge_list_indexed, node_edges_idx, target_nodes, p, q, walk_length, seed, padding_idx,
-                             restart, 0, g_rng_mode.load(), g_check.load());
+                             restart, 0, g_rng_mode.load(), -1);
 }
 
 // to_windows / to_windows_cbow: reference dispatchers csrc/rw_init.cpp:77-101.
@@ -375,7 +432,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("walk_ex", &walk_ex, "walk with an explicit global walker base, RNG mode and status check",
           pybind11::arg("row_ptr"), pybind11::arg("col_idx"), pybind11::arg("target_nodes"), pybind11::arg("p"),
           pybind11::arg("q"), pybind11::arg("walk_length"), pybind11::arg("seed"), pybind11::arg("walker_base") = 0,
-          pybind11::arg("rng_mode") = (int64_t)TRW_RNG_AUTO, pybind11::arg("check") = true,
+          pybind11::arg("rng_mode") = (int64_t)TRW_RNG_AUTO, pybind11::arg("check") = (int64_t)-1,
           pybind11::arg("out") = pybind11::none());
     m.def("to_windows", &to_windows, "to_windows", pybind11::arg("walks"), pybind11::arg("window_size"),
           pybind11::arg("num_nodes"), pybind11::arg("seed"));
@@ -412,7 +469,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           pybind11::arg("edge_list_indexed"), pybind11::arg("node_edge_index"), pybind11::arg("target_nodes"),
           pybind11::arg("p"), pybind11::arg("q"), pybind11::arg("walk_length"), pybind11::arg("seed"),
           pybind11::arg("padding_idx"), pybind11::arg("restart"), pybind11::arg("walker_base") = 0,
-          pybind11::arg("rng_mode") = (int64_t)TRW_RNG_AUTO, pybind11::arg("check") = true);
+          pybind11::arg("rng_mode") = (int64_t)TRW_RNG_AUTO, pybind11::arg("check") = (int64_t)-1);
     m.def("walk_triples", &walk_triples, "walk_triples", pybind11::arg("triples_indexed"),
           pybind11::arg("relation_tail_index"), pybind11::arg("target_nodes"), pybind11::arg("walk_length"),
           pybind11::arg("padding_idx"), pybind11::arg("restart"), pybind11::arg("seed"));
@@ -420,14 +477,31 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           pybind11::arg("triples_indexed"), pybind11::arg("relation_tail_index"), pybind11::arg("target_nodes"),
           pybind11::arg("walk_length"), pybind11::arg("padding_idx"), pybind11::arg("restart"), pybind11::arg("seed"),
           pybind11::arg("walker_base") = 0, pybind11::arg("rng_mode") = (int64_t)TRW_RNG_AUTO,
-          pybind11::arg("check") = true);
+          pybind11::arg("check") = (int64_t)-1);
     m.def("set_rng_mode", [](int64_t mode) {
         TORCH_CHECK(mode == TRW_RNG_AUTO || mode == TRW_RNG_GLIBC || mode == TRW_RNG_WALKER, "unknown rng mode ", mode);
         g_rng_mode.store((int)mode);
     });
     m.def("get_rng_mode", []() { return (int64_t)g_rng_mode.load(); });
-    m.def("set_check", [](bool on) { g_check.store(on); });
-    m.def("get_check", []() { return g_check.load(); });
+    m.def("set_check", [](int64_t mode) {
+        TORCH_CHECK(mode == kCheckOff || mode == kCheckStrict || mode == kCheckDeferred, "unknown check mode ", mode);
+        g_check.store((int)mode);
+    });
+    m.def("get_check", []() { return (int64_t)g_check.load(); });
+    m.def("check_status", [](bool wait) {
+        int64_t bits = 0;
+        int rc;
+        {
+            pybind11::gil_scoped_release nogil;
+            rc = trw_status_collect(wait ? 1 : 0, &bits);
+        }
+        TORCH_CHECK(rc >= 0, "torch_rw status collect failed (", rc, "): ", trw_last_error());
+        TORCH_CHECK(bits == 0, "torch_rw: ", status_text(bits), "status bits ", bits);
+        return (int64_t)rc;
+    }, pybind11::arg("wait") = true);
+    m.attr("CHECK_OFF") = (int64_t)kCheckOff;
+    m.attr("CHECK_STRICT") = (int64_t)kCheckStrict;
+    m.attr("CHECK_DEFERRED") = (int64_t)kCheckDeferred;
     m.def("abi_version", []() { return (int64_t)trw_version(); });
     m.attr("RNG_AUTO") = (int64_t)TRW_RNG_AUTO;
     m.attr("RNG_GLIBC") = (int64_t)TRW_RNG_GLIBC;

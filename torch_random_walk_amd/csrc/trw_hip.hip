@@ -1016,6 +1016,80 @@ int trw_walk_status(const void *workspace, void *hip_stream, int64_t status_out[
     return TRW_OK;
 }
 
+// ---- deferred status: asynchronous read-backs of status blocks -----------------------------------
+namespace {
+struct StatusSlot {
+    int64_t *host = nullptr;  // pinned, 16 words
+    hipEvent_t ev = nullptr;
+    bool busy = false;
+};
+constexpr int kStatusSlots = 64;
+std::mutex g_status_mu;
+StatusSlot g_status_slots[kStatusSlots];
+int64_t g_status_carry = 0;  // bits of read-backs that were finished to make room, not yet collected
+
+// ORs the bits of every finished read-back into *bits and frees its slot; returns how many are still in flight.
+int status_sweep(bool wait, int64_t *bits)
+{
+    int pending = 0;
+    for (auto &sl : g_status_slots) {
+        if (!sl.busy) continue;
+        hipError_t e = wait ? hipEventSynchronize(sl.ev) : hipEventQuery(sl.ev);
+        if (e == hipErrorNotReady) {
+            ++pending;
+            continue;
+        }
+        sl.busy = false;  // finished (or failed: nothing more to learn from it)
+        if (e == hipSuccess && bits) *bits |= sl.host[0];
+    }
+    return pending;
+}
+}  // namespace
+
+int trw_status_post(const void *workspace, void *hip_stream)
+{
+    t_last_error.clear();
+    if (!workspace) return fail(TRW_E_ARG, "null argument");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return TRW_OK;
+    std::lock_guard<std::mutex> lock(g_status_mu);
+    StatusSlot *slot = nullptr;
+    for (int round = 0; round < 2 && !slot; ++round) {
+        for (auto &sl : g_status_slots)
+            if (!sl.busy) {
+                slot = &sl;
+                break;
+            }
+        if (!slot) status_sweep(true, &g_status_carry);  // every slot in flight: finish them, keep their bits
+    }
+    if (!slot) return fail(TRW_E_HIP, "no status slot free");
+    hipError_t e = hipSuccess;
+    if (!slot->host) {
+        e = hipHostMalloc((void **)&slot->host, 16 * sizeof(int64_t), hipHostMallocDefault);
+        if (e != hipSuccess) return fail_hip(e, "hipHostMalloc(status slot)");
+        e = hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming);
+        if (e != hipSuccess) return fail_hip(e, "hipEventCreate(status slot)");
+    }
+    slot->host[0] = 0;
+    e = hipMemcpyAsync(slot->host, workspace, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return fail_hip(e, "hipMemcpyAsync(status)");
+    e = hipEventRecord(slot->ev, stream);
+    if (e != hipSuccess) return fail_hip(e, "hipEventRecord(status)");
+    slot->busy = true;
+    return TRW_OK;
+}
+
+int trw_status_collect(int wait, int64_t *bits)
+{
+    t_last_error.clear();
+    if (!bits) return fail(TRW_E_ARG, "null argument");
+    std::lock_guard<std::mutex> lock(g_status_mu);
+    *bits = g_status_carry;
+    g_status_carry = 0;
+    return status_sweep(wait != 0, bits);
+}
+
 int trw_walk_counters(const void *workspace, void *hip_stream, uint64_t counters_out[4])
 {
     t_last_error.clear();

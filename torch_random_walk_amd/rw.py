@@ -18,8 +18,26 @@ def walk(row_ptr, col_idx, target_nodes, p, q, walk_length, seed):
     return torch_rw_native.walk(row_ptr, col_idx, target_nodes, p, q, walk_length, seed)
 
 
+CHECK_OFF, CHECK_STRICT, CHECK_DEFERRED = (int(torch_rw_native.CHECK_OFF), int(torch_rw_native.CHECK_STRICT),
+                                           int(torch_rw_native.CHECK_DEFERRED))
+
+
+def _check_code(check):
+    """None -> the process-wide mode (set_check); True -> strict (synchronise, raise now); False -> never
+    look; "deferred" -> asynchronous read-back, raised by the next call or by check_status()."""
+    if check is None:
+        return -1
+    if check is True:
+        return CHECK_STRICT
+    if check is False:
+        return CHECK_OFF
+    if check == "deferred" or check == CHECK_DEFERRED:
+        return CHECK_DEFERRED
+    raise ValueError("check must be None, True, False or 'deferred'")
+
+
 def walk_ex(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, walker_base=0, rng_mode=RNG_AUTO,
-            check=True, out=None):
+            check=None, out=None):
     """``walk`` with an explicit global index for ``target_nodes[0]`` and RNG mode.
 
     A shard that passes the global offset of its slice reproduces exactly the rows
@@ -28,7 +46,7 @@ def walk_ex(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, walker_base
     the gathered result) instead of a fresh one.
     """
     return torch_rw_native.walk_ex(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, walker_base,
-                                   rng_mode, check, out)
+                                   rng_mode, _check_code(check), out)
 
 
 def set_rng_mode(mode):
@@ -40,9 +58,28 @@ def get_rng_mode():
     return torch_rw_native.get_rng_mode()
 
 
-def set_check(on):
-    """Whether ``walk`` synchronises and raises on device-side data faults (default True)."""
-    torch_rw_native.set_check(bool(on))
+def set_check(mode):
+    """How the GPU calls report device-side data faults (degree-0 node, ids out of range, ...):
+
+    ``"deferred"`` (default)  no host synchronisation, like the reference's launch-and-return GPU entry
+                              point (csrc/cuda/rw_cuda.cu:223-245): the status block is read back
+                              asynchronously and the ``RuntimeError`` is raised by the next torch_rw call
+                              that finds it landed, or by ``check_status()``;
+    ``True``                  strict: every call synchronises its stream and raises at once;
+    ``False``                 never look (the output rows of a faulty walker are still defined).
+    CPU tensors always raise at once (the host leg is synchronous anyway).
+    """
+    torch_rw_native.set_check(CHECK_DEFERRED if mode is None else _check_code(mode))
+
+
+def get_check():
+    return torch_rw_native.get_check()
+
+
+def check_status(wait=True):
+    """Raise ``RuntimeError`` for device-side faults of earlier deferred-check calls.  ``wait=True``
+    first waits for every outstanding read-back; returns the number still in flight otherwise."""
+    return torch_rw_native.check_status(wait)
 
 
 def walk_triples(triples_indexed, relation_tail_index, target_nodes, walk_length, padding_idx, seed, restart=True):
@@ -58,10 +95,10 @@ def walk_triples(triples_indexed, relation_tail_index, target_nodes, walk_length
 
 
 def walk_triples_ex(triples_indexed, relation_tail_index, target_nodes, walk_length, padding_idx, seed,
-                    restart=True, walker_base=0, rng_mode=RNG_AUTO, check=True):
+                    restart=True, walker_base=0, rng_mode=RNG_AUTO, check=None):
     """``walk_triples`` with an explicit global walker base and RNG mode (see ``walk_ex``)."""
     return torch_rw_native.walk_triples_ex(triples_indexed, relation_tail_index, target_nodes, walk_length,
-                                           padding_idx, restart, seed, walker_base, rng_mode, check)
+                                           padding_idx, restart, seed, walker_base, rng_mode, _check_code(check))
 
 
 def walk_edge_list(edge_list_indexed, node_edge_index, target_nodes, p, q, walk_length, seed, padding_idx,
@@ -74,10 +111,10 @@ def walk_edge_list(edge_list_indexed, node_edge_index, target_nodes, p, q, walk_
 
 
 def walk_edge_list_ex(edge_list_indexed, node_edge_index, target_nodes, p, q, walk_length, seed, padding_idx,
-                      restart=True, walker_base=0, rng_mode=RNG_AUTO, check=True):
+                      restart=True, walker_base=0, rng_mode=RNG_AUTO, check=None):
     """``walk_edge_list`` with an explicit global walker base and RNG mode (see ``walk_ex``)."""
     return torch_rw_native.walk_edge_list_ex(edge_list_indexed, node_edge_index, target_nodes, p, q, walk_length, seed,
-                                             padding_idx, restart, walker_base, rng_mode, check)
+                                             padding_idx, restart, walker_base, rng_mode, _check_code(check))
 
 
 def to_windows(walks, window_size, num_nodes, seed):
