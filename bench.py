@@ -265,17 +265,24 @@ def main():
         return _Pending(dist.batch_isend_irecv(ops) if ops else [], walks, after)
 
     walks = None
+    # Warm-up calls are where a graph gets prepared (rw.walk keeps the prepared graph of the tensors it has seen:
+    # the first call builds what one call is worth, the second node2vec call the full neighbourhood masks); their
+    # prepare times are reported beside the steady-state number.
+    lib.trw_profile_enable(1)
+    cold_prepare_ms = []
     for _ in range(args.warmup):
         walks = None   # let the allocator hand the same block out again (matters when a result is tens of GB)
         walks = walk_once()
         if gather:
             gather_async(walks).wait()
+        pm = ctypes.c_double()
+        if lib.trw_profile_prepare_last(ctypes.byref(pm)) == 0:
+            cold_prepare_ms.append(pm.value)
     torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps between barriers -------------------------------------
     # N > 1: the gather of step k rides RCCL's stream while step k+1 walks (the blocks of
     # successive steps are independent); every gather has completed before the closing barrier.
-    lib.trw_profile_enable(1)
     kernel_ms, prepare_ms, finish_ms = [], [], []
     if world > 1:
         dist.barrier()
@@ -357,31 +364,47 @@ def main():
                        3: "uniform_glibc_rows_kernel<true>"}[int(stw[3])]
         del out, ws
     else:
+        # the counting variant of the kernel over a graph prepared exactly as the timed calls' was
+        cached = [i for i in rw.cache_info() if i[0] == n and i[1] == nnz]
+        what = int(cached[0][2]) if cached else int(lib.trw_prepare_plan(n, nnz, B, L, p, q, mode))
+        stream = torch.cuda.current_stream().cuda_stream
+        pbytes = lib.trw_prepare_csr_bytes(n, nnz, what)
+        blob = torch.empty(pbytes, dtype=torch.uint8, device=dev)
+        rc = lib.trw_prepare_csr_hip(row_ptr.data_ptr(), n, col_idx.data_ptr(), nnz, what, blob.data_ptr(), pbytes, stream)
+        assert rc == 0, lib.trw_last_error()
         lib.trw_profile_enable(2)
-        nbytes = lib.trw_walk_csr_workspace_bytes(n, nnz, B, L, p, q, mode)
+        nbytes = lib.trw_walk_csr_prepared_workspace_bytes(B, L, p, q, mode)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         out = torch.empty((B, L + 1), dtype=torch.int64, device=dev)
-        stream = torch.cuda.current_stream().cuda_stream
-        rc = lib.trw_walk_csr_hip(row_ptr.data_ptr(), n, col_idx.data_ptr(), nnz, targets.data_ptr(), B,
-                                  walker_base, p, q, L, args.seed, mode, out.data_ptr(), ws.data_ptr(), nbytes,
-                                  stream)
+        rc = lib.trw_walk_csr_prepared_hip(blob.data_ptr(), pbytes, what, row_ptr.data_ptr(), n, col_idx.data_ptr(), nnz,
+                                           targets.data_ptr(), B, walker_base, p, q, L, args.seed, mode, out.data_ptr(),
+                                           ws.data_ptr(), nbytes, stream)
         assert rc == 0, lib.trw_last_error()
         c = (ctypes.c_uint64 * 4)()
         assert lib.trw_walk_counters(ws.data_ptr(), stream, c) == 0
         stw = (ctypes.c_int64 * 4)()
         assert lib.trw_walk_status(ws.data_ptr(), stream, stw) == 0
-        kernel_name = {0: "biased_walker_wide_kernel", 1: "biased_walker_kernel", 2: "biased_hash_kernel"}[int(stw[3])]
+        family = int(stw[3])
+        kernel_name = {0: "biased_walker_wide_kernel", 1: "biased_walker_kernel", 2: "biased_hash_kernel",
+                       4: "biased_mask_kernel"}[family]
         lib.trw_profile_enable(0)
         assert torch.equal(out, walks), "counting variant of the kernel produced different walks"
         trials, fetches, tests, probes = (int(x) for x in c)
-        counters = dict(trials=trials, candidate_loads=fetches, membership_tests=tests, table_or_bisect_entries=probes)
-        # int64-API-layout bytes the algorithm as run must move (with this kernel's
-        # own counts): per walker 8 B target + 8 B column 0 + 32 B first step; per later step
-        # 16 B row_ptr pair + 8 B stored column; 8 B per candidate entry actually loaded and per
-        # table/col_idx entry a lookup reads.  (The reference's own access pattern -- a candidate load
-        # and a linear row scan on every trial -- counts many times more: roofline.reference_accounting.)
-        alg_bytes = B * 16 + B * 32 + (L - 1) * B * (16 + 8) + 8 * fetches + 8 * probes
-        del out, ws
+        counters = dict(trials=trials, candidate_loads=fetches, membership_tests=tests, table_or_bisect_entries=probes,
+                        prepared_what=what, prepared_bytes=int(pbytes))
+        if family == 4:
+            # biased_mask_kernel, bytes the algorithm as run must move: per walker 8 B target + 8 B row32 pair; per
+            # column 8 B stored; 32 B per fat entry gathered (every accepted offset, plus candidates the table is
+            # asked about); 16 B per table slot read.
+            alg_bytes = B * 16 + 8 * B * (L + 1) + 32 * fetches + 16 * probes
+        else:
+            # int64-API-layout bytes (with this kernel's own counts): per walker 8 B target + 8 B column 0
+            # + 32 B first step; per later step 16 B row_ptr pair + 8 B stored column; 8 B per candidate entry loaded
+            # and per table/col_idx entry a lookup reads.
+            alg_bytes = B * 16 + B * 32 + (L - 1) * B * (16 + 8) + 8 * fetches + 8 * probes
+        # (The reference's own access pattern -- a candidate load and a linear row scan on every trial -- counts
+        # many times more: roofline.reference_accounting.)
+        del out, ws, blob
 
     steps_per_launch = B * L
     k_ms = sum(kernel_ms) / max(1, len(kernel_ms))
@@ -566,6 +589,7 @@ def main():
                 "kernel_ms": k_ms,
                 "prepare_ms": sum(prepare_ms) / max(1, len(prepare_ms)),
                 "finish_ms": sum(finish_ms) / max(1, len(finish_ms)),
+                "cold_prepare_ms": cold_prepare_ms,   # prepare passes of the warm-up calls (first sight, upgrade)
                 "kernel_steps_per_s": steps_per_launch / (k_ms * 1e-3) if k_ms > 0 else None,
                 "counters": counters,
                 "request_rate": request_rate,

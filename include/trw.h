@@ -127,6 +127,48 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes,
                      void *hip_stream);
 
 /*
+ * The prepared graph.  Everything the walk derives from (row_ptr, col_idx) alone -- validation, the uint32
+ * shadow, fat entries, the edge table, the per-edge neighbourhood masks -- is built into ONE caller-owned
+ * device buffer and reused by any number of walks (the reference has no such object: it re-reads the int64
+ * CSR on every call; SURVEY 8(b) "Ownership" allows cached derived data).  trw_walk_csr_hip above is the
+ * one-shot form: it prepares inside its own workspace on every call.
+ *
+ *   what  OR of TRW_PREP_* bits (0 = validated uint32 shadow only):
+ *     TRW_PREP_UNIFORM  + 16-byte fat entries {v, start(v), deg(v)}: the uniform walk is one gather per step
+ *     TRW_PREP_BIASED   + edge hash table (16 B x 2^k slots, 2^k >= 3*nnz) and 32-byte fat entries {v, start(v),
+ *                       deg(v), where-the-reverse-edge-sits, 128-bit "is the node at this offset a neighbour
+ *                       of the node I came from" mask}: a node2vec rejection trial is decided in registers and
+ *                       the graph is read once per step.  Masks are worked out for entries one of whose rows
+ *                       has at most 8 entries; the rest ask the table.
+ *     TRW_PREP_MARKS    (implies BIASED) masks for every entry one of whose rows has at most 4096 entries:
+ *                       about 5x the prepare time, pays when the graph is walked more than once
+ *   or one of          TRW_PREP_ORDER_ONLY: no shadow, only the row-order probe the int64 biased kernels want;
+ *                      TRW_PREP_NOTHING: header only (uniform walk on the per-walker stream)
+ * trw_prepare_plan returns the `what` one call of the given shape is worth (what trw_walk_csr_hip builds).
+ * The buffer must be 16-byte aligned and stay untouched while walks use it; it is valid for exactly the
+ * (row_ptr, col_idx) contents it was built from.  trw_walk_csr_prepared_hip takes the same arguments as
+ * trw_walk_csr_hip plus the buffer; its workspace is small (status block + 124 B per lane of a uniform walk).
+ */
+#define TRW_PREP_UNIFORM     1
+#define TRW_PREP_BIASED      2
+#define TRW_PREP_MARKS       4
+#define TRW_PREP_ORDER_ONLY (-1)
+#define TRW_PREP_NOTHING    (-2)
+int32_t trw_prepare_plan(int64_t n_nodes, int64_t nnz, int64_t n_walkers, int32_t walk_length,
+                         double p, double q, int32_t rng_mode);
+size_t trw_prepare_csr_bytes(int64_t n_nodes, int64_t nnz, int32_t what);
+int trw_prepare_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col_idx, int64_t nnz,
+                        int32_t what, void *prepared, size_t prepared_bytes, void *hip_stream);
+size_t trw_walk_csr_prepared_workspace_bytes(int64_t n_walkers, int32_t walk_length, double p, double q,
+                                             int32_t rng_mode);
+int trw_walk_csr_prepared_hip(const void *prepared, size_t prepared_bytes, int32_t what,
+                              const int64_t *row_ptr, int64_t n_nodes,
+                              const int64_t *col_idx, int64_t nnz,
+                              const int64_t *targets, int64_t n_walkers, int64_t walker_base,
+                              double p, double q, int32_t walk_length, int32_t seed, int32_t rng_mode,
+                              int64_t *out, void *workspace, size_t workspace_bytes, void *hip_stream);
+
+/*
  * The host leg of the same walk.  Replaces the reference's
  *     torch::Tensor walk_cpu(row_ptr, column_idx, target_nodes, p, q, walk_length, seed)
  * (csrc/cpu/rw_cpu.h:5-11, called from csrc/rw_init.cpp:22-23 for CPU tensors).  All pointers are HOST
@@ -276,6 +318,14 @@ int trw_walk_status(const void *workspace, void *hip_stream, int64_t status[4]);
 int trw_status_post(const void *workspace, void *hip_stream);
 int trw_status_collect(int wait, int64_t *bits);
 
+/* Helpers for a host layer that keeps a prepared graph across calls and streams (the torch extension's
+ * cache): is `hip_stream` being captured into a HIP graph (1/0); an event recorded on a stream (NULL on
+ * failure), made a dependency of another stream, destroyed. */
+int trw_stream_is_capturing(void *hip_stream);
+void *trw_event_record(void *hip_stream);
+int trw_event_wait(void *event, void *hip_stream);
+void trw_event_destroy(void *event);
+
 /* Integer form of the reference's accept test (rw_cpu.cpp:169-194):
  * (double)r / (double)RAND_MAX < prob  <=>  r < trw_accept_threshold(prob).
  * Host helper, exported so tests can pin it against the fp64 expression. */
@@ -302,6 +352,9 @@ void trw_glibc_window_at(int32_t seed, uint64_t pos, uint32_t window[31]);
  *   (membership tests and the once-per-step location of t in prev's row). */
 int trw_profile_enable(int flags);
 int trw_profile_last(double *prepare_ms, double *walk_ms, double *finish_ms);
+/* Device time of the last trw_prepare_csr_hip since profiling was enabled (reported once; TRW_E_ARG if there
+ * was none -- e.g. the call found its graph in the host layer's cache). */
+int trw_profile_prepare_last(double *prepare_ms);
 int trw_walk_counters(const void *workspace, void *hip_stream, uint64_t counters[4]);
 
 #ifdef __cplusplus

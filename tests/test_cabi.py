@@ -64,20 +64,38 @@ def test_window_reproduces_libc_draws(libc_vectors):
 
 
 def test_workspace_bytes():
+    """One-shot workspace = the call's own scratch (status block, RNG windows) + the prepared-graph blob
+    (256-byte header, uint32 shadow, and by call shape the fat entries / the edge table)."""
     from torch_random_walk_amd import _native
-    f = _native.cabi().trw_walk_csr_workspace_bytes
+    lib = _native.cabi()
+    f = lib.trw_walk_csr_workspace_bytes
     n, nnz, N, L = 10, 20, 1000, 80
+    head = 256 + 256                                                  # status block + prepared header
     shadow = 4 * (n + 1) + 4 * nnz
     stage = 4 * N * (L + 1)
     assert f(n, nnz, 0, 5, 1.0, 1.0, 0) >= 256
-    assert f(n, nnz, N, L, 0.5, 2.0, 1) == 256                        # serial glibc replay: status block only
-    assert f(n, nnz, N, L, 1.0, 1.0, 2) == 256                        # uniform on the walker stream: int64 kernels
+    assert f(n, nnz, N, L, 0.5, 2.0, 1) == head                       # serial glibc replay: int64 kernels, no shadow
+    assert f(n, nnz, N, L, 1.0, 1.0, 2) == head                       # uniform on the walker stream: int64 kernels
     table = 16 * 1024                                                 # edge table: >= 3 slots per edge, >= 1024 slots
-    assert shadow + table <= f(n, nnz, N, L, 0.5, 2.0, 2) - 256 <= shadow + table + 4 * 256   # rows written in place
+    fat = 32 * nnz                                                    # 32-byte entries of the biased walk
+    assert shadow + table + fat <= f(n, nnz, N, L, 0.5, 2.0, 2) - head <= shadow + table + fat + 6 * 256
     uniform = f(n, nnz, N, L, 1.0, 1.0, 0)                            # windows + shadow; rows written in place
-    assert 256 + N * 124 + shadow <= uniform < 256 + N * 124 + shadow + stage
-    assert f(2**31, nnz, N, L, 0.5, 2.0, 2) == 256                    # too many nodes for the uint32 shadow
-    assert f(n, 2**32, N, L, 0.5, 2.0, 2) == 256
+    assert head + N * 124 + shadow <= uniform < head + N * 124 + shadow + stage
+    assert f(2**31, nnz, N, L, 0.5, 2.0, 2) == head                   # too many nodes for the uint32 shadow
+    assert f(n, 2**32, N, L, 0.5, 2.0, 2) == head
+    # the prepared blob by itself, and what a call over it needs
+    g = lib.trw_prepare_csr_bytes
+    assert g(n, nnz, 0) >= 256 + shadow and g(n, nnz, 1) >= g(n, nnz, 0) + 16 * nnz
+    assert g(n, nnz, 2) >= g(n, nnz, 0) + table + fat and g(n, nnz, 2 | 4) > g(n, nnz, 2)
+    assert g(n, nnz, -1) == 256 and g(n, nnz, -2) == 256
+    w = lib.trw_walk_csr_prepared_workspace_bytes
+    assert w(N, L, 0.5, 2.0, 2) == 256 and 256 + N * 124 <= w(N, L, 1.0, 1.0, 0) < 256 + N * 124 + 1024
+    plan = lib.trw_prepare_plan
+    assert plan(n, nnz, N, L, 0.5, 2.0, 2) == 2 and plan(1000, 10**6, 100, L, 0.5, 2.0, 2) == 0
+    assert plan(n, nnz, N, L, 0.5, 2.0, 1) == -1 and plan(n, nnz, N, L, 1.0, 1.0, 2) == -2
+    # a graph the size of BASELINE configs[3] keeps the table path: 2^32 slots (64-bit slot arithmetic)
+    big = g(111_000_000, 1_711_000_000, 2)
+    assert 16 * 2**32 + 32 * 1_711_000_000 < big < 16 * 2**32 + 32 * 1_711_000_000 + 9 * 10**9
 
 
 def test_argument_errors_return_codes_without_touching_the_gpu():

@@ -1,0 +1,232 @@
+"""The prepared graph and its cache (pytest -m gpu): what `rw.walk` keeps between calls over the same tensors,
+when it is invalid, and that every level of preparation walks the same rows."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests.helpers import hub_graph, random_graph
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture()
+def rw():
+    from torch_rw import rw as _rw
+    _rw.clear_cache()
+    _rw.set_cache(True, 2)
+    yield _rw
+    _rw.clear_cache()
+    _rw.set_cache(True, 2)
+
+
+def _dev(*arrays):
+    return [torch.as_tensor(np.asarray(a), dtype=torch.int64).to(DEV) for a in arrays]
+
+
+def test_second_walk_reuses_the_prepared_graph_and_third_has_full_marks(rw):
+    rp, ci = hub_graph(3000, 6)
+    tg = np.random.default_rng(2).integers(0, 3000, 20_000)
+    d_rp, d_ci, d_tg = _dev(rp, ci, tg)
+    ref = O.walk(rp, ci, tg, 0.25, 4.0, 30, 10, rng_mode=O.RNG_WALKER)
+    assert rw.cache_info() == []
+    w1 = rw.walk(d_rp, d_ci, d_tg, 0.25, 4.0, 30, 10)
+    info = rw.cache_info()
+    assert len(info) == 1 and info[0][:2] == (3000, len(ci)) and info[0][2] == rw.PREP_BIASED and info[0][4] == 1
+    w2 = rw.walk(d_rp, d_ci, d_tg, 0.25, 4.0, 30, 10)            # second node2vec walk: upgrade to full marks
+    info = rw.cache_info()
+    assert len(info) == 1 and info[0][2] == rw.PREP_BIASED | rw.PREP_MARKS and info[0][4] == 2
+    blob_bytes = info[0][3]
+    w3 = rw.walk(d_rp, d_ci, d_tg, 0.25, 4.0, 30, 10)            # served from the cache as it is
+    assert rw.cache_info()[0][3] == blob_bytes and rw.cache_info()[0][4] == 3
+    for w in (w1, w2, w3):
+        assert (w.cpu().numpy() == ref).all()
+    # a uniform walk over the same graph shares the entry (its shadow); fat entries join when they pay
+    u = rw.walk(d_rp, d_ci, d_tg, 1.0, 1.0, 30, 10)
+    assert (u.cpu().numpy() == O.walk(rp, ci, tg, 1.0, 1.0, 30, 10)).all()
+    assert len(rw.cache_info()) == 1
+    # other (p, q), other batch, walker_base: the prepared graph depends on none of them
+    for p, q in ((4.0, 0.25), (0.7, 0.5), (1.0, 1.0 + 1e-12)):
+        got = rw.walk_ex(d_rp, d_ci, d_tg[:777], p, q, 17, 3, walker_base=5000, rng_mode=rw.RNG_WALKER)
+        assert (got.cpu().numpy() == O.walk(rp, ci, tg[:777], p, q, 17, 3, rng_mode=O.RNG_WALKER, walker_base=5000)).all()
+    rw.check_status()
+
+
+def test_in_place_write_invalidates(rw):
+    rp, ci = random_graph(400, 6, 3)
+    tg = np.arange(400).repeat(20)
+    d_rp, d_ci, d_tg = _dev(rp, ci, tg)
+    for p, q, omode in ((0.25, 4.0, O.RNG_WALKER), (1.0, 1.0, O.RNG_GLIBC_SEQ)):
+        mode = rw.RNG_WALKER if omode == O.RNG_WALKER else rw.RNG_GLIBC
+        for _ in range(3):
+            rw.walk_ex(d_rp, d_ci, d_tg, p, q, 20, 7, rng_mode=mode)
+        # rewire: every row's entries reversed (rows stay sorted? no -- so re-sort each row descending->ascending of n-1-x)
+        ci2 = ci.copy()
+        n = 400
+        for v in range(n):
+            ci2[rp[v]:rp[v + 1]] = np.sort((ci[rp[v]:rp[v + 1]] * 7 + 3) % n)
+        d_ci.copy_(torch.as_tensor(ci2).to(DEV))                 # in place: same storage, new version
+        got = rw.walk_ex(d_rp, d_ci, d_tg, p, q, 20, 7, rng_mode=mode).cpu().numpy()
+        assert (got == O.walk(rp, ci2, tg, p, q, 20, 7, rng_mode=omode)).all(), "stale prepared graph was used"
+        d_ci.copy_(torch.as_tensor(ci).to(DEV))
+        got = rw.walk_ex(d_rp, d_ci, d_tg, p, q, 20, 7, rng_mode=mode).cpu().numpy()
+        assert (got == O.walk(rp, ci, tg, p, q, 20, 7, rng_mode=omode)).all()
+
+
+def test_entries_die_with_their_tensors_and_lru(rw):
+    graphs = [random_graph(300 + 10 * k, 5, k) for k in range(4)]
+    devs = [_dev(rp, ci) for rp, ci in graphs]
+    tg = torch.arange(300, device=DEV).repeat(4)
+    for d in devs[:3]:
+        rw.walk(d[0], d[1], tg, 0.5, 2.0, 10, 1)
+    assert [i[0] for i in rw.cache_info()] == [320, 310]                  # capacity 2, most recent first
+    rw.set_cache(True, 3)
+    rw.walk(devs[0][0], devs[0][1], tg, 0.5, 2.0, 10, 1)
+    assert [i[0] for i in rw.cache_info()] == [300, 320, 310]
+    del devs[2]
+    rw.walk(devs[0][0], devs[0][1], tg, 0.5, 2.0, 10, 1)                  # the dead graph's entry goes at the next call
+    assert [i[0] for i in rw.cache_info()] == [300, 310]
+    # a NEW graph in freed-and-reused memory never matches an old entry: the key holds weak storage references
+    rp, ci = graphs[1]
+    ptr = devs[1][1].data_ptr()
+    del devs[1]
+    torch.cuda.synchronize()
+    ci_new = ((torch.as_tensor(ci) + 1) % 310).to(DEV)
+    rp_new = torch.as_tensor(rp).to(DEV)
+    ci_sorted = ci_new.cpu().numpy().copy()
+    for v in range(310):
+        ci_sorted[rp[v]:rp[v + 1]] = np.sort(ci_sorted[rp[v]:rp[v + 1]])
+    ci_new.copy_(torch.as_tensor(ci_sorted))
+    got = rw.walk_ex(rp_new, ci_new, tg, 0.5, 2.0, 10, 1, rng_mode=rw.RNG_WALKER).cpu().numpy()
+    assert (got == O.walk(rp, ci_sorted, tg.cpu().numpy(), 0.5, 2.0, 10, 1, rng_mode=O.RNG_WALKER)).all()
+    assert ptr  # (whether the allocator reused the address or not, the walk above had to be right)
+    rw.clear_cache()
+    assert rw.cache_info() == []
+
+
+@pytest.mark.parametrize("deg,inline_cap", [(5, None), (60, None), (60, "0"), (150, None), (150, "4096"), (150, "0")])
+def test_every_marking_path_walks_the_same_rows(rw, deg, inline_cap, monkeypatch):
+    """Masks worked out by the owning thread (short rows), by the wave-per-entry pass (rows of 33..4096), exact
+    (rows <= 128) and as filters (longer rows: set bits ask the table), or not at all (cap 0 without marks)."""
+    if inline_cap is not None:
+        monkeypatch.setenv("TRW_COMMON_MAX", inline_cap)
+    rp, ci = random_graph(400, deg, 11)
+    tg = np.random.default_rng(1).integers(0, 400, 5000)
+    d_rp, d_ci, d_tg = _dev(rp, ci, tg)
+    for p, q in ((0.25, 4.0), (4.0, 0.25)):
+        ref = O.walk(rp, ci, tg, p, q, 25, 9, rng_mode=O.RNG_WALKER)
+        rw.clear_cache()
+        cold = rw.walk_ex(d_rp, d_ci, d_tg, p, q, 25, 9, rng_mode=rw.RNG_WALKER)          # cheap marks
+        warm = rw.walk_ex(d_rp, d_ci, d_tg, p, q, 25, 9, rng_mode=rw.RNG_WALKER)          # full marks (second walk)
+        assert rw.cache_info()[0][2] & rw.PREP_MARKS
+        assert (cold.cpu().numpy() == ref).all() and (warm.cpu().numpy() == ref).all()
+    rw.clear_cache()
+    assert rw.prepare(d_rp, d_ci) == rw.PREP_BIASED | rw.PREP_MARKS
+    assert (rw.walk(d_rp, d_ci, d_tg, 0.25, 4.0, 25, 9).cpu().numpy() == O.walk(rp, ci, tg, 0.25, 4.0, 25, 9, rng_mode=O.RNG_WALKER)).all()
+    assert rw.prepare(d_rp, d_ci, biased=False, marks=False, uniform=True) == rw.PREP_BIASED | rw.PREP_MARKS | rw.PREP_UNIFORM
+
+
+@pytest.mark.parametrize("env", [{"TRW_MASK_KERNEL": "0"}, {"TRW_MASK_KERNEL": "0", "TRW_NO_POS": "1"},
+                                 {"TRW_RESIDENT_BLOCKS": "1"}, {"TRW_HASH_SLACK": "2", "TRW_RESIDENT_BLOCKS": "8"}])
+def test_mask_kernel_and_state_machine_kernel_agree(rw, env, monkeypatch):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rp, ci = hub_graph(800, 5)
+    tg = np.random.default_rng(9).integers(0, 800, 4000)
+    d = _dev(rp, ci, tg)
+    for p, q in ((0.25, 4.0), (4.0, 0.25), (0.7, 0.5)):
+        ref = O.walk(rp, ci, tg, p, q, 30, 10, rng_mode=O.RNG_WALKER)
+        for _ in range(2):
+            assert (rw.walk_ex(*d, p, q, 30, 10, rng_mode=rw.RNG_WALKER).cpu().numpy() == ref).all()
+
+
+def test_cache_off_and_capture_bypass(rw):
+    rp, ci = hub_graph(2000, 6)
+    tg = np.random.default_rng(2).integers(0, 2000, 20_000)
+    d_rp, d_ci, d_tg = _dev(rp, ci, tg)
+    ref = O.walk(rp, ci, tg, 0.25, 4.0, 20, 10, rng_mode=O.RNG_WALKER)
+    rw.set_cache(False)
+    assert (rw.walk(d_rp, d_ci, d_tg, 0.25, 4.0, 20, 10).cpu().numpy() == ref).all() and rw.cache_info() == []
+    rw.set_cache(True)
+    rw.walk_ex(d_rp, d_ci, d_tg[:8], 1.0, 1.0, 20, 10)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            rw.walk_ex(d_rp, d_ci, d_tg, 0.25, 4.0, 20, 10, rng_mode=rw.RNG_WALKER, check=False)
+    torch.cuda.current_stream().wait_stream(s)
+    before = rw.cache_info()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        wb = rw.walk_ex(d_rp, d_ci, d_tg, 0.25, 4.0, 20, 10, rng_mode=rw.RNG_WALKER, check=False)
+    assert rw.cache_info() == before                              # a captured call prepares for itself
+    rw.clear_cache()                                              # ... so the graph survives the cache being dropped
+    for _ in range(2):
+        wb.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert (wb.cpu().numpy() == ref).all()
+
+
+def test_prepared_graph_from_another_stream_and_thread(rw):
+    import threading
+    rp, ci = hub_graph(3000, 7)
+    d_rp, d_ci = _dev(rp, ci)
+    tg = np.random.default_rng(4).integers(0, 3000, 30_000)
+    d_tg = torch.as_tensor(tg).to(DEV)
+    ref = O.walk(rp, ci, tg, 0.25, 4.0, 25, 3, rng_mode=O.RNG_WALKER)
+    errors = []
+
+    def worker(k):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(5):                                # first arrivals build / upgrade, the others reuse
+                    got = rw.walk_ex(d_rp, d_ci, d_tg, 0.25, 4.0, 25, 3, rng_mode=rw.RNG_WALKER)
+                    if not (got.cpu().numpy() == ref).all():
+                        errors.append("thread %d differs" % k)
+        except Exception as e:      # noqa: BLE001
+            errors.append("thread %d: %r" % (k, e))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert len(rw.cache_info()) == 1 and rw.cache_info()[0][4] == 15
+
+
+def test_prepared_c_abi_direct(rw):
+    """trw_prepare_csr_hip + trw_walk_csr_prepared_hip with raw pointers, every `what`."""
+    from torch_random_walk_amd import _native
+    L = _native.cabi()
+    rp, ci = hub_graph(700, 8)
+    tg = np.random.default_rng(8).integers(0, 700, 3000)
+    d_rp, d_ci, d_tg = _dev(rp, ci, tg)
+    stream = torch.cuda.current_stream().cuda_stream
+    n, nnz, N, Lw = 700, len(ci), 3000, 30
+    for what in (0, 1, 2, 6, 7, -1, -2):
+        pb = L.trw_prepare_csr_bytes(n, nnz, what)
+        blob = torch.empty(pb, dtype=torch.uint8, device=DEV)
+        assert L.trw_prepare_csr_hip(d_rp.data_ptr(), n, d_ci.data_ptr(), nnz, what, blob.data_ptr(), pb, stream) == 0
+        for p, q, mode, omode in ((1.0, 1.0, 1, O.RNG_GLIBC_SEQ), (0.25, 4.0, 2, O.RNG_WALKER), (1.0, 1.0, 2, O.RNG_WALKER)):
+            out = torch.empty((N, Lw + 1), dtype=torch.int64, device=DEV)
+            wb = L.trw_walk_csr_prepared_workspace_bytes(N, Lw, p, q, mode)
+            ws = torch.empty(wb, dtype=torch.uint8, device=DEV)
+            rc = L.trw_walk_csr_prepared_hip(blob.data_ptr(), pb, what, d_rp.data_ptr(), n, d_ci.data_ptr(), nnz,
+                                             d_tg.data_ptr(), N, 0, p, q, Lw, 10, mode, out.data_ptr(), ws.data_ptr(),
+                                             wb, stream)
+            if what == -2 and p != 1.0:                            # no row-order probe: refused for a biased walk
+                assert rc == -1
+                continue
+            assert rc == 0, L.trw_last_error()
+            st = (ctypes.c_int64 * 4)()
+            assert L.trw_walk_status(ws.data_ptr(), stream, st) == 0 and st[0] == 0
+            assert (out.cpu().numpy() == O.walk(rp, ci, tg, p, q, Lw, 10, rng_mode=omode)).all(), (what, p, q, mode)
+            if what in (2, 6, 7) and mode == 2 and p != 1.0:
+                assert st[3] == 4                                  # the mask kernel

@@ -49,6 +49,17 @@ def cabi():
         L.trw_walk_edge_list_hip.argtypes = [vp, i64, vp, i64, vp, i64, i64, dbl, dbl, i32, i32, i64, i32, i32, vp,
                                              vp, ctypes.c_size_t, vp]
         L.trw_walk_edge_list_hip.restype = ctypes.c_int
+        L.trw_prepare_plan.argtypes = [i64, i64, i64, i32, dbl, dbl, i32]
+        L.trw_prepare_plan.restype = ctypes.c_int32
+        L.trw_prepare_csr_bytes.argtypes = [i64, i64, i32]
+        L.trw_prepare_csr_bytes.restype = ctypes.c_size_t
+        L.trw_prepare_csr_hip.argtypes = [vp, i64, vp, i64, i32, vp, ctypes.c_size_t, vp]
+        L.trw_prepare_csr_hip.restype = ctypes.c_int
+        L.trw_walk_csr_prepared_workspace_bytes.argtypes = [i64, i32, dbl, dbl, i32]
+        L.trw_walk_csr_prepared_workspace_bytes.restype = ctypes.c_size_t
+        L.trw_walk_csr_prepared_hip.argtypes = [vp, ctypes.c_size_t, i32, vp, i64, vp, i64, vp, i64, i64, dbl, dbl,
+                                                i32, i32, i32, vp, vp, ctypes.c_size_t, vp]
+        L.trw_walk_csr_prepared_hip.restype = ctypes.c_int
         L.trw_walk_csr_cpu.argtypes = [vp, i64, vp, i64, vp, i64, i64, dbl, dbl, i32, i32, i32, vp, i32]
         L.trw_walk_csr_cpu.restype = ctypes.c_int
         L.trw_status_post.argtypes = [vp, vp]
@@ -65,6 +76,8 @@ def cabi():
         L.trw_profile_enable.restype = ctypes.c_int
         L.trw_profile_last.argtypes = [ctypes.POINTER(ctypes.c_double)] * 3
         L.trw_profile_last.restype = ctypes.c_int
+        L.trw_profile_prepare_last.argtypes = [ctypes.POINTER(ctypes.c_double)]
+        L.trw_profile_prepare_last.restype = ctypes.c_int
         L.trw_walk_counters.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_uint64)]
         L.trw_walk_counters.restype = ctypes.c_int
         _cabi = L

@@ -25,6 +25,9 @@
 #include <ATen/Parallel.h>
 
 #include <atomic>
+#include <cstdlib>
+#include <list>
+#include <mutex>
 #include <string>
 
 #include "../../include/trw.h"
@@ -122,6 +125,157 @@ torch::Tensor walk_cpu_leg(const torch::Tensor &row_ptr, const torch::Tensor &co
     return walks;
 }
 
+// ---- prepared graphs, kept across calls --------------------------------------------------------------------
+// What a walk derives from (row_ptr, col_idx) alone (uint32 shadow, fat entries, edge table, neighbourhood
+// masks: trw_prepare_csr_hip) is cached per graph, so the second and later walks over the same tensors start at
+// the walk kernel (SURVEY 8(b) "Ownership": cached derived data keyed on data_ptr/version).  An entry is valid for
+// exactly the storages it was built from, while they are alive (weak references: a freed-and-reused address can
+// not match) and unmodified (tensor version counters: an in-place write invalidates).  Policy: the first walk
+// builds what a single call of its shape is worth; the second node2vec walk over the same graph also builds the
+// full neighbourhood masks (TRW_PREP_MARKS: about 5x the prepare time, then every later walk is faster);
+// rw.prepare() asks for them up front.  Least-recently-used graphs beyond `capacity` are dropped; entries whose
+// tensors died are dropped at the next call.  TRW_CACHE=0 (or set_cache(False)) turns the cache off: every
+// call then prepares into its own workspace, as trw_walk_csr_hip does.  Calls on a stream that is being captured
+// into a HIP graph never use the cache (a replay must not depend on memory the cache may drop).
+struct PreparedGraph {
+    c10::weak_intrusive_ptr<c10::StorageImpl> rp_storage, ci_storage;
+    const void *rp_ptr = nullptr, *ci_ptr = nullptr;
+    int64_t rp_numel = 0, ci_numel = 0;
+    uint32_t rp_version = 0, ci_version = 0;
+    c10::Device device{c10::kCPU};
+    int32_t what = 0;
+    torch::Tensor blob;
+    void *ready = nullptr;        // event recorded after the prepare kernels
+    void *built_on = nullptr;     // the stream they ran on
+    int64_t biased_walks = 0;
+    bool pinned = false;          // rw.prepare(): not upgraded/evicted behind the caller's back
+    PreparedGraph(c10::weak_intrusive_ptr<c10::StorageImpl> a, c10::weak_intrusive_ptr<c10::StorageImpl> b)
+        : rp_storage(std::move(a)), ci_storage(std::move(b)) {}
+    ~PreparedGraph() { trw_event_destroy(ready); }
+};
+
+std::mutex g_cache_mu;
+std::list<std::shared_ptr<PreparedGraph>> g_cache;  // most recently used first
+std::atomic<int64_t> g_cache_capacity{2};
+std::atomic<int> g_cache_on{-1};  // -1: not decided yet (TRW_CACHE)
+
+bool cache_enabled()
+{
+    int v = g_cache_on.load();
+    if (v < 0) {
+        const char *env = std::getenv("TRW_CACHE");
+        v = (env && env[0] == '0') ? 0 : 1;
+        g_cache_on.store(v);
+    }
+    return v == 1;
+}
+
+bool cacheable(const torch::Tensor &t) { return !t.is_inference() && t.has_storage(); }
+
+bool entry_matches(const PreparedGraph &e, const torch::Tensor &rp, const torch::Tensor &ci)
+{
+    const auto a = e.rp_storage.lock(), b = e.ci_storage.lock();
+    return a && b && a.get() == rp.storage().unsafeGetStorageImpl() && b.get() == ci.storage().unsafeGetStorageImpl() &&
+           e.rp_ptr == rp.data_ptr() && e.ci_ptr == ci.data_ptr() && e.rp_numel == rp.numel() &&
+           e.ci_numel == ci.numel() && e.rp_version == rp._version() && e.ci_version == ci._version() &&
+           e.device == rp.device();
+}
+
+// (Re)builds the prepared blob of `entry` with `what`; falls back to leaner layouts when the device is short of
+// memory (each part is optional: the walk then takes the kernel that does without it).
+void build_blob(PreparedGraph &entry, const torch::Tensor &rp, const torch::Tensor &ci, int32_t what, void *stream)
+{
+    const int64_t n_nodes = rp.numel() - 1, nnz = ci.numel();
+    const int32_t ladder[4] = {what, (int32_t)(what & ~TRW_PREP_MARKS), (int32_t)(what & TRW_PREP_UNIFORM), 0};
+    for (int k = 0; k < 4; ++k) {
+        const int32_t w = ladder[k];
+        if (k > 0 && w == ladder[k - 1]) continue;
+        const size_t bytes = trw_prepare_csr_bytes(n_nodes, nnz, w);
+        torch::Tensor blob;
+        try {
+            blob = torch::empty({(int64_t)bytes}, rp.options().dtype(torch::kUInt8));
+        } catch (const c10::OutOfMemoryError &) {
+            if (k == 3) throw;
+            continue;  // (the allocator has already given its cached blocks back before throwing)
+        }
+        const int rc = trw_prepare_csr_hip(rp.data_ptr<int64_t>(), n_nodes, ci.data_ptr<int64_t>(), nnz, w,
+                                           blob.data_ptr(), bytes, stream);
+        TORCH_CHECK(rc == TRW_OK, "torch_rw prepare failed (", rc, "): ", trw_last_error());
+        trw_event_destroy(entry.ready);
+        entry.ready = trw_event_record(stream);
+        entry.built_on = stream;
+        entry.blob = blob;
+        entry.what = w;
+        return;
+    }
+}
+
+// What one call takes from the cache: its own reference to the blob (an upgrade by another thread replaces the
+// entry's tensor, never the memory under a running call) and the layout flags that go with it.
+struct PreparedUse {
+    torch::Tensor blob;
+    int32_t what = 0;
+    bool valid = false;
+};
+
+// The prepared graph for this call (built or upgraded as needed); !valid when the call should prepare for
+// itself (cache off, capture in progress, uncacheable tensors).
+PreparedUse prepared_for(const torch::Tensor &rp, const torch::Tensor &ci, int32_t needed, bool biased_walk, bool pin,
+                         const c10::hip::HIPStreamMasqueradingAsCUDA &torch_stream)
+{
+    void *const stream = (void *)torch_stream.stream();
+    PreparedUse use;
+    if (!cache_enabled() || !cacheable(rp) || !cacheable(ci) || trw_stream_is_capturing(stream)) return use;
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    std::shared_ptr<PreparedGraph> hit;
+    for (auto it = g_cache.begin(); it != g_cache.end();) {
+        if (entry_matches(**it, rp, ci)) {
+            hit = *it;
+            it = g_cache.erase(it);
+        } else if ((*it)->rp_storage.expired() || (*it)->ci_storage.expired()) {
+            it = g_cache.erase(it);  // its graph is gone
+        } else {
+            ++it;
+        }
+    }
+    if (!hit) {
+        hit = std::make_shared<PreparedGraph>(rp.storage().getWeakStorageImpl(), ci.storage().getWeakStorageImpl());
+        hit->rp_ptr = rp.data_ptr();
+        hit->ci_ptr = ci.data_ptr();
+        hit->rp_numel = rp.numel();
+        hit->ci_numel = ci.numel();
+        hit->rp_version = rp._version();
+        hit->ci_version = ci._version();
+        hit->device = rp.device();
+        hit->what = -100;  // nothing built yet
+    }
+    int32_t want = needed < 0 ? 0 : needed;
+    if (hit->what >= 0) want |= hit->what;
+    // the second node2vec walk over a graph is the sign that it is walked repeatedly: worth the full masks
+    if (biased_walk && (want & TRW_PREP_BIASED) && hit->biased_walks >= 1) want |= TRW_PREP_MARKS;
+    if (want & TRW_PREP_MARKS) want |= TRW_PREP_BIASED;
+    if (hit->what < 0 || (want & ~hit->what) != 0) build_blob(*hit, rp, ci, want, stream);
+    if (biased_walk) ++hit->biased_walks;
+    hit->pinned = hit->pinned || pin;
+    g_cache.push_front(hit);
+    const int64_t cap = g_cache_capacity.load();
+    while ((int64_t)g_cache.size() > (cap < 1 ? 1 : cap)) {
+        auto victim = std::prev(g_cache.end());
+        while (victim != g_cache.begin() && (*victim)->pinned) --victim;
+        if (victim == g_cache.begin()) break;  // only pinned graphs (and this call's) left
+        g_cache.erase(victim);
+    }
+    if (hit->built_on != stream) {  // built on another stream: order after it, keep the blob alive for this one
+        const int rc = trw_event_wait(hit->ready, stream);
+        TORCH_CHECK(rc == TRW_OK, "torch_rw: ", trw_last_error());
+        hit->blob.record_stream(torch_stream.unwrap());
+    }
+    use.blob = hit->blob;
+    use.what = hit->what;
+    use.valid = true;
+    return use;
+}
+
 // walk_ex: the reference's seven arguments plus what this library adds (global walker base, RNG mode,
 // status check, and an optional destination: a contiguous int64 [N, L+1] tensor to walk into -- e.g. a
 // shard's slice of the gathered result).
@@ -165,20 +319,57 @@ torch::Tensor walk_ex(const torch::Tensor &row_ptr, const torch::Tensor &col_idx
         walks = torch::empty({n_walkers, walk_length + 1}, rp.options());
     }
 
-    const size_t ws_bytes =
-        trw_walk_csr_workspace_bytes(n_nodes, nnz, n_walkers, (int32_t)walk_length, p, q, (int32_t)rng_mode);
-    auto workspace = torch::empty({(int64_t)ws_bytes}, rp.options().dtype(torch::kUInt8));
+    void *const hs = (void *)stream.stream();
+    // what a call of this shape is worth preparing; < 0: it runs the int64 kernels and wants no shadow at all
+    const int32_t needed = trw_prepare_plan(n_nodes, nnz, n_walkers, (int32_t)walk_length, p, q, (int32_t)rng_mode);
+    const bool biased_parallel = !(p == 1.0 && q == 1.0) && needed != TRW_PREP_ORDER_ONLY;
+    PreparedUse prepared;
+    // (a strided input was copied by .contiguous() above: a temporary is not worth a cache entry)
+    if (n_walkers > 0 && needed >= 0 && rp.is_same(row_ptr) && ci.is_same(col_idx))
+        prepared = prepared_for(rp, ci, needed, biased_parallel, false, stream);
 
+    torch::Tensor workspace;
     int rc;
-    {
+    if (prepared.valid) {
+        const size_t ws_bytes =
+            trw_walk_csr_prepared_workspace_bytes(n_walkers, (int32_t)walk_length, p, q, (int32_t)rng_mode);
+        workspace = torch::empty({(int64_t)ws_bytes}, rp.options().dtype(torch::kUInt8));
+        pybind11::gil_scoped_release nogil;
+        rc = trw_walk_csr_prepared_hip(prepared.blob.data_ptr(), (size_t)prepared.blob.numel(), prepared.what,
+                                       rp.data_ptr<int64_t>(), n_nodes, ci.data_ptr<int64_t>(), nnz,
+                                       tg.data_ptr<int64_t>(), n_walkers, walker_base, p, q, (int32_t)walk_length,
+                                       (int32_t)seed, (int32_t)rng_mode, walks.data_ptr<int64_t>(),
+                                       workspace.data_ptr(), ws_bytes, hs);
+    } else {
+        const size_t ws_bytes =
+            trw_walk_csr_workspace_bytes(n_nodes, nnz, n_walkers, (int32_t)walk_length, p, q, (int32_t)rng_mode);
+        workspace = torch::empty({(int64_t)ws_bytes}, rp.options().dtype(torch::kUInt8));
         pybind11::gil_scoped_release nogil;
         rc = trw_walk_csr_hip(rp.data_ptr<int64_t>(), n_nodes, ci.data_ptr<int64_t>(), nnz, tg.data_ptr<int64_t>(),
                               n_walkers, walker_base, p, q, (int32_t)walk_length, (int32_t)seed, (int32_t)rng_mode,
-                              walks.data_ptr<int64_t>(), workspace.data_ptr(), ws_bytes, (void *)stream.stream());
+                              walks.data_ptr<int64_t>(), workspace.data_ptr(), ws_bytes, hs);
     }
     TORCH_CHECK(rc == TRW_OK, "torch_rw walk failed (", rc, "): ", trw_last_error());
-    finish_status(workspace, (void *)stream.stream(), check_mode, "walk");
+    finish_status(workspace, hs, check_mode, "walk");
     return walks;
+}
+
+// rw.prepare(): build (or upgrade) the cached prepared graph now; returns the TRW_PREP_* bits it holds.
+int64_t prepare(const torch::Tensor &row_ptr, const torch::Tensor &col_idx, int64_t what)
+{
+    check_index_tensor(row_ptr, "row_ptr");
+    check_index_tensor(col_idx, "col_idx");
+    TORCH_CHECK(row_ptr.device() == col_idx.device(), "row_ptr and col_idx must be on the same device");
+    TORCH_CHECK(row_ptr.numel() >= 1, "row_ptr must have num_nodes + 1 entries");
+    TORCH_CHECK(row_ptr.is_contiguous() && col_idx.is_contiguous(),
+                "prepare() keys on the tensors' storage: row_ptr and col_idx must be contiguous");
+    TORCH_CHECK(what >= 0 && what <= (TRW_PREP_UNIFORM | TRW_PREP_BIASED | TRW_PREP_MARKS), "unknown prepare flags ", what);
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(row_ptr.device());
+    const auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(row_ptr.device().index());
+    TORCH_CHECK(cache_enabled(), "the prepared-graph cache is switched off (TRW_CACHE=0 / set_cache(False))");
+    const auto entry = prepared_for(row_ptr, col_idx, (int32_t)what, false, true, stream);
+    TORCH_CHECK(entry.valid, "this graph cannot be cached (inference tensors, or the stream is being captured)");
+    return (int64_t)entry.what;
 }
 
 // The reference's signature, verbatim (rw_init.cpp:11-17).
@@ -478,6 +669,30 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           pybind11::arg("walk_length"), pybind11::arg("padding_idx"), pybind11::arg("restart"), pybind11::arg("seed"),
           pybind11::arg("walker_base") = 0, pybind11::arg("rng_mode") = (int64_t)TRW_RNG_AUTO,
           pybind11::arg("check") = (int64_t)-1);
+    m.def("prepare", &prepare, "build the cached prepared graph of (row_ptr, col_idx) now", pybind11::arg("row_ptr"),
+          pybind11::arg("col_idx"), pybind11::arg("what"));
+    m.def("set_cache", [](bool on, int64_t capacity) {
+        g_cache_on.store(on ? 1 : 0);
+        if (capacity > 0) g_cache_capacity.store(capacity);
+        if (!on) {
+            std::lock_guard<std::mutex> lock(g_cache_mu);
+            g_cache.clear();
+        }
+    }, pybind11::arg("on"), pybind11::arg("capacity") = (int64_t)0);
+    m.def("clear_cache", []() {
+        std::lock_guard<std::mutex> lock(g_cache_mu);
+        g_cache.clear();
+    });
+    m.def("cache_info", []() {
+        std::lock_guard<std::mutex> lock(g_cache_mu);
+        std::vector<std::tuple<int64_t, int64_t, int64_t, int64_t, int64_t>> out;
+        for (const auto &e : g_cache)
+            out.emplace_back(e->rp_numel - 1, e->ci_numel, (int64_t)e->what, (int64_t)e->blob.numel(), e->biased_walks);
+        return out;
+    });
+    m.attr("PREP_UNIFORM") = (int64_t)TRW_PREP_UNIFORM;
+    m.attr("PREP_BIASED") = (int64_t)TRW_PREP_BIASED;
+    m.attr("PREP_MARKS") = (int64_t)TRW_PREP_MARKS;
     m.def("set_rng_mode", [](int64_t mode) {
         TORCH_CHECK(mode == TRW_RNG_AUTO || mode == TRW_RNG_GLIBC || mode == TRW_RNG_WALKER, "unknown rng mode ", mode);
         g_rng_mode.store((int)mode);

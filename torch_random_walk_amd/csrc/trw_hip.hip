@@ -113,90 +113,121 @@ int resolve_mode(int32_t rng_mode, bool uniform, int64_t n_walkers, int64_t walk
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// Where everything lives in the caller's workspace for one call shape.
-struct Plan {
+// ---- the prepared graph --------------------------------------------------------------------------
+// Everything a walk derives from (row_ptr, col_idx) alone -- validation, the uint32 shadow, fat entries,
+// the edge table -- lives in ONE blob whose layout is a function of (n_nodes, nnz, what).  A one-shot call
+// builds it inside its workspace; a caller that walks a graph more than once builds it once
+// (trw_prepare_csr_hip) and hands it to trw_walk_csr_prepared_hip.
+struct PrepLayout {
     bool narrow = false;   // uint32 shadow kernels (n_nodes < 2^31, nnz < 2^32)
-    bool windows = false;  // glibc jump-ahead windows needed
-    int32_t G = 1;         // walkers chained per lane (uniform glibc)
-    int64_t nlanes = 0;
-    bool hash = false;     // biased: edge hash table + state-machine kernel
-    bool ext = false;      // uniform: fat entries {v, start(v), deg(v)}, one gather per step
-    uint32_t hash_mask = 0;
-    size_t off_win = 0, off_row32 = 0, off_col32 = 0, off_table = 0, off_ext = 0, total = 0;
+    bool ext16 = false;    // uniform: fat entries {v, start(v), deg(v)}, one gather per step
+    bool biased = false;   // edge table + 32-byte fat entries
+    bool marks = false;    // ... with the neighbourhood masks worked out for long rows too
+    uint64_t hash_mask = 0;
+    uint32_t heavy_room = 0;
+    size_t off_row32 = 0, off_col32 = 0, off_ext16 = 0, off_table = 0, off_ext32 = 0, off_heavy = 0, total = 0;
 };
 
-Plan make_plan(int64_t n_nodes, int64_t nnz, int64_t n_walkers, int32_t L, bool uniform, int32_t rng_mode)
+bool graph_fits_narrow(int64_t n_nodes, int64_t nnz)
 {
-    Plan pl;
-    size_t off = kStatusBytes;
-    if (n_walkers <= 0 || L < 1) {
-        pl.total = off;
-        return pl;
-    }
-    const bool may_glibc = rng_mode != TRW_RNG_WALKER;
-    const bool may_walker = rng_mode != TRW_RNG_GLIBC;
-    const bool fits = n_nodes < ((int64_t)1 << 31) && nnz < ((int64_t)1 << 32) - 64 &&
-                      env_long("TRW_FORCE_WIDE", 0, 1, 0) == 0;
-    pl.G = uniform ? glibc_chain_length(n_walkers) : 1;
-    pl.nlanes = (n_walkers + pl.G - 1) / pl.G;
-    if (uniform && may_glibc) {
-        pl.windows = true;
-        pl.off_win = off;
-        off += align_up((size_t)pl.nlanes * kGlDeg * sizeof(uint32_t), 256);
-    }
-    // the narrow kernels serve: uniform on the glibc stream, biased on the walker stream
-    // (uniform_glibc_rows_kernel addresses a wave's 64 rows with a 32-bit byte offset)
-    const bool rows_fit = (int64_t)64 * pl.G * ((int64_t)L + 1) < ((int64_t)1 << 29);
-    pl.narrow = fits && ((uniform && may_glibc && rows_fit) || (!uniform && may_walker));
+    return n_nodes < ((int64_t)1 << 31) && nnz < ((int64_t)1 << 32) - 64 && env_long("TRW_FORCE_WIDE", 0, 1, 0) == 0;
+}
+
+// Slots of the edge table: a power of two, at least `TRW_HASH_SLACK` (default 3) per edge, i.e. load factor
+// <= 1/3 -- relaxed towards 1/2 for graphs whose table would pass 48 GB (1.7e9 entries: 2^32 slots, 69 GB).
+uint64_t edge_table_slots(int64_t nnz)
+{
+    const uint64_t slack = (uint64_t)env_long("TRW_HASH_SLACK", 2, 16, 3);
+    uint64_t cap = 1024;
+    while (cap < slack * (uint64_t)nnz) cap <<= 1;
+    while (cap * 16 > ((uint64_t)48 << 30) && (cap >> 1) >= 2 * (uint64_t)nnz) cap >>= 1;
+    return cap;
+}
+
+PrepLayout make_prep_layout(int64_t n_nodes, int64_t nnz, int32_t what)
+{
+    PrepLayout pl;
+    size_t off = kStatusBytes;  // the header: validation bits and the row-order counters, written by the shadow pass
+    pl.narrow = graph_fits_narrow(n_nodes, nnz) && what >= 0;
     if (pl.narrow) {
         pl.off_row32 = off;
         off += align_up((size_t)(n_nodes + 1 + 4) * sizeof(uint32_t), 256);  // +4: 16-byte gathers at the last node
         pl.off_col32 = off;
         off += align_up((size_t)nnz * sizeof(uint32_t) + 64, 256);
-        // Fat entries cost one pass over the graph per call too: worth it when the batch takes more steps
-        // than the graph has entries (TRW_EXT=0/1 forces).
-        if (uniform) {
-            const long forced = env_long("TRW_EXT", 0, 1, -1);
-            // measured: 15.1 vs 22.6 ms on a 480 MB shadow (R-MAT 10M/110M), 1.14 vs 0.82 ms on a 4.8 MB one
-            // (ER 100k/1.1M, cache resident): the compact shadow wins while it fits the caches
-            const bool big = (size_t)(n_nodes + nnz) * 4 > ((size_t)32 << 20);  // the XCDs' aggregate L2
-            // R-MAT 10M/110M, L=80: 1M walkers 3.1 ms compact / 3.2 ms fat, 2.75M walkers 7.6 / 6.1, 10M 26.5 / 18.1
-            const bool worth = big && (__int128)n_walkers * L >= (__int128)nnz;
-            if (forced == 1 || (forced == -1 && worth)) {
-                pl.ext = true;
-                pl.off_ext = off;
-                off += align_up((size_t)nnz * 16 + 64, 256);
-            }
+        if (what & TRW_PREP_UNIFORM) {
+            pl.ext16 = true;
+            pl.off_ext16 = off;
+            off += align_up((size_t)nnz * 16 + 64, 256);
         }
-        // The edge table costs one pass over the graph per call, so it is built when the batch
-        // is going to make more membership queries than the graph has edges (TRW_HASH=0/1 forces).
-        if (!uniform) {
-            uint64_t cap = 1024;
-            const uint64_t slack = (uint64_t)env_long("TRW_HASH_SLACK", 2, 16, 3);  // slots per edge, at least (load factor <= 1/3)
-            while (cap < slack * (uint64_t)nnz) cap <<= 1;
-            const long forced = env_long("TRW_HASH", 0, 1, -1);
-            // measured on R-MAT 10M/110M, L=80: 344k walkers 18.5 ms without / 23.7 ms with the table, 1M walkers
-            // 38.4 / 32.9 ms -- the table pays from about nnz/2 steps
-            const bool worth = (__int128)n_walkers * L >= (__int128)nnz / 2;
-            if (cap <= ((uint64_t)1 << 31) && (forced == 1 || (forced == -1 && worth))) {
-                pl.hash = true;
-                pl.hash_mask = (uint32_t)(cap - 1);
-                pl.off_table = off;
-                off += (size_t)cap * 16;
-                // fat candidate entries: the accepted candidate brings its row along, one gather less per
-                // step (measured 158.5 -> 151.6 ms on R-MAT 10M/110M); same size rule as the uniform walk
-                const long ext_forced = env_long("TRW_EXT", 0, 1, -1);
-                const bool big = (size_t)(n_nodes + nnz) * 4 > ((size_t)32 << 20);
-                if (ext_forced == 1 || (ext_forced == -1 && big)) {
-                    pl.ext = true;
-                    pl.off_ext = off;
-                    off += align_up((size_t)nnz * 16 + 64, 256);
-                }
+        if (what & (TRW_PREP_BIASED | TRW_PREP_MARKS)) {
+            pl.biased = true;
+            pl.marks = (what & TRW_PREP_MARKS) != 0;
+            const uint64_t cap = edge_table_slots(nnz);
+            pl.hash_mask = cap - 1;
+            pl.off_table = off;
+            off += (size_t)cap * 16 + 64;
+            pl.off_ext32 = off;
+            off += align_up((size_t)nnz * 32 + 64, 256);
+            if (pl.marks) {  // queue of the entries whose mask takes a whole wave
+                const uint64_t room = (uint64_t)nnz / 2 + 1024;
+                pl.heavy_room = room > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)room;
+                pl.off_heavy = off;
+                off += align_up((size_t)pl.heavy_room * 8, 256);
             }
         }
     }
     pl.total = off;
     return pl;
+}
+
+// What one call of this shape would build for itself (each part costs a pass over the graph):
+//   uniform: fat entries when the shadow does not fit the L2s and the batch takes more steps than the graph
+//            has entries -- measured: 15.1 vs 22.6 ms on a 480 MB shadow (R-MAT 10M/110M), 1.14 vs 0.82 ms on
+//            a 4.8 MB one (ER 100k/1.1M, cache resident); 1M walkers 3.1 ms compact / 3.2 ms fat, 2.75M 7.6 / 6.1;
+//   biased:  the table + 32-byte entries from about nnz/2 steps (R-MAT 10M/110M, L=80: 344k walkers 18.5 ms
+//            without / 23.7 ms with, 1M walkers 38.4 / 32.9), the bisection kernel below that.
+int32_t plan_what(int64_t n_nodes, int64_t nnz, int64_t n_walkers, int32_t L, bool uniform, int32_t rng_mode)
+{
+    if (n_walkers <= 0 || L < 1) return TRW_PREP_NOTHING;
+    // the kernels that index the caller's int64 arrays directly want no shadow: the uniform walk on the per-walker
+    // stream nothing at all, the biased ones (serial replay, graphs beyond 2^31/2^32) the row order
+    if (uniform && rng_mode == TRW_RNG_WALKER) return TRW_PREP_NOTHING;
+    if (!uniform && rng_mode == TRW_RNG_GLIBC) return TRW_PREP_ORDER_ONLY;
+    if (!graph_fits_narrow(n_nodes, nnz)) return uniform ? TRW_PREP_NOTHING : TRW_PREP_ORDER_ONLY;
+    if (uniform) {
+        const long forced = env_long("TRW_EXT", 0, 1, -1);
+        const bool big = (size_t)(n_nodes + nnz) * 4 > ((size_t)32 << 20);  // the XCDs' aggregate L2
+        const bool worth = big && (__int128)n_walkers * L >= (__int128)nnz;
+        return (forced == 1 || (forced == -1 && worth)) ? TRW_PREP_UNIFORM : 0;
+    }
+    const long forced = env_long("TRW_HASH", 0, 1, -1);
+    const bool worth = (__int128)n_walkers * L >= (__int128)nnz / 2;
+    return (forced == 1 || (forced == -1 && worth)) ? TRW_PREP_BIASED : 0;
+}
+
+// Per-call scratch of a walk over a prepared graph: the status block and the uniform walk's RNG windows.
+struct CallLayout {
+    bool windows = false;
+    int32_t G = 1;  // walkers chained per lane (uniform glibc)
+    int64_t nlanes = 0;
+    size_t off_win = 0, total = 0;
+};
+
+CallLayout make_call_layout(int64_t n_walkers, int32_t L, bool uniform, int32_t rng_mode)
+{
+    CallLayout cl;
+    size_t off = kStatusBytes;
+    if (n_walkers > 0 && L >= 1) {
+        cl.G = uniform ? glibc_chain_length(n_walkers) : 1;
+        cl.nlanes = (n_walkers + cl.G - 1) / cl.G;
+        if (uniform && rng_mode != TRW_RNG_WALKER) {
+            cl.windows = true;
+            cl.off_win = off;
+            off += align_up((size_t)cl.nlanes * kGlDeg * sizeof(uint32_t), 256);
+        }
+    }
+    cl.total = off;
+    return cl;
 }
 
 // Optional instrumentation (trw_profile_enable): events around the three
@@ -206,6 +237,8 @@ struct Profile {
     bool count = false;
     bool valid = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t prep[2] = {nullptr, nullptr};  // around the last trw_prepare_csr_hip
+    bool prep_valid = false;
 };
 Profile g_prof;
 
@@ -247,6 +280,14 @@ __global__ void __launch_bounds__(kBlock) fill_kernel(uint4 *__restrict__ dst, u
     const uint4 v = {word, word, word, word};
     const size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += stride) dst[i] = v;
+}
+
+// The status block of a call over a prepared graph starts as a copy of the prepared header's findings
+// (validation bits in word 0, row order in status[1] / the descent counters); everything else zero.
+__global__ void status_seed_kernel(const int64_t *__restrict__ header, int64_t *__restrict__ status)
+{
+    const int i = threadIdx.x;
+    if (i < kStatusBytes / 8) status[i] = (i == 0 || i == 1 || i == kStDescents || i == kStBoundary) ? header[i] : 0;
 }
 
 void device_fill(void *dst, uint32_t word, size_t bytes, hipStream_t stream)
@@ -378,19 +419,92 @@ void trw_glibc_window_at(int32_t seed, uint64_t pos, uint32_t window[31])
     }
 }
 
-size_t trw_walk_csr_workspace_bytes(int64_t n_nodes, int64_t nnz, int64_t n_walkers, int32_t walk_length,
-                                    double p, double q, int32_t rng_mode)
+int32_t trw_prepare_plan(int64_t n_nodes, int64_t nnz, int64_t n_walkers, int32_t walk_length, double p, double q,
+                         int32_t rng_mode)
 {
-    if (n_nodes < 0 || nnz < 0) return kStatusBytes;
-    return make_plan(n_nodes, nnz, n_walkers, walk_length, p == 1.0 && q == 1.0, rng_mode).total;
+    if (n_nodes < 0 || nnz < 0) return 0;
+    const bool uniform = (p == 1.0 && q == 1.0);
+    const int mode = resolve_mode(rng_mode, uniform, n_walkers, 0, walk_length);
+    return plan_what(n_nodes, nnz, n_walkers, walk_length, uniform, mode < 0 ? TRW_RNG_AUTO : mode);
 }
 
-int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col_idx, int64_t nnz,
-                     const int64_t *targets, int64_t n_walkers, int64_t walker_base, double p, double q,
-                     int32_t walk_length, int32_t seed, int32_t rng_mode, int64_t *out, void *workspace,
-                     size_t workspace_bytes, void *hip_stream)
+size_t trw_prepare_csr_bytes(int64_t n_nodes, int64_t nnz, int32_t what)
+{
+    if (n_nodes < 0 || nnz < 0) return kStatusBytes;
+    return make_prep_layout(n_nodes, nnz, what).total;
+}
+
+int trw_prepare_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col_idx, int64_t nnz, int32_t what,
+                        void *prepared, size_t prepared_bytes, void *hip_stream)
 {
     t_last_error.clear();
+    if (n_nodes < 0 || nnz < 0) return fail(TRW_E_ARG, "negative size argument");
+    if (!row_ptr) return fail(TRW_E_ARG, "row_ptr is null");
+    if (nnz > 0 && !col_idx) return fail(TRW_E_ARG, "col_idx is null");
+    if (!prepared || ((uintptr_t)prepared & 15u) != 0) return fail(TRW_E_WORKSPACE, "prepared buffer missing or not 16-byte aligned");
+    const PrepLayout pl = make_prep_layout(n_nodes, nnz, what);
+    if (prepared_bytes < pl.total) return fail(TRW_E_WORKSPACE, "prepared buffer too small for this graph");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    char *ws = (char *)prepared;
+    int64_t *header = (int64_t *)ws;
+    if (g_prof.on && (g_prof.prep[0] || hipEventCreate(&g_prof.prep[0]) == hipSuccess))
+        (void)hipEventRecord(g_prof.prep[0], stream);
+    device_fill(header, 0u, kStatusBytes, stream);
+    if (!pl.narrow) {  // int64 kernels: only the row order is worth knowing ahead (may is_neighbor bisect?)
+        if (n_nodes > 0 && what != TRW_PREP_NOTHING) {
+            int64_t blocks = (n_nodes + kBlock - 1) / kBlock;
+            if (blocks > 256 * 16) blocks = 256 * 16;
+            csr_rows_sorted_kernel<<<(unsigned)blocks, kBlock, 0, stream>>>(row_ptr, col_idx, n_nodes, nnz, header);
+        }
+    } else {
+        uint32_t *row32 = (uint32_t *)(ws + pl.off_row32);
+        uint32_t *col32 = (uint32_t *)(ws + pl.off_col32);
+        const unsigned grid = stream_grid(nnz > n_nodes ? nnz : n_nodes + 1);
+        csr_shadow_kernel<true><<<grid, kBlock, 0, stream>>>(row_ptr, col_idx, n_nodes, nnz, row32, col32, header);
+        if (pl.ext16)
+            csr_ext_kernel<<<stream_grid(nnz), kBlock, 0, stream>>>(row32, col32, nnz, (u32x4_a16 *)(ws + pl.off_ext16));
+        if (pl.biased) {
+            uint32_t *table = (uint32_t *)(ws + pl.off_table);
+            device_fill(table, 0xFFFFFFFFu, ((size_t)pl.hash_mask + 1) * 16 + 64, stream);
+            edge_table_build_kernel<<<stream_grid((nnz + 7) / 8), kBlock, 0, stream>>>(row32, col32, n_nodes, nnz, table,
+                                                                                     pl.hash_mask, header);
+            // rows up to inline_cap are marked by the thread that owns the entry; with TRW_PREP_MARKS longer ones
+            // (up to heavy_cap) go through the wave-per-entry pass
+            const uint32_t inline_cap = (uint32_t)env_long("TRW_COMMON_MAX", 0, 4096, pl.marks ? 32 : 8);
+            const uint32_t heavy_cap = pl.marks ? (uint32_t)env_long("TRW_HEAVY_MAX", 0, 1 << 20, 4096) : 0u;
+            HeavyItem *heavy = pl.marks ? (HeavyItem *)(ws + pl.off_heavy) : nullptr;
+            csr_ext32_kernel<<<stream_grid((nnz + 7) / 8), kBlock, 0, stream>>>(
+                row32, col32, n_nodes, nnz, table, pl.hash_mask, inline_cap, heavy_cap,
+                (u32x4_a16 *)(ws + pl.off_ext32), heavy, pl.heavy_room, header);
+            if (pl.marks)
+                csr_ext32_heavy_kernel<<<(unsigned)(device_cu_count() * 8), kBlock, 0, stream>>>(
+                    row32, col32, table, pl.hash_mask, (u32x4_a16 *)(ws + pl.off_ext32), heavy, pl.heavy_room, header);
+        }
+    }
+    if (g_prof.on && g_prof.prep[0] && (g_prof.prep[1] || hipEventCreate(&g_prof.prep[1]) == hipSuccess)) {
+        (void)hipEventRecord(g_prof.prep[1], stream);
+        g_prof.prep_valid = true;
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "kernel launch");
+    return TRW_OK;
+}
+
+size_t trw_walk_csr_prepared_workspace_bytes(int64_t n_walkers, int32_t walk_length, double p, double q, int32_t rng_mode)
+{
+    return make_call_layout(n_walkers, walk_length, p == 1.0 && q == 1.0, rng_mode).total;
+}
+
+static int walk_prepared(const void *prepared, size_t prepared_bytes, int32_t what, const int64_t *row_ptr,
+                         int64_t n_nodes, const int64_t *col_idx, int64_t nnz, const int64_t *targets,
+                         int64_t n_walkers, int64_t walker_base, double p, double q, int32_t walk_length, int32_t seed,
+                         int32_t rng_mode, int64_t *out, void *workspace, size_t workspace_bytes, void *hip_stream,
+                         bool mark_prepare);
+
+static int check_walk_args(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col_idx, int64_t nnz,
+                           const int64_t *targets, int64_t n_walkers, int64_t walker_base, double p, double q,
+                           int32_t walk_length, const int64_t *out, const void *workspace, size_t workspace_bytes)
+{
     if (n_nodes < 0 || nnz < 0 || n_walkers < 0 || walker_base < 0)
         return fail(TRW_E_ARG, "negative size argument");
     if (walk_length < 1) return fail(TRW_E_ARG, "walk_length must be >= 1");
@@ -403,12 +517,41 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col
     if (!workspace || workspace_bytes < (size_t)kStatusBytes)
         return fail(TRW_E_WORKSPACE, "workspace missing or smaller than the status block");
     if (((uintptr_t)workspace & 15u) != 0) return fail(TRW_E_WORKSPACE, "workspace must be 16-byte aligned");
+    return TRW_OK;
+}
+
+int trw_walk_csr_prepared_hip(const void *prepared, size_t prepared_bytes, int32_t what, const int64_t *row_ptr,
+                              int64_t n_nodes, const int64_t *col_idx, int64_t nnz, const int64_t *targets,
+                              int64_t n_walkers, int64_t walker_base, double p, double q, int32_t walk_length,
+                              int32_t seed, int32_t rng_mode, int64_t *out, void *workspace, size_t workspace_bytes,
+                              void *hip_stream)
+{
+    return walk_prepared(prepared, prepared_bytes, what, row_ptr, n_nodes, col_idx, nnz, targets, n_walkers,
+                         walker_base, p, q, walk_length, seed, rng_mode, out, workspace, workspace_bytes, hip_stream,
+                         true);
+}
+
+static int walk_prepared(const void *prepared, size_t prepared_bytes, int32_t what, const int64_t *row_ptr,
+                         int64_t n_nodes, const int64_t *col_idx, int64_t nnz, const int64_t *targets,
+                         int64_t n_walkers, int64_t walker_base, double p, double q, int32_t walk_length, int32_t seed,
+                         int32_t rng_mode, int64_t *out, void *workspace, size_t workspace_bytes, void *hip_stream,
+                         bool mark_prepare)
+{
+    t_last_error.clear();
+    if (int rc = check_walk_args(row_ptr, n_nodes, col_idx, nnz, targets, n_walkers, walker_base, p, q, walk_length, out,
+                                 workspace, workspace_bytes))
+        return rc;
+    const PrepLayout pl = make_prep_layout(n_nodes, nnz, what);
+    if (!prepared || prepared_bytes < pl.total || ((uintptr_t)prepared & 15u) != 0)
+        return fail(TRW_E_WORKSPACE, "prepared graph missing, misaligned or smaller than its layout");
 
     const bool uniform = (p == 1.0 && q == 1.0);  // rw_cpu.cpp:220
     const int mode = resolve_mode(rng_mode, uniform, n_walkers, walker_base, walk_length);
     if (mode < 0) return fail(TRW_E_RNG_MODE, "unknown rng_mode");
     if (mode == TRW_RNG_GLIBC && !uniform && walker_base != 0)
         return fail(TRW_E_RNG_MODE, "TRW_RNG_GLIBC biased walks replay one serial stream: walker_base must be 0");
+    if (!uniform && what == TRW_PREP_NOTHING)
+        return fail(TRW_E_ARG, "a biased walk needs the row order: prepare with TRW_PREP_ORDER_ONLY at least");
     const unsigned __int128 last_pos = ((unsigned __int128)walker_base + (unsigned __int128)n_walkers) *
                                        (unsigned __int128)walk_length;
     if (mode == TRW_RNG_GLIBC && uniform && last_pos >= ((unsigned __int128)1 << 48))
@@ -416,55 +559,33 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col
 
     hipStream_t stream = (hipStream_t)hip_stream;
     int64_t *status = (int64_t *)workspace;
+    const int64_t *header = (const int64_t *)prepared;
     hipError_t e = hipSuccess;
-    device_fill(status, 0u, kStatusBytes, stream);
+    if (mark_prepare) prof_mark(0, stream);  // (a one-shot call marked it before its prepare pass)
+    // the call's status block starts from what the prepare pass found (validation bits, row order)
+    status_seed_kernel<<<1, 64, 0, stream>>>(header, status);
     if (n_walkers == 0) return TRW_OK;
 
-    const Plan pl = make_plan(n_nodes, nnz, n_walkers, walk_length, uniform, mode);
-    if (workspace_bytes < pl.total) return fail(TRW_E_WORKSPACE, "workspace too small for this call shape");
+    const CallLayout cl = make_call_layout(n_walkers, walk_length, uniform, mode);
+    if (workspace_bytes < cl.total) return fail(TRW_E_WORKSPACE, "workspace too small for this call shape");
+    const char *pw = (const char *)prepared;
     char *ws = (char *)workspace;
-    uint32_t *win = (uint32_t *)(ws + pl.off_win);
-    uint32_t *row32 = (uint32_t *)(ws + pl.off_row32);
-    uint32_t *col32 = (uint32_t *)(ws + pl.off_col32);
-    uint32_t *table = (uint32_t *)(ws + pl.off_table);
+    uint32_t *win = (uint32_t *)(ws + cl.off_win);
+    const uint32_t *row32 = (const uint32_t *)(pw + pl.off_row32);
+    const uint32_t *col32 = (const uint32_t *)(pw + pl.off_col32);
+    const uint32_t *table = (const uint32_t *)(pw + pl.off_table);
     const int64_t L = walk_length;
     const unsigned walker_grid = (unsigned)((n_walkers + kBlock - 1) / kBlock);
+    // (uniform_glibc_rows_kernel addresses a wave's 64 rows with a 32-bit byte offset)
+    const bool rows_fit = (int64_t)64 * cl.G * ((int64_t)L + 1) < ((int64_t)1 << 29);
 
     if (uniform && mode == TRW_RNG_GLIBC)
         if (int rc = ensure_jump_table()) return rc;
 
-    // ---- prepare ---------------------------------------------------------------------------
-    prof_mark(0, stream);
-    if (pl.narrow) {
-        const unsigned grid = stream_grid(nnz > n_nodes ? nnz : n_nodes + 1);
-        if (uniform)
-            csr_shadow_kernel<false><<<grid, kBlock, 0, stream>>>(row_ptr, col_idx, n_nodes, nnz, row32, col32,
-                                                                  status);
-        else
-            csr_shadow_kernel<true><<<grid, kBlock, 0, stream>>>(row_ptr, col_idx, n_nodes, nnz, row32, col32,
-                                                                 status);
-    }
-    if (pl.narrow && pl.ext && uniform && mode == TRW_RNG_GLIBC)
-        csr_ext_kernel<<<stream_grid(nnz), kBlock, 0, stream>>>(row32, col32, nnz, (u32x4_a16 *)(ws + pl.off_ext));
-    if (pl.narrow && pl.hash && mode == TRW_RNG_WALKER) {
-        device_fill(table, 0xFFFFFFFFu, ((size_t)pl.hash_mask + 1) * 16, stream);
-        edge_table_build_kernel<<<stream_grid((nnz + 7) / 8), kBlock, 0, stream>>>(row32, col32, n_nodes, nnz, table,
-                                                                                 pl.hash_mask, status);
-        if (pl.ext)
-            csr_ext_rpos_kernel<<<stream_grid((nnz + 7) / 8), kBlock, 0, stream>>>(
-                row32, col32, n_nodes, nnz, table, pl.hash_mask, (uint32_t)env_long("TRW_COMMON_MAX", 0, 4096, 8),
-                (u32x4_a16 *)(ws + pl.off_ext));
-    }
-    const unsigned lane_grid = (unsigned)((pl.nlanes + kBlock - 1) / kBlock);
-    if (uniform && mode == TRW_RNG_GLIBC) {
-        SeedWindow sw;
-        trw::seed_window(seed, sw.w);
-        glibc_windows_kernel<<<lane_grid, kBlock, 0, stream>>>(sw, (uint64_t)walker_base * (uint64_t)L,
-                                                              (uint64_t)pl.G * (uint64_t)L, pl.nlanes, win);
-    }
+    prof_mark(1, stream);
+    const unsigned lane_grid = (unsigned)((cl.nlanes + kBlock - 1) / kBlock);
     Thresholds th = {0, 0, 0};
     BiasedParams bp = {0, 0, 0, 0, 0};
-    bool use_pos = false;
     if (!uniform) {
         // rw_cpu.cpp:130-134, evaluated in the same order, then turned into integer thresholds
         const double max_prob_init = std::fmax(1.0 / p, 1);
@@ -477,32 +598,27 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col
         bp.t2 = th.t2;
         bp.lo = th.t1 < th.t2 ? th.t1 : th.t2;
         bp.hi = th.t1 < th.t2 ? th.t2 : th.t1;
-        // Locating t inside prev's row once per step pays when at least half of the trials draw
-        // above `hi` (and can then be decided from the candidate's offset alone).
-        // (With the edge table the location costs one probe, so any share of such draws pays.)
-        use_pos = bp.t0 > bp.hi && (pl.hash || bp.hi <= (1u << 30)) && env_long("TRW_NO_POS", 0, 1, 0) == 0;
-        if (!pl.narrow && n_nodes > 0) {
-            int64_t blocks = (n_nodes + kBlock - 1) / kBlock;
-            if (blocks > 256 * 16) blocks = 256 * 16;
-            csr_rows_sorted_kernel<<<(unsigned)blocks, kBlock, 0, stream>>>(row_ptr, col_idx, n_nodes, nnz, status);
-        }
     }
-
-    // ---- walk ------------------------------------------------------------------------------
-    prof_mark(1, stream);
     if (uniform) {
         if (mode == TRW_RNG_GLIBC) {
-            if (pl.narrow && pl.ext)
+            SeedWindow sw;
+            trw::seed_window(seed, sw.w);
+            glibc_windows_kernel<<<lane_grid, kBlock, 0, stream>>>(sw, (uint64_t)walker_base * (uint64_t)L,
+                                                                  (uint64_t)cl.G * (uint64_t)L, cl.nlanes, win);
+            // fat entries pay from about nnz steps in the batch (see plan_what); below that the compact shadow wins
+            // even when the entries are there
+            const bool use_fat = pl.ext16 && (env_long("TRW_EXT", 0, 1, -1) == 1 ||
+                                              (__int128)n_walkers * L >= (__int128)nnz);
+            if (pl.narrow && rows_fit && use_fat)
                 uniform_glibc_rows_kernel<true><<<lane_grid, kBlock, 0, stream>>>(
-                    row32, col32, (const u32x4_a16 *)(ws + pl.off_ext), targets, n_nodes, n_walkers, walk_length,
-                    pl.G, pl.nlanes, win, out, status);
-            else if (pl.narrow)
+                    row32, col32, (const u32x4_a16 *)(pw + pl.off_ext16), targets, n_nodes, n_walkers, walk_length,
+                    cl.G, cl.nlanes, win, out, status);
+            else if (pl.narrow && rows_fit)
                 uniform_glibc_rows_kernel<false><<<lane_grid, kBlock, 0, stream>>>(
-                    row32, col32, nullptr, targets, n_nodes, n_walkers, walk_length, pl.G, pl.nlanes, win, out,
-                    status);
+                    row32, col32, nullptr, targets, n_nodes, n_walkers, walk_length, cl.G, cl.nlanes, win, out, status);
             else
                 uniform_glibc_wide_kernel<<<lane_grid, kBlock, 0, stream>>>(row_ptr, col_idx, targets, n_nodes, nnz,
-                                                                           n_walkers, walk_length, pl.G, pl.nlanes,
+                                                                           n_walkers, walk_length, cl.G, cl.nlanes,
                                                                            win, out, status);
         } else {
             uniform_walker_kernel<<<walker_grid, kBlock, 0, stream>>>(row_ptr, col_idx, targets, n_nodes, nnz,
@@ -514,23 +630,39 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col
         trw::seed_window(seed, sw.w);
         biased_glibc_seq_kernel<<<1, 64, 0, stream>>>(row_ptr, col_idx, targets, n_nodes, nnz, n_walkers,
                                                      walk_length, sw, th, out, status);
-    } else if (pl.narrow && pl.hash) {
+    } else if (pl.narrow && pl.biased) {
         // persistent lanes: walkers are dealt out by a device counter (status[kStNextWalker])
         int64_t blocks = (n_walkers + kBlock - 1) / kBlock;
-        // Workgroups per CU (TRW_RESIDENT_BLOCKS; 8 = every wave slot).  The memory system is saturated well
-        // before that: measured on R-MAT 10M/110M 138.5 ms at 8, 136.8 at 5, 135.9 at 4, 141.0 at 3 (and the
-        // same shape on the 1M graph), so 5 -- which also leaves wave slots to a collective on another stream.
+        // Workgroups per CU (TRW_RESIDENT_BLOCKS; 8 = every wave slot)
         const int64_t resident = (int64_t)device_cu_count() * env_long("TRW_RESIDENT_BLOCKS", 1, 8, 5);
         if (blocks > resident) blocks = resident;
+        const u32x4_a16 *ext32 = (const u32x4_a16 *)(pw + pl.off_ext32);
+        const bool mask_kernel = env_long("TRW_MASK_KERNEL", 0, 1, 1) == 1;
+        // sorted rows: the mask kernel; unsorted rows: the state-machine kernel (each returns at once when the
+        // graph is not its kind -- the row order is known on the device only)
+        if (mask_kernel) {
+            if (g_prof.count)
+                biased_mask_kernel<true><<<(unsigned)blocks, kBlock, 0, stream>>>(
+                    row32, ext32, table, pl.hash_mask, targets, n_nodes, n_walkers, walker_base, walk_length,
+                    (uint32_t)seed, bp, out, status);
+            else
+                biased_mask_kernel<false><<<(unsigned)blocks, kBlock, 0, stream>>>(
+                    row32, ext32, table, pl.hash_mask, targets, n_nodes, n_walkers, walker_base, walk_length,
+                    (uint32_t)seed, bp, out, status);
+        }
+        const int32_t want_pos = (bp.t0 > bp.hi && env_long("TRW_NO_POS", 0, 1, 0) == 0) ? 1 : 0;
         if (g_prof.count)
             biased_hash_kernel<true><<<(unsigned)blocks, kBlock, 0, stream>>>(
-                row32, col32, pl.ext ? (const uint32_t *)(ws + pl.off_ext) : nullptr, table, pl.hash_mask, targets,
-                n_nodes, n_walkers, walker_base, walk_length, (uint32_t)seed, bp, use_pos ? 1 : 0, out, status);
+                row32, col32, (const uint32_t *)ext32, table, pl.hash_mask, targets, n_nodes, n_walkers, walker_base,
+                walk_length, (uint32_t)seed, bp, want_pos, mask_kernel ? 1 : 0, out, status);
         else
             biased_hash_kernel<false><<<(unsigned)blocks, kBlock, 0, stream>>>(
-                row32, col32, pl.ext ? (const uint32_t *)(ws + pl.off_ext) : nullptr, table, pl.hash_mask, targets,
-                n_nodes, n_walkers, walker_base, walk_length, (uint32_t)seed, bp, use_pos ? 1 : 0, out, status);
+                row32, col32, (const uint32_t *)ext32, table, pl.hash_mask, targets, n_nodes, n_walkers, walker_base,
+                walk_length, (uint32_t)seed, bp, want_pos, mask_kernel ? 1 : 0, out, status);
     } else if (pl.narrow) {
+        // Locating t inside prev's row once per step (a bisection here) pays when at least half of the trials
+        // draw above `hi` and can then be decided from the candidate's offset alone.
+        const bool use_pos = bp.t0 > bp.hi && bp.hi <= (1u << 30) && env_long("TRW_NO_POS", 0, 1, 0) == 0;
 #define TRW_LAUNCH_BIASED(POS, COUNT)                                                                          \
     biased_walker_kernel<POS, COUNT><<<walker_grid, kBlock, 0, stream>>>(                                      \
         row32, col32, targets, n_nodes, n_walkers, walker_base, walk_length, (uint32_t)seed, bp, out, status)
@@ -552,14 +684,52 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col
                 row_ptr, col_idx, targets, n_nodes, nnz, n_walkers, walker_base, walk_length, (uint32_t)seed, th,
                 out, status);
     }
-
-    // ---- finish ----------------------------------------------------------------------------
     prof_mark(2, stream);
-    // every walk kernel writes the caller's rows itself: nothing to finish
-    prof_mark(3, stream);
+    prof_mark(3, stream);  // every walk kernel writes the caller's rows itself: nothing to finish
     e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "kernel launch");
     return TRW_OK;
+}
+
+// One-shot form: prepares what this call shape is worth (plan_what) inside the workspace, then walks.
+size_t trw_walk_csr_workspace_bytes(int64_t n_nodes, int64_t nnz, int64_t n_walkers, int32_t walk_length,
+                                    double p, double q, int32_t rng_mode)
+{
+    if (n_nodes < 0 || nnz < 0) return kStatusBytes;
+    const bool uniform = (p == 1.0 && q == 1.0);
+    const int32_t what = plan_what(n_nodes, nnz, n_walkers, walk_length, uniform, rng_mode);
+    return align_up(make_call_layout(n_walkers, walk_length, uniform, rng_mode).total, 256) +
+           make_prep_layout(n_nodes, nnz, what).total;
+}
+
+int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col_idx, int64_t nnz,
+                     const int64_t *targets, int64_t n_walkers, int64_t walker_base, double p, double q,
+                     int32_t walk_length, int32_t seed, int32_t rng_mode, int64_t *out, void *workspace,
+                     size_t workspace_bytes, void *hip_stream)
+{
+    t_last_error.clear();
+    if (int rc = check_walk_args(row_ptr, n_nodes, col_idx, nnz, targets, n_walkers, walker_base, p, q, walk_length, out,
+                                 workspace, workspace_bytes))
+        return rc;
+    const bool uniform = (p == 1.0 && q == 1.0);
+    const int mode = resolve_mode(rng_mode, uniform, n_walkers, walker_base, walk_length);
+    if (mode < 0) return fail(TRW_E_RNG_MODE, "unknown rng_mode");
+    if (mode == TRW_RNG_GLIBC && !uniform && walker_base != 0)
+        return fail(TRW_E_RNG_MODE, "TRW_RNG_GLIBC biased walks replay one serial stream: walker_base must be 0");
+    if (n_walkers == 0) {
+        device_fill(workspace, 0u, kStatusBytes, (hipStream_t)hip_stream);
+        return TRW_OK;
+    }
+    // planned with the resolved mode: never larger than what trw_walk_csr_workspace_bytes sized with the caller's
+    const int32_t what = plan_what(n_nodes, nnz, n_walkers, walk_length, uniform, mode);
+    const size_t call_bytes = align_up(make_call_layout(n_walkers, walk_length, uniform, mode).total, 256);
+    const size_t prep_bytes = make_prep_layout(n_nodes, nnz, what).total;
+    if (workspace_bytes < call_bytes + prep_bytes) return fail(TRW_E_WORKSPACE, "workspace too small for this call shape");
+    void *prepared = (char *)workspace + call_bytes;
+    prof_mark(0, (hipStream_t)hip_stream);
+    if (int rc = trw_prepare_csr_hip(row_ptr, n_nodes, col_idx, nnz, what, prepared, prep_bytes, hip_stream)) return rc;
+    return walk_prepared(prepared, prep_bytes, what, row_ptr, n_nodes, col_idx, nnz, targets, n_walkers, walker_base, p,
+                         q, walk_length, seed, mode, out, workspace, call_bytes, hip_stream, false);
 }
 
 // ---- triples (knowledge-graph) walk, reference csrc/cpu/rw_cpu_triples.cpp -----------------------
@@ -980,6 +1150,21 @@ int trw_profile_enable(int flags)
     g_prof.on = (flags & 1) != 0;
     g_prof.count = (flags & 2) != 0;
     g_prof.valid = false;
+    g_prof.prep_valid = false;
+    return TRW_OK;
+}
+
+int trw_profile_prepare_last(double *prepare_ms)
+{
+    t_last_error.clear();
+    if (!g_prof.on || !g_prof.prep_valid || !prepare_ms) return fail(TRW_E_ARG, "no profiled prepare recorded");
+    hipError_t e = hipEventSynchronize(g_prof.prep[1]);
+    if (e != hipSuccess) return fail_hip(e, "hipEventSynchronize");
+    float ms = 0.f;
+    e = hipEventElapsedTime(&ms, g_prof.prep[0], g_prof.prep[1]);
+    if (e != hipSuccess) return fail_hip(e, "hipEventElapsedTime");
+    *prepare_ms = ms;
+    g_prof.prep_valid = false;  // reported once
     return TRW_OK;
 }
 
@@ -1045,6 +1230,37 @@ int status_sweep(bool wait, int64_t *bits)
     return pending;
 }
 }  // namespace
+
+// ---- small stream helpers for hosts that keep prepared graphs across streams ---------------------------
+int trw_stream_is_capturing(void *hip_stream)
+{
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)hip_stream, &cap) != hipSuccess) return 0;
+    return cap != hipStreamCaptureStatusNone ? 1 : 0;
+}
+
+void *trw_event_record(void *hip_stream)
+{
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventRecord(ev, (hipStream_t)hip_stream) != hipSuccess) {
+        (void)hipEventDestroy(ev);
+        return nullptr;
+    }
+    return (void *)ev;
+}
+
+int trw_event_wait(void *event, void *hip_stream)
+{
+    if (!event) return TRW_OK;
+    const hipError_t e = hipStreamWaitEvent((hipStream_t)hip_stream, (hipEvent_t)event, 0);
+    return e == hipSuccess ? TRW_OK : fail_hip(e, "hipStreamWaitEvent");
+}
+
+void trw_event_destroy(void *event)
+{
+    if (event) (void)hipEventDestroy((hipEvent_t)event);
+}
 
 int trw_status_post(const void *workspace, void *hip_stream)
 {

@@ -562,6 +562,15 @@ __device__ __forceinline__ uint32_t edge_hash(uint32_t u, uint32_t v)
     return h;
 }
 
+// Slot of edge (u, v) in a table of mask+1 slots (a power of two).  Tables beyond 2^32 slots (graphs with more
+// than ~1.4e9 entries) take a second hash word for the high bits; `mask` is wave-uniform, so is the branch.
+__device__ __forceinline__ uint64_t edge_slot(uint32_t u, uint32_t v, uint64_t mask)
+{
+    uint64_t h = edge_hash(u, v);
+    if (mask > 0xFFFFFFFFull) h |= (uint64_t)edge_hash(v ^ 0x9E3779B9u, u + 0x7F4A7C15u) << 32;
+    return h & mask;
+}
+
 // table: `mask`+1 slots of {u, v, lo, cnt-1}, all bytes 0xFF when empty.
 // Each thread owns 8 consecutive entries: one bisection of row32 finds the row of the first,
 // the others follow by walking row32 forward.  With sorted rows (the shadow pass counted no
@@ -570,11 +579,12 @@ __device__ __forceinline__ uint32_t edge_hash(uint32_t u, uint32_t v)
 // entry goes through CAS + min + add.
 __global__ void __launch_bounds__(kBlock)
 edge_table_build_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32, int64_t n_nodes,
-                        int64_t nnz, uint32_t *__restrict__ table, uint32_t mask,
+                        int64_t nnz, uint32_t *__restrict__ table, uint64_t mask,
                         const int64_t *__restrict__ status)
 {
     constexpr int kPer = 8;
     const bool sorted = status[kStDescents] == status[kStBoundary];
+    const uint32_t e_first = row32[0], e_last = row32[n_nodes];  // entries outside belong to no row: not edges
     const int64_t chunks = (nnz + kPer - 1) / kPer;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x; c < chunks; c += stride) {
@@ -599,6 +609,7 @@ edge_table_build_kernel(const uint32_t *__restrict__ row32, const uint32_t *__re
                 row_lo = row_hi;
                 row_hi = row32[u + 1];
             }
+            if (e < e_first || e >= e_last) continue;
             const uint32_t v = col32[e];
             uint32_t cnt = 1;
             if (sorted) {
@@ -606,9 +617,9 @@ edge_table_build_kernel(const uint32_t *__restrict__ row32, const uint32_t *__re
                 while (e + cnt < row_hi && col32[e + cnt] == v) ++cnt;
             }
             const unsigned long long key = ((unsigned long long)v << 32) | u;
-            uint32_t slot = edge_hash(u, v) & mask;
+            uint64_t slot = edge_slot(u, v, mask);
             while (true) {
-                uint32_t *ent = table + 4 * (size_t)slot;
+                uint32_t *ent = table + 4 * slot;
                 const unsigned long long old = atomicCAS((unsigned long long *)ent, ~0ull, key);
                 if (sorted) {
                     if (old == ~0ull) {
@@ -627,42 +638,105 @@ edge_table_build_kernel(const uint32_t *__restrict__ row32, const uint32_t *__re
     }
 }
 
-// Fat entries for the biased walk: ext[e] = {v, start(v), deg(v), rpos} for edge u -> v, where rpos says
-// where u sits in v's row -- exactly what the walker needs after accepting v from u ("where is t in
-// prev's row") -- so that step skips its table probe.  rpos = (multiplicity << 28) | first offset when
-// both fit (multiplicity <= 15, offset < 2^28), 0 = u is not in v's row, 1 = look it up in the table.
-// One thread per 8 consecutive entries, as edge_table_build_kernel; one table probe per entry.
+// Fat entries for the biased walk, 32 bytes per CSR entry e = (u -> v):
+//     word 0..3   v, start(v), deg(v) | kMaskIsFilter, rpos
+//     word 4..7   a 128-bit neighbourhood mask of the step that follows u -> v
+// A walker that took u -> v stands on prev = v with t = u and draws candidates from v's row by OFFSET
+// (idx = draw % deg(v)).  Everything the rejection trial has to know about offset idx is here:
+//   * rpos says where u itself sits in v's row ((multiplicity << 28) | first offset when multiplicity <= 15
+//     and offset < 2^28; 0 = u is not in v's row; 1 = look it up in the edge table) -- the "x == t" case;
+//   * mask bit (idx & 127) says whether the node at offset idx of v's row is in u's row -- is_neighbor(x, t)
+//     of the reference (rw_cpu.cpp:32-56), precomputed.  For deg(v) <= 128 the bit is the exact answer.
+//     For longer rows offsets alias modulo 128 and the bit is the OR over its aliases: a clear bit still
+//     means "not a neighbour" for certain, a set bit means "ask the edge table" (kMaskIsFilter set).
+// So a trial is decided from registers, and the graph is read once per STEP: the 32-byte entry of the
+// accepted offset, which carries the next step's row, rpos and mask.
 //
-// The top bit of the deg field (kNoCommon; rows have fewer than 2^31 entries) says that the rows of u and v
-// share NO node.  A walker that took u -> v then stands on prev = v with t = u, and every candidate x != t
-// it draws from v's row is known not to be in t's row: the rejection trials that would ask is_neighbor
-// (draw in [lo, hi)) are decided without loading the candidate or probing the table.  On R-MAT 10M/110M
-// 58 % of the visited (t, prev) pairs are like that (scripts/triangle_stats.py); the flag is worked out
-// only where u's row has at most `common_max` entries (that many probes at most, early exit).  Measured
-// there with common_max = 8 (TRW_COMMON_MAX): candidate loads 3.82 -> 3.01 and membership tests 2.86 -> 2.05
-// per step, walk kernel 136 -> 129 ms for 1.6 ms more in this pass; 64 takes the kernel to 125 ms but costs
-// 24 ms here.
+// Cost of the mask: the common neighbours of u and v, found by walking the shorter of the two rows and
+// probing the edge table for the other (one probe per entry).  Rows up to `inline_cap` are done by the
+// thread that owns the entry; longer ones (up to `heavy_cap`) are queued for csr_ext32_heavy_kernel, one
+// wave per entry; beyond that, and for graphs whose rows are not sorted, the mask is all ones + filter
+// (every band trial asks the table, as the walk did before there were masks).
 constexpr uint32_t kRposAbsent = 0u, kRposLookup = 1u;
-constexpr uint32_t kNoCommon = 0x80000000u;
+constexpr uint32_t kMaskIsFilter = 0x80000000u;  // top bit of the deg word (rows have fewer than 2^31 entries)
+constexpr uint32_t kNoCommon = kMaskIsFilter;    // (name used by the unsorted-rows kernel when it strips the bit)
+constexpr int kStHeavyCount = 11;                // status slot of the PREPARED header: entries queued for the heavy pass
 
-// is (a -> b) an edge?  (one probe chain of the edge table)
-__device__ __forceinline__ bool edge_table_has(const uint32_t *__restrict__ table, uint32_t mask, uint32_t a, uint32_t b)
+// is (a -> b) an edge?  (one probe chain of the edge table); lo/cnt: first offset of b in a's row, multiplicity
+__device__ __forceinline__ bool edge_table_find(const uint32_t *__restrict__ table, uint64_t mask, uint32_t a,
+                                                uint32_t b, uint32_t &lo, uint32_t &cnt)
 {
-    uint32_t slot = edge_hash(a, b) & mask;
+    uint64_t slot = edge_slot(a, b, mask);
     while (true) {
-        const u32x2_a4 g = *reinterpret_cast<const u32x2_a4 *>(table + 4 * (size_t)slot);
+        const u32x4_a16 g = *reinterpret_cast<const u32x4_a16 *>(table + 4 * slot);
         if (g.x == 0xFFFFFFFFu) return false;
-        if (g.x == a && g.y == b) return true;
+        if (g.x == a && g.y == b) {
+            lo = g.z;
+            cnt = g.w + 1u;
+            return true;
+        }
         slot = (slot + 1) & mask;
     }
 }
 
+struct Mask128 {
+    uint32_t w[4];
+    __device__ __forceinline__ void clear() { w[0] = w[1] = w[2] = w[3] = 0u; }
+    __device__ __forceinline__ void fill() { w[0] = w[1] = w[2] = w[3] = 0xFFFFFFFFu; }
+    __device__ __forceinline__ void set(uint32_t off)
+    {
+        const uint32_t b = 1u << (off & 31u), k = (off >> 5) & 3u;
+        w[0] |= k == 0u ? b : 0u;
+        w[1] |= k == 1u ? b : 0u;
+        w[2] |= k == 2u ? b : 0u;
+        w[3] |= k == 3u ? b : 0u;
+    }
+    __device__ __forceinline__ void set_run(uint32_t lo, uint32_t cnt)
+    {
+        if (cnt >= 128u) {
+            fill();
+            return;
+        }
+        for (uint32_t k = 0; k < cnt; ++k) set(lo + k);
+    }
+};
+
+// mask of the step after u -> v: offsets of v's row [v_start, v_start+v_deg) whose node is in u's row
+// [u_lo, u_hi); the caller's lane handles entries first, first+stride, ... of the shorter row.
+__device__ __forceinline__ void common_mask(const uint32_t *__restrict__ col32, const uint32_t *__restrict__ table,
+                                            uint64_t tmask, uint32_t u, uint32_t u_lo, uint32_t u_hi, uint32_t v,
+                                            uint32_t v_start, uint32_t v_deg, uint32_t first, uint32_t stride,
+                                            Mask128 &m)
+{
+    const uint32_t u_deg = u_hi - u_lo;
+    uint32_t lo, cnt;
+    if (u_deg <= v_deg) {  // walk u's row: each distinct w in it, looked up in v's row
+        for (uint32_t i = first; i < u_deg; i += stride) {
+            const uint32_t w = col32[u_lo + i];
+            if (i > 0 && col32[u_lo + i - 1] == w) continue;  // sorted rows: a run of equal entries is one node
+            if (edge_table_find(table, tmask, v, w, lo, cnt)) m.set_run(lo, cnt);
+        }
+    } else {  // walk v's row: the node at each offset, looked up in u's row
+        for (uint32_t j = first; j < v_deg; j += stride) {
+            const uint32_t x = col32[v_start + j];
+            if (edge_table_find(table, tmask, u, x, lo, cnt)) m.set(j);
+        }
+    }
+}
+
+struct HeavyItem {
+    uint32_t e, u;
+};
+
 __global__ void __launch_bounds__(kBlock)
-csr_ext_rpos_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32, int64_t n_nodes,
-                    int64_t nnz, const uint32_t *__restrict__ table, uint32_t mask, uint32_t common_max,
-                    u32x4_a16 *__restrict__ ext)
+csr_ext32_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32, int64_t n_nodes,
+                 int64_t nnz, const uint32_t *__restrict__ table, uint64_t tmask, uint32_t inline_cap,
+                 uint32_t heavy_cap, u32x4_a16 *__restrict__ ext, HeavyItem *__restrict__ heavy, uint32_t heavy_room,
+                 int64_t *__restrict__ header)
 {
     constexpr int kPer = 8;
+    const bool sorted = header[kStDescents] == header[kStBoundary];
+    const uint32_t e_first = row32[0], e_last = row32[n_nodes];  // entries outside belong to no row
     const int64_t chunks = (nnz + kPer - 1) / kPer;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x; c < chunks; c += stride) {
@@ -689,33 +763,58 @@ csr_ext_rpos_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restri
             const uint32_t v = col32[e];
             uint32_t start, deg;
             load_row32(row32, v, start, deg);
-            uint32_t rpos = kRposAbsent;
-            uint32_t slot = edge_hash(v, u) & mask;
-            while (true) {  // is u in v's row, and where?
-                const u32x4_a16 g = *reinterpret_cast<const u32x4_a16 *>(table + 4 * (size_t)slot);
-                if (g.x == 0xFFFFFFFFu) break;
-                if (g.x == v && g.y == u) {
-                    const uint32_t cnt = g.w + 1u;
-                    rpos = (cnt <= 15u && g.z < (1u << 28)) ? ((cnt << 28) | g.z) : kRposLookup;
-                    break;
+            Mask128 m;
+            m.fill();
+            uint32_t flag = kMaskIsFilter, rpos = kRposAbsent;
+            if (e >= e_first && e < e_last) {
+                uint32_t lo, cnt;
+                if (edge_table_find(table, tmask, v, u, lo, cnt))
+                    rpos = (cnt <= 15u && lo < (1u << 28)) ? ((cnt << 28) | lo) : kRposLookup;
+                const uint32_t deg_u = row_hi - row_lo;
+                const uint32_t shorter = deg_u < deg ? deg_u : deg;
+                if (sorted && shorter <= inline_cap) {
+                    m.clear();
+                    common_mask(col32, table, tmask, u, row_lo, row_hi, v, start, deg, 0u, 1u, m);
+                    flag = deg > 128u ? kMaskIsFilter : 0u;
+                } else if (sorted && shorter <= heavy_cap && heavy) {
+                    const uint32_t at = (uint32_t)atomicAdd((unsigned long long *)&header[kStHeavyCount], 1ull);
+                    if (at < heavy_room) heavy[at] = HeavyItem{e, u};
                 }
-                slot = (slot + 1) & mask;
-            }
-            // Do the rows of u and v share a node?  Asked only where u's row is short (walk it, probe v's row):
-            // that is the cheap side to ask from (u's row is this thread's own stretch of col32) and the one that
-            // pays -- a short row of v means few distinct candidates and probes, which the caches absorb anyway.
-            uint32_t flag = 0u;
-            const uint32_t deg_u = row_hi - row_lo;
-            if (deg_u <= common_max && deg < kNoCommon) {
-                flag = kNoCommon;
-                for (uint32_t i = 0; i < deg_u; ++i)
-                    if (edge_table_has(table, mask, v, col32[row_lo + i])) {
-                        flag = 0u;
-                        break;
-                    }
             }
             u32x4_a16 o = {v, start, deg | flag, rpos};
-            ext[e] = o;
+            u32x4_a16 mm = {m.w[0], m.w[1], m.w[2], m.w[3]};
+            ext[2 * (size_t)e] = o;
+            ext[2 * (size_t)e + 1] = mm;
+        }
+    }
+}
+
+// The queued entries, one wave each: 64 lanes stride over the shorter row, OR their masks together.
+__global__ void __launch_bounds__(kBlock)
+csr_ext32_heavy_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32,
+                       const uint32_t *__restrict__ table, uint64_t tmask, u32x4_a16 *__restrict__ ext,
+                       const HeavyItem *__restrict__ heavy, uint32_t heavy_room, const int64_t *__restrict__ header)
+{
+    const uint64_t queued = (uint64_t)header[kStHeavyCount];
+    const uint32_t count = queued < heavy_room ? (uint32_t)queued : heavy_room;
+    const int lane = threadIdx.x & 63;
+    const uint32_t waves = gridDim.x * (kBlock / 64);
+    for (uint32_t it = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); it < count; it += waves) {
+        const HeavyItem h = heavy[it];
+        const uint32_t v = col32[h.e];
+        uint32_t start, deg;
+        load_row32(row32, v, start, deg);
+        Mask128 m;
+        m.clear();
+        common_mask(col32, table, tmask, h.u, row32[h.u], row32[h.u + 1], v, start, deg, (uint32_t)lane, 64u, m);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m.w[k] |= __shfl_xor(m.w[k], off);
+        if (lane == 0) {
+            u32x4_a16 mm = {m.w[0], m.w[1], m.w[2], m.w[3]};
+            ext[2 * (size_t)h.e + 1] = mm;
+            if (deg <= 128u) reinterpret_cast<uint32_t *>(ext + 2 * (size_t)h.e)[2] = deg;  // exact: drop the filter bit
         }
     }
 }
@@ -745,10 +844,14 @@ constexpr int kTrialsPerIter = TRW_TRIALS_PER_ITER;
 template <bool kCount>
 __global__ void __launch_bounds__(kBlock)
 biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32,
-                   const uint32_t *__restrict__ ext, const uint32_t *__restrict__ table, uint32_t mask, const int64_t *__restrict__ targets,
+                   const uint32_t *__restrict__ ext, const uint32_t *__restrict__ table, uint64_t mask, const int64_t *__restrict__ targets,
                    int64_t n_nodes, int64_t n_walkers, int64_t walker_base, int32_t L, uint32_t seed,
-                   BiasedParams bp, int32_t want_pos, int64_t *__restrict__ out, int64_t *__restrict__ status)
+                   BiasedParams bp, int32_t want_pos, int32_t only_unsorted, int64_t *__restrict__ out,
+                   int64_t *__restrict__ status)
 {
+    // Sorted graphs are walked by biased_mask_kernel; the host cannot see which kind it has without a
+    // synchronisation, so it launches both and the one that does not apply returns here.
+    if (only_unsorted && status[kStDescents] == status[kStBoundary]) return;
     // Per-lane ring of upcoming draws, draw d of the lane's walker at ring[d % kRing][tid] (slot-major: a
     // lane always hits its own bank).  The ring is topped up for ALL lanes of the wave at once whenever one
     // lane runs dry, so the Philox rounds execute with (nearly) every lane active instead of for the few
@@ -762,11 +865,12 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
     const bool use_pos = want_pos && status[kStDescents] == status[kStBoundary];
     const int lane = threadIdx.x & 63;
     uint32_t *my_ring = ring + threadIdx.x;
-    // candidates come from the fat entries {v, start(v), deg(v), 0} when the call built them: the accepted
-    // candidate then brings its own row and the LS_ROW gather of the next step is skipped
+    // candidates come from the fat entries (32 bytes each; this kernel reads the first 16: {v, start(v), deg(v),
+    // rpos}) when the call built them: the accepted candidate then brings its own row and the LS_ROW gather of
+    // the next step is skipped
     const bool fat = ext != nullptr;
     const uint32_t *cand_base = fat ? ext : col32;
-    const uint32_t cand_shift = fat ? 2u : 0u;
+    const uint32_t cand_shift = fat ? 3u : 0u;
 
     uint32_t st = 0;
     uint32_t n_trials = 0, n_fetch = 0, n_tests = 0, n_probes = 0;
@@ -781,7 +885,8 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
     fm.d = 1;
     fm.z = 0;
     uint32_t d_cons = 0, d_prod = 0;  // draws consumed / produced for the current walker
-    uint32_t slot = 0, ku = 0, kv = 0, ru = 0, rejected = 0;
+    uint64_t slot = 0;
+    uint32_t ku = 0, kv = 0, ru = 0, rejected = 0;
     uint32_t c_start = 0, c_deg = 0, c_rpos = kRposLookup;  // the candidate's row and where prev sits in it (fat entries)
     bool no_common = false;  // rows of t and prev share no node (kNoCommon of the entry the walker came through)
     const uint32_t *addr = row32;
@@ -898,7 +1003,7 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
             const bool match = g.x == ku && g.y == kv;
             if (!empty && !match) {
                 slot = (slot + 1) & mask;
-                addr = table + 4 * (size_t)slot;
+                addr = table + 4 * slot;
                 fresh = true;
             } else if (state == LS_POS) {  // where t sits in prev's row
                 pos_lo = match ? g.z : 0u;
@@ -1021,7 +1126,7 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                 if (fat && (c_deg & ~kNoCommon) != 0 && !(st & TRW_ST_DEGREE0)) {  // the candidate brought its row along
                     p_start = c_start;
                     p_deg = c_deg & ~kNoCommon;
-                    no_common = (c_deg & kNoCommon) != 0;
+                    no_common = false;  // (the top bit of the deg word marks a filter mask now; stripped above)
                     fm.init(p_deg);
                     if (use_pos && c_rpos == kRposLookup) {
                         ku = prev;
@@ -1043,11 +1148,282 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
 
         // ---- start a table probe ----
         if (ev_probe) {
-            slot = edge_hash(ku, kv) & mask;
-            addr = table + 4 * (size_t)slot;
+            slot = edge_slot(ku, kv, mask);
+            addr = table + 4 * slot;
             fresh = true;
             state = probe_state;
         }
+    }
+
+    if (st) atomicOr((unsigned long long *)&status[0], (unsigned long long)st);
+    if (kCount) {
+        const uint64_t a = wave_sum(n_trials), b = wave_sum(n_fetch), c = wave_sum(n_tests), d = wave_sum(n_probes);
+        if (lane == 0) {
+            atomicAdd((unsigned long long *)&status[4], (unsigned long long)a);
+            atomicAdd((unsigned long long *)&status[5], (unsigned long long)b);
+            atomicAdd((unsigned long long *)&status[6], (unsigned long long)c);
+            atomicAdd((unsigned long long *)&status[7], (unsigned long long)d);
+        }
+    }
+}
+
+// ===========================================================================
+// Biased walk over the 32-byte fat entries: trials decided in registers
+// ===========================================================================
+// The kernel for sorted graphs with a prepared table + fat entries (csr_ext32_kernel).  Same stream, same
+// decisions, same rows as biased_walker_kernel / biased_hash_kernel -- what changes is where the answers come
+// from.  With t = the node two steps back and prev = the node the walker stands on, a rejection trial draws an
+// OFFSET idx into prev's row and an acceptance value ru, and the reference (rw_cpu.cpp:166-195) accepts
+//     x == t              iff ru < t0
+//     x in t's row        iff ru < t1
+//     otherwise           iff ru < t2.
+// The entry the walker came through tells, per offset: is it t (rpos), is its node in t's row (mask bit).  So:
+//     offset holds t                      -> decided (accept iff ru < t0)
+//     ru below both / above both of t1,t2 -> decided
+//     in between, mask bit clear          -> not a neighbour, decided
+//     in between, bit set, exact mask     -> neighbour, decided
+//     in between, bit set, filter mask    -> load the entry (the candidate), ask the edge table, then decide
+// A lane runs its trials back to back out of its LDS draw ring and touches memory once per step: the 32-byte
+// entry of the accepted offset, which is at once the next node, its row, rpos and the next step's mask.  That
+// gather is issued from inside the trial burst and collected after it, so its latency hides behind the other
+// lanes' trials; lanes take their next walker from a device counter as they finish.
+enum : uint32_t { MS_IDLE = 0, MS_START, MS_ROW, MS_CAND, MS_MEMBER, MS_POS, MS_TRIAL };
+
+#ifndef TRW_MASK_BURST
+#define TRW_MASK_BURST 4
+#endif
+constexpr int kMaskBurst = TRW_MASK_BURST;  // trials per lane between two visits of the gather/adopt code
+#ifndef TRW_MASK_RING
+#define TRW_MASK_RING 16
+#endif
+constexpr int kMaskRing = TRW_MASK_RING;    // draws buffered per lane in LDS (a power of two >= 2*burst + 4)
+
+template <bool kCount>
+__global__ void __launch_bounds__(kBlock)
+biased_mask_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restrict__ ext,
+                   const uint32_t *__restrict__ table, uint64_t mask, const int64_t *__restrict__ targets,
+                   int64_t n_nodes, int64_t n_walkers, int64_t walker_base, int32_t L, uint32_t seed, BiasedParams bp,
+                   int64_t *__restrict__ out, int64_t *__restrict__ status)
+{
+    static_assert((kMaskRing & (kMaskRing - 1)) == 0 && kMaskRing >= 2 * kMaskBurst + 4, "ring too small for the burst");
+    // unsorted rows: t's offsets in prev's row are not one run, rpos cannot describe them -- biased_hash_kernel's job
+    if (status[kStDescents] != status[kStBoundary]) return;
+    __shared__ uint32_t ring[kMaskRing * kBlock];  // draw d of the lane's walker at ring[d % kMaskRing][tid]
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        status[2] = TRW_RNG_WALKER;
+        status[3] = 4;
+    }
+    const int lane = threadIdx.x & 63;
+    uint32_t *my_ring = ring + threadIdx.x;
+    // in the band between the two thresholds: a neighbour is accepted iff t1 is the upper one
+    const bool band_takes_near = bp.t1 > bp.t2;
+
+    uint32_t st = 0;
+    uint32_t n_trials = 0, n_fetch = 0, n_tests = 0, n_probes = 0;
+
+    uint32_t state = MS_START;
+    int64_t walker = 0;
+    uint64_t gw = 0;
+    int32_t s = 0;
+    uint32_t t = 0, prev = 0, p_start = 0, p_deg = 0;
+    uint32_t pos_lo = 0, pos_cnt = 0;
+    uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+    bool exact = false;
+    FastMod fm;
+    fm.d = 1;
+    fm.z = 0;
+    uint32_t d_cons = 0, d_prod = 0;  // draws consumed / produced for the current walker
+    uint64_t slot = 0;
+    uint32_t ru = 0, rejected = 0;
+    bool taken = false;               // MS_CAND: the entry in flight is an accepted one (else: a candidate to test)
+    // The ONE gather a lane has in flight lands in e0 (+ e1 for a 32-byte entry): a row32 pair, a table slot or
+    // a fat entry.  One load site per iteration keeps the compiler's wait to one place (it orders every load
+    // after whatever else might still be writing the same registers).
+    u32x4_a4 e0 = {0u, 0u, 0u, 0u}, e1 = {0u, 0u, 0u, 0u};
+    u32x4_a4 c0 = {0u, 0u, 0u, 0u}, c1 = {0u, 0u, 0u, 0u};  // the candidate entry, kept while the table is asked about it
+    // what the lane wants fetched at the end of this iteration: 0 nothing, 1 the 32-byte entry `want_at`,
+    // 2 the row32 pair of node `want_at`, 3 table slot `slot`
+    uint32_t want = 0, want_at = 0;
+    RowCombiner row = {out, 0u, 0u, 0u, 0u};
+    // verdict of a band trial by (mask bit, exact): 0 reject, 1 accept, 2 load the candidate and ask the table
+    const uint32_t v_clear = band_takes_near ? 0u : 1u, v_set_exact = band_takes_near ? 1u : 0u;
+
+    while (true) {
+        // ---- collect what the previous iteration asked for (the one wait of the loop) ----
+        bool adopt = false;
+        if (state == MS_ROW) {  // e0 = row32[start node], row32[start node + 1], ...
+            p_start = e0.x;
+            p_deg = e0.y >= e0.x ? e0.y - e0.x : 0u;
+            if (p_deg == 0) {  // dead end at the start node: reported, the walker stays (the reference divides by zero)
+                st |= TRW_ST_DEGREE0;
+                for (; s <= L; ++s) row.emit(prev, s, L);
+                state = MS_START;
+            } else {  // first step: plain uniform neighbour, draw 0 (rw_cpu.cpp:159)
+                const uint32_t r0 = my_ring[0] >> 1;
+                d_cons = 1;
+                want = 1u;
+                want_at = p_start + r0 % p_deg;
+                if (kCount) ++n_fetch;
+                taken = true;
+                state = MS_CAND;
+            }
+        } else if (state == MS_CAND) {  // e0, e1 = the entry at the offset the trial drew
+            c0 = e0;
+            c1 = e1;
+            if (taken) {
+                adopt = true;
+            } else {  // a candidate from a row whose mask is only a filter: is it in t's row?
+                if (kCount) ++n_tests;
+                slot = edge_slot(t, c0.x, mask);
+                want = 3u;
+                state = MS_MEMBER;
+            }
+        } else if (state == MS_MEMBER || state == MS_POS) {  // e0 = {u, v, lo, cnt-1} of one slot
+            if (kCount) ++n_probes;
+            const bool empty = e0.x == 0xFFFFFFFFu;
+            const bool match = state == MS_MEMBER ? (e0.x == t && e0.y == c0.x) : (e0.x == prev && e0.y == t);
+            if (!empty && !match) {
+                slot = (slot + 1) & mask;
+                want = 3u;
+            } else if (state == MS_POS) {  // where t sits in prev's row
+                pos_lo = match ? e0.z : 0u;
+                pos_cnt = match ? e0.w + 1u : 0u;
+                state = MS_TRIAL;
+            } else if (ru < (match ? bp.t1 : bp.t2)) {
+                adopt = true;
+            } else {
+                state = MS_TRIAL;
+                if (++rejected >= kTrialCap) {
+                    st |= (uint32_t)kStTrialCap;
+                    adopt = true;
+                }
+            }
+        }
+        if (adopt) {  // step onto the entry in c0/c1
+            const uint32_t x = c0.x;
+            row.emit(x, s, L);
+            ++s;
+            rejected = 0;
+            t = prev;
+            prev = x;
+            p_start = c0.y;
+            p_deg = c0.z & ~kMaskIsFilter;
+            if (s > L) {
+                state = MS_START;
+            } else if (p_deg == 0) {  // dead end: reported, the walker stays
+                st |= TRW_ST_DEGREE0;
+                for (; s <= L; ++s) row.emit(prev, s, L);
+                state = MS_START;
+            } else {
+                exact = (c0.z & kMaskIsFilter) == 0u;
+                m0 = c1.x;
+                m1 = c1.y;
+                m2 = c1.z;
+                m3 = c1.w;
+                fm.init(p_deg);
+                pos_lo = c0.w & 0x0FFFFFFFu;
+                pos_cnt = c0.w >> 28;
+                state = MS_TRIAL;
+                if (c0.w == kRposLookup) {  // too many parallel edges / too far into the row for the packed form
+                    slot = edge_slot(prev, t, mask);
+                    want = 3u;
+                    state = MS_POS;
+                }
+            }
+        }
+
+        // ---- hand out walkers to the lanes that need one (one atomic per wave) ----
+        const unsigned long long need = __ballot(state == MS_START);
+        if (need) {
+            const int leader = (int)__ffsll((long long)need) - 1;
+            long long base = 0;
+            if (lane == leader)
+                base = (long long)atomicAdd((unsigned long long *)&status[kStNextWalker],
+                                            (unsigned long long)__popcll(need));
+            base = __shfl(base, leader);
+            if (state == MS_START) {
+                walker = base + __popcll(need & ((1ull << lane) - 1ull));
+                if (walker >= n_walkers) {
+                    state = MS_IDLE;
+                } else {
+                    const int64_t tg = targets[walker];
+                    row.sp = out + walker * (int64_t)(L + 1);
+                    if ((uint64_t)tg >= (uint64_t)n_nodes) {
+                        st |= TRW_ST_NODE_RANGE;  // reported; the row is filled with the bad id
+                        for (int32_t c = 0; c <= L; ++c) row.sp[c] = tg;
+                    } else {
+                        row.emit((uint32_t)tg, 0, L);  // column 0
+                        gw = (uint64_t)walker_base + (uint64_t)walker;
+                        d_cons = 0;
+                        d_prod = 0;
+                        s = 1;
+                        rejected = 0;
+                        prev = (uint32_t)tg;  // step 1 leaves the start node
+                        t = prev;
+                        want = 2u;
+                        want_at = prev;
+                        state = MS_ROW;
+                    }
+                }
+            }
+        }
+        if (__ballot(state != MS_IDLE) == 0) break;
+
+        // ---- top up the draw rings when some lane is about to run dry (all live lanes generate together) ----
+        const bool live = state != MS_IDLE && state != MS_START;
+        if (__ballot(live && d_prod - d_cons < 2u * kMaskBurst)) {
+            while (__ballot(live && d_prod - d_cons <= (uint32_t)(kMaskRing - 4))) {
+                if (live && d_prod - d_cons <= (uint32_t)(kMaskRing - 4)) {
+                    uint32_t blk[4];
+                    walker_block(gw, d_prod >> 2, seed, blk);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) my_ring[((d_prod + k) & (kMaskRing - 1)) * kBlock] = blk[k];
+                    d_prod += 4;
+                }
+            }
+        }
+
+        // ---- the trial burst: memory-free trials back to back, straight-line; a lane leaves at its first
+        //      accepted (or to-be-tested) offset ----
+#pragma unroll 1
+        for (int rep = 0; rep < kMaskBurst; ++rep) {
+            const bool act = state == MS_TRIAL && d_prod - d_cons >= 2u;
+            if (__ballot(act) == 0) break;
+            if (act) {
+                const uint32_t rc = my_ring[(d_cons & (kMaskRing - 1)) * kBlock] >> 1;
+                ru = my_ring[((d_cons + 1) & (kMaskRing - 1)) * kBlock] >> 1;
+                d_cons += 2;
+                if (kCount) ++n_trials;
+                const uint32_t idx = fm.mod(rc);
+                const uint32_t k = (idx >> 5) & 3u;
+                const uint32_t word = k == 0u ? m0 : (k == 1u ? m1 : (k == 2u ? m2 : m3));
+                const bool bit = (word >> (idx & 31u)) & 1u;
+                const uint32_t v_band = bit ? (exact ? v_set_exact : 2u) : v_clear;
+                const uint32_t v_other = ru < bp.lo ? 1u : (ru >= bp.hi ? 0u : v_band);
+                uint32_t verdict = (idx - pos_lo < pos_cnt) ? (ru < bp.t0 ? 1u : 0u) : v_other;
+                rejected = verdict == 0u ? rejected + 1u : rejected;
+                if (rejected >= kTrialCap) {  // take whatever this trial drew
+                    st |= (uint32_t)kStTrialCap;
+                    verdict = 1u;
+                }
+                if (verdict != 0u) {
+                    want = 1u;
+                    want_at = p_start + idx;
+                    if (kCount) ++n_fetch;
+                    taken = verdict == 1u;
+                    state = MS_CAND;
+                }
+            }
+        }
+
+        // ---- the gather of this iteration, collected at the top of the next ----
+        if (want != 0u) {
+            const uint32_t *addr = want == 1u ? reinterpret_cast<const uint32_t *>(ext + 2 * (size_t)want_at)
+                                              : (want == 2u ? row32 + want_at : table + 4 * slot);
+            e0 = *reinterpret_cast<const u32x4_a4 *>(addr);
+            if (want == 1u) e1 = *reinterpret_cast<const u32x4_a4 *>(addr + 4);
+        }
+        want = 0u;
     }
 
     if (st) atomicOr((unsigned long long *)&status[0], (unsigned long long)st);

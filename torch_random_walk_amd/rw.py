@@ -49,6 +49,41 @@ def walk_ex(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, walker_base
                                    rng_mode, _check_code(check), out)
 
 
+PREP_UNIFORM, PREP_BIASED, PREP_MARKS = (int(torch_rw_native.PREP_UNIFORM), int(torch_rw_native.PREP_BIASED),
+                                         int(torch_rw_native.PREP_MARKS))
+
+
+def prepare(row_ptr, col_idx, biased=True, uniform=False, marks=True):
+    """Build now what the GPU walks derive from ``(row_ptr, col_idx)`` alone and keep it for every later
+    ``walk`` over the same tensors (no reference counterpart: the reference re-reads the int64 CSR on each call).
+
+    ``walk`` does this by itself -- the first call over a graph prepares what one call is worth, the second
+    node2vec call adds the full neighbourhood masks -- so ``prepare`` is only a way to pay up front:
+    ``biased``: edge table + 32-byte fat entries (node2vec walks), ``marks``: with masks for long rows too
+    (about 5x the time, faster walks), ``uniform``: 16-byte fat entries for ``p == q == 1`` walks.
+    Valid while the two tensors are alive and not written to (an in-place write re-prepares on the next walk).
+    Returns the ``PREP_*`` bits the cached graph holds.
+    """
+    what = (PREP_BIASED if biased or marks else 0) | (PREP_MARKS if marks else 0) | (PREP_UNIFORM if uniform else 0)
+    return torch_rw_native.prepare(row_ptr, col_idx, what)
+
+
+def set_cache(on=True, capacity=0):
+    """Switch the prepared-graph cache on/off (off: every call prepares into its own workspace);
+    ``capacity`` > 0 sets how many graphs are kept (default 2, least recently used dropped first)."""
+    torch_rw_native.set_cache(bool(on), int(capacity))
+
+
+def clear_cache():
+    """Drop every cached prepared graph (their device memory goes back to the allocator)."""
+    torch_rw_native.clear_cache()
+
+
+def cache_info():
+    """``[(num_nodes, nnz, PREP_* bits, bytes, node2vec walks served), ...]``, most recently used first."""
+    return torch_rw_native.cache_info()
+
+
 def set_rng_mode(mode):
     """Process-wide RNG mode used by ``walk`` (RNG_AUTO / RNG_GLIBC / RNG_WALKER)."""
     torch_rw_native.set_rng_mode(mode)
