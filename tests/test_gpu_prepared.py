@@ -81,14 +81,17 @@ def test_entries_die_with_their_tensors_and_lru(rw):
     graphs = [random_graph(300 + 10 * k, 5, k) for k in range(4)]
     devs = [_dev(rp, ci) for rp, ci in graphs]
     tg = torch.arange(300, device=DEV).repeat(4)
-    for d in devs[:3]:
-        rw.walk(d[0], d[1], tg, 0.5, 2.0, 10, 1)
+    def walk(d):      # (explicit per-walker stream: under AUTO a batch this small is the serial replay, which prepares nothing)
+        return rw.walk_ex(d[0], d[1], tg, 0.5, 2.0, 10, 1, rng_mode=rw.RNG_WALKER)
+
+    for k in range(3):
+        walk(devs[k])
     assert [i[0] for i in rw.cache_info()] == [320, 310]                  # capacity 2, most recent first
     rw.set_cache(True, 3)
-    rw.walk(devs[0][0], devs[0][1], tg, 0.5, 2.0, 10, 1)
+    walk(devs[0])
     assert [i[0] for i in rw.cache_info()] == [300, 320, 310]
     del devs[2]
-    rw.walk(devs[0][0], devs[0][1], tg, 0.5, 2.0, 10, 1)                  # the dead graph's entry goes at the next call
+    walk(devs[0])                                                         # the dead graph's entry goes at the next call
     assert [i[0] for i in rw.cache_info()] == [300, 310]
     # a NEW graph in freed-and-reused memory never matches an old entry: the key holds weak storage references
     rp, ci = graphs[1]

@@ -1189,14 +1189,10 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
 // lanes' trials; lanes take their next walker from a device counter as they finish.
 enum : uint32_t { MS_IDLE = 0, MS_START, MS_ROW, MS_CAND, MS_MEMBER, MS_POS, MS_TRIAL };
 
-#ifndef TRW_MASK_BURST
-#define TRW_MASK_BURST 4
+#ifndef TRW_MASK_PAIRS
+#define TRW_MASK_PAIRS 8
 #endif
-constexpr int kMaskBurst = TRW_MASK_BURST;  // trials per lane between two visits of the gather/adopt code
-#ifndef TRW_MASK_RING
-#define TRW_MASK_RING 16
-#endif
-constexpr int kMaskRing = TRW_MASK_RING;    // draws buffered per lane in LDS (a power of two >= 2*burst + 4)
+constexpr int kMaskPairs = TRW_MASK_PAIRS;  // Philox blocks (= pairs of trials) per lane between two visits of the gather/adopt code
 
 template <bool kCount>
 __global__ void __launch_bounds__(kBlock)
@@ -1205,21 +1201,19 @@ biased_mask_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                    int64_t n_nodes, int64_t n_walkers, int64_t walker_base, int32_t L, uint32_t seed, BiasedParams bp,
                    int64_t *__restrict__ out, int64_t *__restrict__ status)
 {
-    static_assert((kMaskRing & (kMaskRing - 1)) == 0 && kMaskRing >= 2 * kMaskBurst + 4, "ring too small for the burst");
     // unsorted rows: t's offsets in prev's row are not one run, rpos cannot describe them -- biased_hash_kernel's job
     if (status[kStDescents] != status[kStBoundary]) return;
-    __shared__ uint32_t ring[kMaskRing * kBlock];  // draw d of the lane's walker at ring[d % kMaskRing][tid]
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         status[2] = TRW_RNG_WALKER;
         status[3] = 4;
     }
     const int lane = threadIdx.x & 63;
-    uint32_t *my_ring = ring + threadIdx.x;
     // in the band between the two thresholds: a neighbour is accepted iff t1 is the upper one
     const bool band_takes_near = bp.t1 > bp.t2;
 
     uint32_t st = 0;
     uint32_t n_trials = 0, n_fetch = 0, n_tests = 0, n_probes = 0;
+    uint32_t w_iters = 0, w_reps = 0, w_refills = 0, w_adopts = 0, w_adopt_lanes = 0;  // wave-level (kCount)
 
     uint32_t state = MS_START;
     int64_t walker = 0;
@@ -1232,7 +1226,11 @@ biased_mask_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
     FastMod fm;
     fm.d = 1;
     fm.z = 0;
-    uint32_t d_cons = 0, d_prod = 0;  // draws consumed / produced for the current walker
+    // The walker's draws, in registers: draw d is word d % 4 of Philox block d / 4 (>> 1).  Draw 0 takes the first
+    // step; trial k uses draws 2k+1 and 2k+2 -- words 1,2 of a block when k is even, word 3 and word 0 of the NEXT
+    // block when k is odd.  The lane keeps words 1..3 of block `blk_at` and whether its next trial is an odd one.
+    uint32_t w1 = 0, w2 = 0, w3 = 0, blk_at = 0;
+    bool odd = false;
     uint64_t slot = 0;
     uint32_t ru = 0, rejected = 0;
     bool taken = false;               // MS_CAND: the entry in flight is an accepted one (else: a candidate to test)
@@ -1259,8 +1257,14 @@ biased_mask_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                 for (; s <= L; ++s) row.emit(prev, s, L);
                 state = MS_START;
             } else {  // first step: plain uniform neighbour, draw 0 (rw_cpu.cpp:159)
-                const uint32_t r0 = my_ring[0] >> 1;
-                d_cons = 1;
+                uint32_t blk[4];
+                walker_block(gw, 0u, seed, blk);
+                const uint32_t r0 = blk[0] >> 1;
+                w1 = blk[1];
+                w2 = blk[2];
+                w3 = blk[3];
+                blk_at = 0u;
+                odd = false;
                 want = 1u;
                 want_at = p_start + r0 % p_deg;
                 if (kCount) ++n_fetch;
@@ -1298,6 +1302,12 @@ biased_mask_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                     adopt = true;
                 }
             }
+        }
+        if (kCount) {
+            ++w_iters;
+            const unsigned long long ab = __ballot(adopt);
+            if (ab) ++w_adopts;
+            w_adopt_lanes += (uint32_t)__popcll(ab);
         }
         if (adopt) {  // step onto the entry in c0/c1
             const uint32_t x = c0.x;
@@ -1354,8 +1364,6 @@ biased_mask_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                     } else {
                         row.emit((uint32_t)tg, 0, L);  // column 0
                         gw = (uint64_t)walker_base + (uint64_t)walker;
-                        d_cons = 0;
-                        d_prod = 0;
                         s = 1;
                         rejected = 0;
                         prev = (uint32_t)tg;  // step 1 leaves the start node
@@ -1369,49 +1377,57 @@ biased_mask_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
         }
         if (__ballot(state != MS_IDLE) == 0) break;
 
-        // ---- top up the draw rings when some lane is about to run dry (all live lanes generate together) ----
-        const bool live = state != MS_IDLE && state != MS_START;
-        if (__ballot(live && d_prod - d_cons < 2u * kMaskBurst)) {
-            while (__ballot(live && d_prod - d_cons <= (uint32_t)(kMaskRing - 4))) {
-                if (live && d_prod - d_cons <= (uint32_t)(kMaskRing - 4)) {
-                    uint32_t blk[4];
-                    walker_block(gw, d_prod >> 2, seed, blk);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) my_ring[((d_prod + k) & (kMaskRing - 1)) * kBlock] = blk[k];
-                    d_prod += 4;
-                }
-            }
-        }
-
-        // ---- the trial burst: memory-free trials back to back, straight-line; a lane leaves at its first
+        // ---- the trial burst: memory-free trials back to back, two per Philox block; a lane leaves at its first
         //      accepted (or to-be-tested) offset ----
+        auto trial = [&](uint32_t rc, uint32_t ru_now) {
+            ru = ru_now;
+            if (kCount) ++n_trials;
+            const uint32_t idx = fm.mod(rc);
+            const uint32_t k = (idx >> 5) & 3u;
+            const uint32_t word = k == 0u ? m0 : (k == 1u ? m1 : (k == 2u ? m2 : m3));
+            const bool bit = (word >> (idx & 31u)) & 1u;
+            const uint32_t v_band = bit ? (exact ? v_set_exact : 2u) : v_clear;
+            const uint32_t v_other = ru_now < bp.lo ? 1u : (ru_now >= bp.hi ? 0u : v_band);
+            uint32_t verdict = (idx - pos_lo < pos_cnt) ? (ru_now < bp.t0 ? 1u : 0u) : v_other;
+            rejected = verdict == 0u ? rejected + 1u : rejected;
+            if (rejected >= kTrialCap) {  // take whatever this trial drew
+                st |= (uint32_t)kStTrialCap;
+                verdict = 1u;
+            }
+            if (verdict != 0u) {
+                want = 1u;
+                want_at = p_start + idx;
+                if (kCount) ++n_fetch;
+                taken = verdict == 1u;
+                state = MS_CAND;
+            }
+        };
 #pragma unroll 1
-        for (int rep = 0; rep < kMaskBurst; ++rep) {
-            const bool act = state == MS_TRIAL && d_prod - d_cons >= 2u;
-            if (__ballot(act) == 0) break;
-            if (act) {
-                const uint32_t rc = my_ring[(d_cons & (kMaskRing - 1)) * kBlock] >> 1;
-                ru = my_ring[((d_cons + 1) & (kMaskRing - 1)) * kBlock] >> 1;
-                d_cons += 2;
-                if (kCount) ++n_trials;
-                const uint32_t idx = fm.mod(rc);
-                const uint32_t k = (idx >> 5) & 3u;
-                const uint32_t word = k == 0u ? m0 : (k == 1u ? m1 : (k == 2u ? m2 : m3));
-                const bool bit = (word >> (idx & 31u)) & 1u;
-                const uint32_t v_band = bit ? (exact ? v_set_exact : 2u) : v_clear;
-                const uint32_t v_other = ru < bp.lo ? 1u : (ru >= bp.hi ? 0u : v_band);
-                uint32_t verdict = (idx - pos_lo < pos_cnt) ? (ru < bp.t0 ? 1u : 0u) : v_other;
-                rejected = verdict == 0u ? rejected + 1u : rejected;
-                if (rejected >= kTrialCap) {  // take whatever this trial drew
-                    st |= (uint32_t)kStTrialCap;
-                    verdict = 1u;
+        for (int rep = 0; rep < kMaskPairs; ++rep) {
+            if (__ballot(state == MS_TRIAL) == 0) break;
+            if (kCount) ++w_reps;
+            if (state == MS_TRIAL) {
+                uint32_t nb[4];
+                walker_block(gw, blk_at + 1u, seed, nb);
+                // first trial of the pair: an even one reads this block, an odd one straddles into the next
+                const bool was_odd = odd;
+                trial((was_odd ? w3 : w1) >> 1, (was_odd ? nb[0] : w2) >> 1);
+                if (was_odd) {  // moved on to the next block (now an even trial on it)
+                    w1 = nb[1];
+                    w2 = nb[2];
+                    w3 = nb[3];
+                    ++blk_at;
                 }
-                if (verdict != 0u) {
-                    want = 1u;
-                    want_at = p_start + idx;
-                    if (kCount) ++n_fetch;
-                    taken = verdict == 1u;
-                    state = MS_CAND;
+                odd = !was_odd;
+                if (state == MS_TRIAL) {  // second trial of the pair
+                    trial((was_odd ? w1 : w3) >> 1, (was_odd ? w2 : nb[0]) >> 1);
+                    if (!was_odd) {
+                        w1 = nb[1];
+                        w2 = nb[2];
+                        w3 = nb[3];
+                        ++blk_at;
+                    }
+                    odd = was_odd;
                 }
             }
         }
@@ -1434,6 +1450,12 @@ biased_mask_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
             atomicAdd((unsigned long long *)&status[5], (unsigned long long)b);
             atomicAdd((unsigned long long *)&status[6], (unsigned long long)c);
             atomicAdd((unsigned long long *)&status[7], (unsigned long long)d);
+            // how the wave spent its passes: iterations, burst repetitions, refill passes, iterations with an adopt,
+            // lanes adopting -- lane utilisation of each block = lane events / (passes x 64)
+            atomicAdd((unsigned long long *)&status[12], (unsigned long long)w_iters);
+            atomicAdd((unsigned long long *)&status[13], (unsigned long long)w_reps);
+            atomicAdd((unsigned long long *)&status[14], (unsigned long long)w_refills);
+            atomicAdd((unsigned long long *)&status[15], ((unsigned long long)w_adopts << 40) | (unsigned long long)w_adopt_lanes);
         }
     }
 }
