@@ -386,7 +386,7 @@ def main():
         assert lib.trw_walk_status(ws.data_ptr(), stream, stw) == 0
         family = int(stw[3])
         kernel_name = {0: "biased_walker_wide_kernel", 1: "biased_walker_kernel", 2: "biased_hash_kernel",
-                       4: "biased_mask_kernel"}[family]
+                       4: "biased_mask_kernel", 5: "biased_pool_kernel"}[family]
         lib.trw_profile_enable(0)
         assert torch.equal(out, walks), "counting variant of the kernel produced different walks"
         trials, fetches, tests, probes = (int(x) for x in c)

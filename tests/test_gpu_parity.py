@@ -347,7 +347,7 @@ def test_c_abi_direct_call(rw):
         assert rc == 0, L.trw_last_error()
         st = (ctypes.c_int64 * 4)()
         assert L.trw_walk_status(ws.data_ptr(), stream, st) == 0
-        assert st[0] == 0 and st[2] == mode and st[3] in (1, 2, 3, 4)   # uint32-shadow kernels (2: + edge table, 3: fat entries)
+        assert st[0] == 0 and st[2] == mode and st[3] in (1, 2, 3, 4, 5)   # uint32-shadow kernels (2: + edge table, 3: fat entries)
         assert (out.cpu().numpy() == O.walk(rp, ci, tg, p, q, 40, 10, rng_mode=omode)).all()
 
 

@@ -232,4 +232,4 @@ def test_prepared_c_abi_direct(rw):
             assert L.trw_walk_status(ws.data_ptr(), stream, st) == 0 and st[0] == 0
             assert (out.cpu().numpy() == O.walk(rp, ci, tg, p, q, Lw, 10, rng_mode=omode)).all(), (what, p, q, mode)
             if what in (2, 6, 7) and mode == 2 and p != 1.0:
-                assert st[3] == 4                                  # the mask kernel
+                assert st[3] in (4, 5)                             # the mask / walker-pool kernel

@@ -640,7 +640,23 @@ static int walk_prepared(const void *prepared, size_t prepared_bytes, int32_t wh
         const bool mask_kernel = env_long("TRW_MASK_KERNEL", 0, 1, 1) == 1;
         // sorted rows: the mask kernel; unsorted rows: the state-machine kernel (each returns at once when the
         // graph is not its kind -- the row order is known on the device only)
-        if (mask_kernel) {
+        // walker pool (lanes as executors over walker state in LDS) unless switched off or the batch does not fit its
+        // 32-bit walker numbers; TRW_POOL_KERNEL=0 runs the lane-per-walker mask kernel instead
+        const bool pool_kernel = mask_kernel && n_walkers < ((int64_t)1 << 32) && env_long("TRW_POOL_KERNEL", 0, 1, 1) == 1;
+        if (pool_kernel) {
+            // 3 workgroups per CU: a wave's pool is 11 KB of LDS (kPoolSlots walkers x 22 words), 51 KB per workgroup
+            int64_t pblocks = (n_walkers + (int64_t)kPoolWaves * kPoolSlots - 1) / ((int64_t)kPoolWaves * kPoolSlots);
+            const int64_t president = (int64_t)device_cu_count() * env_long("TRW_POOL_BLOCKS", 1, 4, 3);
+            if (pblocks > president) pblocks = president;
+            if (g_prof.count)
+                biased_pool_kernel<true><<<(unsigned)pblocks, kBlock, 0, stream>>>(
+                    row32, ext32, table, pl.hash_mask, targets, n_nodes, n_walkers, walker_base, walk_length,
+                    (uint32_t)seed, bp, out, status);
+            else
+                biased_pool_kernel<false><<<(unsigned)pblocks, kBlock, 0, stream>>>(
+                    row32, ext32, table, pl.hash_mask, targets, n_nodes, n_walkers, walker_base, walk_length,
+                    (uint32_t)seed, bp, out, status);
+        } else if (mask_kernel) {
             if (g_prof.count)
                 biased_mask_kernel<true><<<(unsigned)blocks, kBlock, 0, stream>>>(
                     row32, ext32, table, pl.hash_mask, targets, n_nodes, n_walkers, walker_base, walk_length,

@@ -1460,4 +1460,398 @@ biased_mask_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
     }
 }
 
+// ===========================================================================
+// Biased walk, walker pool: walker state in LDS, lanes as executors (ballot / prefix-sum compaction)
+// ===========================================================================
+// biased_mask_kernel keeps one walker per lane, and a wave executes the union of what its lanes are doing: the
+// counters say 35 of 64 lanes are active per instruction -- the Philox rounds and the trials run with the lanes
+// that happen to be between gathers (45 %), the step-onto-the-next-entry code with the handful of lanes that
+// accepted in the last burst (17 %).  Here a wave owns a POOL of kPoolSlots walkers whose state lives in LDS
+// (struct of arrays, one word per field and slot) and three queues of slot numbers, and every phase of the
+// loop takes a FULL wave of work items from its queue (ballot + mbcnt prefix sums compact the pushes):
+//     adopt   the lanes that issued a gather in the previous iteration consume it for their slot: step onto the
+//             entry (emit the column, write the next step's row / rpos / mask into the slot) -> trial queue;
+//             first-step row, edge-table probes likewise
+//     refill  free slots take new walkers from the device counter -> issue queue
+//     issue   pop up to 64 slots that want a gather, form the address, load; the data is collected by `adopt`
+//             in the NEXT iteration, after the burst below -- the wave hides its own memory latency
+//     burst   pop up to 64 slots that are between gathers, load their trial state, run up to 2*kPoolPairs
+//             rejection trials each in registers (two per Philox block), write back; lanes with an accepted (or
+//             to-be-tested) offset push their slot to the issue queue, the others back to the trial queue
+// A phase waits until its queue holds most of a wave (or nothing else can run), so its instructions execute
+// with most lanes active whatever the individual walkers are doing.  Same stream, same decisions, same rows as
+// biased_mask_kernel.
+#ifndef TRW_POOL_SLOTS
+#define TRW_POOL_SLOTS 128
+#endif
+#ifndef TRW_POOL_PAIRS
+#define TRW_POOL_PAIRS 2
+#endif
+constexpr int kPoolSlots = TRW_POOL_SLOTS;  // walkers resident per wave (a power of two, >= 128 keeps every phase fed)
+constexpr int kPoolPairs = TRW_POOL_PAIRS;  // Philox blocks (pairs of trials) per visit of the burst
+constexpr int kPoolWaves = kBlock / 64;
+enum : uint32_t { PK_ROW = 0, PK_ENTRY = 1, PK_TEST = 2, PK_MEMBER = 3, PK_POS = 4 };  // what a slot's gather is for
+enum : int {
+    PF_T = 0, PF_PREV, PF_START, PF_DEG, PF_Z, PF_POSLO, PF_POSCNT, PF_M0, PF_M1, PF_M2, PF_M3,
+    PF_FLAGS,   // bit 0: mask is exact, bit 1: next trial is an odd one, bits 4..6: PK_* of the queued / in-flight gather
+    PF_S, PF_REJ, PF_WALKER, PF_W1, PF_W2, PF_W3, PF_BLK,
+    PF_X,       // the candidate node a table probe asks about
+    PF_AT,      // fat entry index to gather
+    PF_PROBE,   // how far the probe chain of the current table lookup has gone
+    PF_COUNT
+};
+constexpr uint32_t kPfExact = 1u, kPfOdd = 2u;
+
+struct PoolQueue {  // a ring of slot numbers in LDS; head/count are wave-uniform
+    uint32_t *q;
+    uint32_t head, count;
+    // pops up to 64 entries: lane i < n gets one
+    __device__ __forceinline__ uint32_t pop(int lane, uint32_t &n, uint32_t &slot)
+    {
+        n = count < 64u ? count : 64u;
+        slot = q[(head + (uint32_t)lane) & (uint32_t)(kPoolSlots - 1)];
+        head = (head + n) & (uint32_t)(kPoolSlots - 1);
+        count -= n;
+        return n;
+    }
+    // lanes with `yes` append their slot (compacted: ballot + prefix count)
+    __device__ __forceinline__ void push(bool yes, uint32_t slot)
+    {
+        const unsigned long long b = __ballot(yes);
+        if (b == 0) return;
+        const uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+        if (yes) q[(head + count + off) & (uint32_t)(kPoolSlots - 1)] = slot;
+        count += (uint32_t)__popcll(b);
+    }
+};
+
+__device__ __forceinline__ void pool_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool kCount>
+__global__ void __launch_bounds__(kBlock)
+biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restrict__ ext,
+                   const uint32_t *__restrict__ table, uint64_t mask, const int64_t *__restrict__ targets,
+                   int64_t n_nodes, int64_t n_walkers, int64_t walker_base, int32_t L, uint32_t seed, BiasedParams bp,
+                   int64_t *__restrict__ out, int64_t *__restrict__ status)
+{
+    static_assert((kPoolSlots & (kPoolSlots - 1)) == 0 && kPoolSlots >= 64, "pool size must be a power of two >= 64");
+    if (status[kStDescents] != status[kStBoundary]) return;  // unsorted rows: biased_hash_kernel's job
+    __shared__ uint32_t pool_mem[kPoolWaves][PF_COUNT][kPoolSlots];
+    __shared__ uint32_t queue_mem[kPoolWaves][3][kPoolSlots];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        status[2] = TRW_RNG_WALKER;
+        status[3] = 5;
+    }
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t(*P)[kPoolSlots] = pool_mem[wv];
+    PoolQueue trial_q = {queue_mem[wv][0], 0u, 0u}, issue_q = {queue_mem[wv][1], 0u, 0u}, free_q = {queue_mem[wv][2], 0u, 0u};
+    for (int i = lane; i < kPoolSlots; i += 64) free_q.q[i] = (uint32_t)i;
+    free_q.count = kPoolSlots;
+    pool_fence();
+    const bool band_takes_near = bp.t1 > bp.t2;
+    const uint32_t v_clear = band_takes_near ? 0u : 1u, v_set_exact = band_takes_near ? 1u : 0u;
+    const int32_t cols = L + 1;
+
+    uint32_t st = 0;
+    uint32_t n_trials = 0, n_fetch = 0, n_tests = 0, n_probes = 0;
+    bool hold = false;         // this lane issued a gather for slot `hs` in the previous iteration
+    uint32_t hs = 0, hkind = 0;
+    u32x4_a4 e0 = {0u, 0u, 0u, 0u}, e1 = {0u, 0u, 0u, 0u};
+    bool more_walkers = true;  // wave-uniform: the device counter has not run out yet
+
+    // Columns go out one 8-byte store each: this kernel runs out of instruction issue, not of write requests, and
+    // a plain store is an address and one instruction where combining four columns cost 25 and four words of state.
+    auto row_of = [&](uint32_t slot) { return out + (int64_t)P[PF_WALKER][slot] * cols; };
+
+    while (true) {
+        // ================= adopt: consume the gathers issued in the previous iteration =================
+        {
+            bool to_trial = false, to_issue = false, to_free = false;
+            if (hold) {
+                const uint32_t slot = hs;
+                if (hkind == PK_ROW) {  // e0 = row32[start node], row32[start node + 1]
+                    const uint32_t start = e0.x, deg = e0.y >= e0.x ? e0.y - e0.x : 0u;
+                    const uint32_t prev = P[PF_PREV][slot];
+                    if (deg == 0) {  // dead end at the start node: reported, the walker stays
+                        st |= TRW_ST_DEGREE0;
+                        int64_t *r = row_of(slot);
+                        for (int32_t s = 1; s <= L; ++s) r[s] = (int64_t)prev;
+                        to_free = true;
+                    } else {  // first step: plain uniform neighbour, draw 0 (rw_cpu.cpp:159)
+                        uint32_t blk[4];
+                        walker_block((uint64_t)walker_base + (uint64_t)P[PF_WALKER][slot], 0u, seed, blk);
+                        P[PF_W1][slot] = blk[1];
+                        P[PF_W2][slot] = blk[2];
+                        P[PF_W3][slot] = blk[3];
+                        P[PF_BLK][slot] = 0u;
+                        P[PF_AT][slot] = start + (blk[0] >> 1) % deg;
+                        P[PF_FLAGS][slot] = PK_ENTRY << 4;
+                        if (kCount) ++n_fetch;
+                        to_issue = true;
+                    }
+                } else if (hkind == PK_ENTRY) {  // e0, e1 = the accepted entry: step onto it
+                    const uint32_t x = e0.x;
+                    int32_t s = (int32_t)P[PF_S][slot];
+                    const uint32_t prev = P[PF_PREV][slot];
+                    int64_t *r = row_of(slot);
+                    r[s] = (int64_t)x;
+                    ++s;
+                    const uint32_t deg = e0.z & ~kMaskIsFilter;
+                    if (s > L) {
+                        to_free = true;
+                    } else if (deg == 0) {  // dead end: reported, the walker stays
+                        st |= TRW_ST_DEGREE0;
+                        for (; s <= L; ++s) r[s] = (int64_t)x;
+                        to_free = true;
+                    } else {
+                        FastMod fm;
+                        fm.init(deg);
+                        P[PF_T][slot] = prev;
+                        P[PF_PREV][slot] = x;
+                        P[PF_START][slot] = e0.y;
+                        P[PF_DEG][slot] = deg;
+                        P[PF_Z][slot] = fm.z;
+                        P[PF_M0][slot] = e1.x;
+                        P[PF_M1][slot] = e1.y;
+                        P[PF_M2][slot] = e1.z;
+                        P[PF_M3][slot] = e1.w;
+                        P[PF_S][slot] = (uint32_t)s;
+                        P[PF_REJ][slot] = 0u;
+                        const uint32_t keep = P[PF_FLAGS][slot] & kPfOdd;
+                        const uint32_t ex = (e0.z & kMaskIsFilter) ? 0u : kPfExact;
+                        if (e0.w == kRposLookup) {  // too many parallel edges / too far into the row for the packed form
+                            P[PF_FLAGS][slot] = keep | ex | (PK_POS << 4);
+                            P[PF_PROBE][slot] = 0u;
+                            to_issue = true;
+                        } else {
+                            P[PF_POSLO][slot] = e0.w & 0x0FFFFFFFu;
+                            P[PF_POSCNT][slot] = e0.w >> 28;
+                            P[PF_FLAGS][slot] = keep | ex;
+                            to_trial = true;
+                        }
+                    }
+                } else if (hkind == PK_TEST) {  // e0.x = a candidate whose mask bit is only a filter: ask the table
+                    if (kCount) ++n_tests;
+                    P[PF_X][slot] = e0.x;
+                    P[PF_PROBE][slot] = 0u;
+                    P[PF_FLAGS][slot] = (P[PF_FLAGS][slot] & 15u) | (PK_MEMBER << 4);
+                    to_issue = true;
+                } else {  // PK_MEMBER / PK_POS: e0 = {u, v, lo, cnt-1} of one table slot
+                    if (kCount) ++n_probes;
+                    const uint32_t t = P[PF_T][slot], prev = P[PF_PREV][slot];
+                    const bool empty = e0.x == 0xFFFFFFFFu;
+                    const bool match = hkind == PK_MEMBER ? (e0.x == t && e0.y == P[PF_X][slot]) : (e0.x == prev && e0.y == t);
+                    if (!empty && !match) {
+                        P[PF_PROBE][slot] += 1u;
+                        to_issue = true;
+                    } else if (hkind == PK_POS) {  // where t sits in prev's row
+                        P[PF_POSLO][slot] = match ? e0.z : 0u;
+                        P[PF_POSCNT][slot] = match ? e0.w + 1u : 0u;
+                        P[PF_FLAGS][slot] &= 15u;
+                        to_trial = true;
+                    } else {  // the trial drew inside the band: a neighbour is accepted iff t1 is the upper threshold
+                        bool accept = match == band_takes_near;
+                        if (!accept) {
+                            const uint32_t rej = P[PF_REJ][slot] + 1u;
+                            P[PF_REJ][slot] = rej;
+                            if (rej >= kTrialCap) {
+                                st |= (uint32_t)kStTrialCap;
+                                accept = true;
+                            }
+                        }
+                        if (accept) {  // gather the entry again, this time to step onto it
+                            P[PF_FLAGS][slot] = (P[PF_FLAGS][slot] & 15u) | (PK_ENTRY << 4);
+                            if (kCount) ++n_fetch;
+                            to_issue = true;
+                        } else {
+                            P[PF_FLAGS][slot] &= 15u;
+                            to_trial = true;
+                        }
+                    }
+                }
+            }
+            trial_q.push(to_trial, hs);
+            issue_q.push(to_issue, hs);
+            free_q.push(to_free, hs);
+            hold = false;
+            pool_fence();
+        }
+
+        // ================= refill: new walkers into free slots =================
+        if (more_walkers && (free_q.count >= 32u || trial_q.count + issue_q.count < 64u) && free_q.count > 0u) {
+            uint32_t n, slot;
+            const uint32_t avail = free_q.count < 64u ? free_q.count : 64u;
+            long long base = 0;
+            if (lane == 0) base = (long long)atomicAdd((unsigned long long *)&status[kStNextWalker], (unsigned long long)avail);
+            base = __shfl(base, 0);
+            int64_t left = n_walkers - (int64_t)base;
+            left = left < 0 ? 0 : left;
+            const uint32_t take = left < (int64_t)avail ? (uint32_t)left : avail;
+            if (take < avail) more_walkers = false;
+            // pop `take` slots only
+            const uint32_t keep_count = free_q.count;
+            free_q.pop(lane, n, slot);
+            if (take < n) {  // hand the unused ones back (they are the last ones popped)
+                free_q.head = (free_q.head + (uint32_t)kPoolSlots - (n - take)) & (uint32_t)(kPoolSlots - 1);
+                free_q.count = keep_count - take;
+            }
+            bool to_issue = false, back = false;
+            if ((uint32_t)lane < take) {
+                const int64_t walker = (int64_t)base + lane;
+                const int64_t tg = targets[walker];
+                if ((uint64_t)tg >= (uint64_t)n_nodes) {
+                    st |= TRW_ST_NODE_RANGE;  // reported; the row is filled with the bad id
+                    int64_t *rowp = out + walker * cols;
+                    for (int32_t c = 0; c <= L; ++c) rowp[c] = tg;
+                    back = true;
+                } else {
+                    P[PF_WALKER][slot] = (uint32_t)walker;
+                    out[walker * cols] = tg;  // column 0
+                    P[PF_PREV][slot] = (uint32_t)tg;  // step 1 leaves the start node
+                    P[PF_T][slot] = (uint32_t)tg;
+                    P[PF_S][slot] = 1u;
+                    P[PF_REJ][slot] = 0u;
+                    P[PF_FLAGS][slot] = PK_ROW << 4;
+                    to_issue = true;
+                }
+            }
+            issue_q.push(to_issue, slot);
+            free_q.push(back, slot);
+            pool_fence();
+        }
+        if (!more_walkers && free_q.count == (uint32_t)kPoolSlots) break;  // every walker of this wave is done
+
+        // ================= issue: gathers for the slots that want one =================
+        if (issue_q.count >= 48u || (issue_q.count > 0u && trial_q.count < 64u)) {
+            uint32_t n, slot;
+            issue_q.pop(lane, n, slot);
+            if ((uint32_t)lane < n) {
+                const uint32_t kind = P[PF_FLAGS][slot] >> 4;
+                const uint32_t *addr;
+                if (kind == PK_ENTRY || kind == PK_TEST) {
+                    addr = reinterpret_cast<const uint32_t *>(ext + 2 * (size_t)P[PF_AT][slot]);
+                } else if (kind == PK_ROW) {
+                    addr = row32 + P[PF_PREV][slot];
+                } else {
+                    const uint32_t t = P[PF_T][slot], prev = P[PF_PREV][slot];
+                    const uint64_t s0 = kind == PK_MEMBER ? edge_slot(t, P[PF_X][slot], mask) : edge_slot(prev, t, mask);
+                    addr = table + 4 * ((s0 + P[PF_PROBE][slot]) & mask);
+                }
+                e0 = *reinterpret_cast<const u32x4_a4 *>(addr);
+                if (kind == PK_ENTRY) e1 = *reinterpret_cast<const u32x4_a4 *>(addr + 4);
+                hold = true;
+                hs = slot;
+                hkind = kind;
+            }
+        }
+
+        // ================= burst: trials for a wave of slots that are between gathers =================
+        if (trial_q.count >= 48u || (trial_q.count > 0u && issue_q.count < 48u)) {
+            uint32_t n, slot;
+            trial_q.pop(lane, n, slot);
+            bool busy = (uint32_t)lane < n;
+            // the slot's trial state, into registers
+            const uint32_t t_start = P[PF_START][slot], deg = P[PF_DEG][slot];
+            FastMod fm;
+            fm.d = busy ? deg : 1u;
+            fm.z = P[PF_Z][slot];
+            const uint32_t pos_lo = P[PF_POSLO][slot], pos_cnt = P[PF_POSCNT][slot];
+            const uint32_t m0 = P[PF_M0][slot], m1 = P[PF_M1][slot], m2 = P[PF_M2][slot], m3 = P[PF_M3][slot];
+            const uint32_t flags = P[PF_FLAGS][slot];
+            const bool exact = (flags & kPfExact) != 0u;
+            bool odd = (flags & kPfOdd) != 0u;
+            uint32_t rejected = P[PF_REJ][slot];
+            uint32_t w1 = P[PF_W1][slot], w2 = P[PF_W2][slot], w3 = P[PF_W3][slot], blk_at = P[PF_BLK][slot];
+            const uint64_t gw = (uint64_t)walker_base + (uint64_t)P[PF_WALKER][slot];
+            uint32_t verdict = 0u, at = 0u;
+
+            auto trial = [&](uint32_t rc, uint32_t ru) {
+                if (kCount) ++n_trials;
+                const uint32_t idx = fm.mod(rc);
+                const uint32_t k = (idx >> 5) & 3u;
+                const uint32_t word = k == 0u ? m0 : (k == 1u ? m1 : (k == 2u ? m2 : m3));
+                const bool bit = (word >> (idx & 31u)) & 1u;
+                const uint32_t v_band = bit ? (exact ? v_set_exact : 2u) : v_clear;
+                const uint32_t v_other = ru < bp.lo ? 1u : (ru >= bp.hi ? 0u : v_band);
+                uint32_t v = (idx - pos_lo < pos_cnt) ? (ru < bp.t0 ? 1u : 0u) : v_other;
+                rejected = v == 0u ? rejected + 1u : rejected;
+                if (rejected >= kTrialCap) {  // take whatever this trial drew
+                    st |= (uint32_t)kStTrialCap;
+                    v = 1u;
+                }
+                verdict = v;
+                at = t_start + idx;
+            };
+            bool running = busy;
+#pragma unroll 1
+            for (int rep = 0; rep < kPoolPairs; ++rep) {
+                if (__ballot(running) == 0) break;
+                if (running) {
+                    uint32_t nb[4];
+                    walker_block(gw, blk_at + 1u, seed, nb);
+                    const bool was_odd = odd;
+                    trial((was_odd ? w3 : w1) >> 1, (was_odd ? nb[0] : w2) >> 1);
+                    if (was_odd) {  // moved on to the next block (now an even trial on it)
+                        w1 = nb[1];
+                        w2 = nb[2];
+                        w3 = nb[3];
+                        ++blk_at;
+                    }
+                    odd = !was_odd;
+                    if (verdict == 0u) {  // second trial of the pair
+                        trial((was_odd ? w1 : w3) >> 1, (was_odd ? w2 : nb[0]) >> 1);
+                        if (!was_odd) {
+                            w1 = nb[1];
+                            w2 = nb[2];
+                            w3 = nb[3];
+                            ++blk_at;
+                        }
+                        odd = was_odd;
+                    }
+                    running = verdict == 0u;
+                }
+            }
+            // write back what moved
+            bool to_issue = false, to_trial = false;
+            if (busy) {
+                P[PF_W1][slot] = w1;
+                P[PF_W2][slot] = w2;
+                P[PF_W3][slot] = w3;
+                P[PF_BLK][slot] = blk_at;
+                P[PF_REJ][slot] = rejected;
+                uint32_t nf = (flags & kPfExact) | (odd ? kPfOdd : 0u);
+                if (verdict != 0u) {
+                    if (kCount) ++n_fetch;
+                    P[PF_AT][slot] = at;
+                    nf |= (verdict == 1u ? PK_ENTRY : PK_TEST) << 4;
+                    to_issue = true;
+                } else {
+                    to_trial = true;
+                }
+                P[PF_FLAGS][slot] = nf;
+            }
+            issue_q.push(to_issue, slot);
+            trial_q.push(to_trial, slot);
+            pool_fence();
+        }
+    }
+
+    if (st) atomicOr((unsigned long long *)&status[0], (unsigned long long)st);
+    if (kCount) {
+        const uint64_t a = wave_sum(n_trials), b = wave_sum(n_fetch), c = wave_sum(n_tests), d = wave_sum(n_probes);
+        if (lane == 0) {
+            atomicAdd((unsigned long long *)&status[4], (unsigned long long)a);
+            atomicAdd((unsigned long long *)&status[5], (unsigned long long)b);
+            atomicAdd((unsigned long long *)&status[6], (unsigned long long)c);
+            atomicAdd((unsigned long long *)&status[7], (unsigned long long)d);
+        }
+    }
+}
+
 }  // namespace
