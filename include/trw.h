@@ -139,9 +139,10 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes,
  *                       deg(v), where-the-reverse-edge-sits, 128-bit "is the node at this offset a neighbour
  *                       of the node I came from" mask}: a node2vec rejection trial is decided in registers and
  *                       the graph is read once per step.  Masks are worked out for entries one of whose rows
- *                       has at most 8 entries; the rest ask the table.
- *     TRW_PREP_MARKS    (implies BIASED) masks for every entry one of whose rows has at most 4096 entries:
- *                       about 5x the prepare time, pays when the graph is walked more than once
+ *                       has at most 32 entries; the rest ask the table.
+ *     TRW_PREP_MARKS    (implies BIASED) masks for every entry one of whose rows has at most 256 entries:
+ *                       about 3.5x the prepare time, 30 % faster walks -- pays from about 3 walks of a graph
+ *     TRW_PREP_MARKS_FULL (implies MARKS) ... at most 4096 entries: about 10x the prepare time, another 10 %
  *   or one of          TRW_PREP_ORDER_ONLY: no shadow, only the row-order probe the int64 biased kernels want;
  *                      TRW_PREP_NOTHING: header only (uniform walk on the per-walker stream)
  * trw_prepare_plan returns the `what` one call of the given shape is worth (what trw_walk_csr_hip builds).
@@ -152,6 +153,7 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes,
 #define TRW_PREP_UNIFORM     1
 #define TRW_PREP_BIASED      2
 #define TRW_PREP_MARKS       4
+#define TRW_PREP_MARKS_FULL  8
 #define TRW_PREP_ORDER_ONLY (-1)
 #define TRW_PREP_NOTHING    (-2)
 int32_t trw_prepare_plan(int64_t n_nodes, int64_t nnz, int64_t n_walkers, int32_t walk_length,

@@ -131,6 +131,12 @@ def test_every_marking_path_walks_the_same_rows(rw, deg, inline_cap, monkeypatch
     assert rw.prepare(d_rp, d_ci) == rw.PREP_BIASED | rw.PREP_MARKS
     assert (rw.walk(d_rp, d_ci, d_tg, 0.25, 4.0, 25, 9).cpu().numpy() == O.walk(rp, ci, tg, 0.25, 4.0, 25, 9, rng_mode=O.RNG_WALKER)).all()
     assert rw.prepare(d_rp, d_ci, biased=False, marks=False, uniform=True) == rw.PREP_BIASED | rw.PREP_MARKS | rw.PREP_UNIFORM
+    full = rw.PREP_BIASED | rw.PREP_MARKS | rw.PREP_MARKS_FULL | rw.PREP_UNIFORM
+    assert rw.prepare(d_rp, d_ci, marks="full") == full
+    for p, q in ((0.25, 4.0), (4.0, 0.25)):
+        assert (rw.walk_ex(d_rp, d_ci, d_tg, p, q, 25, 9, rng_mode=rw.RNG_WALKER).cpu().numpy()
+                == O.walk(rp, ci, tg, p, q, 25, 9, rng_mode=O.RNG_WALKER)).all()
+    assert rw.cache_info()[0][2] == full
 
 
 @pytest.mark.parametrize("env", [{"TRW_MASK_KERNEL": "0"}, {"TRW_MASK_KERNEL": "0", "TRW_NO_POS": "1"},
@@ -213,7 +219,7 @@ def test_prepared_c_abi_direct(rw):
     d_rp, d_ci, d_tg = _dev(rp, ci, tg)
     stream = torch.cuda.current_stream().cuda_stream
     n, nnz, N, Lw = 700, len(ci), 3000, 30
-    for what in (0, 1, 2, 6, 7, -1, -2):
+    for what in (0, 1, 2, 6, 7, 14, -1, -2):
         pb = L.trw_prepare_csr_bytes(n, nnz, what)
         blob = torch.empty(pb, dtype=torch.uint8, device=DEV)
         assert L.trw_prepare_csr_hip(d_rp.data_ptr(), n, d_ci.data_ptr(), nnz, what, blob.data_ptr(), pb, stream) == 0
@@ -231,5 +237,5 @@ def test_prepared_c_abi_direct(rw):
             st = (ctypes.c_int64 * 4)()
             assert L.trw_walk_status(ws.data_ptr(), stream, st) == 0 and st[0] == 0
             assert (out.cpu().numpy() == O.walk(rp, ci, tg, p, q, Lw, 10, rng_mode=omode)).all(), (what, p, q, mode)
-            if what in (2, 6, 7) and mode == 2 and p != 1.0:
+            if what in (2, 6, 7, 14) and mode == 2 and p != 1.0:
                 assert st[3] in (4, 5)                             # the mask / walker-pool kernel

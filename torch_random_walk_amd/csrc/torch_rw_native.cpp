@@ -132,8 +132,8 @@ torch::Tensor walk_cpu_leg(const torch::Tensor &row_ptr, const torch::Tensor &co
 // exactly the storages it was built from, while they are alive (weak references: a freed-and-reused address can
 // not match) and unmodified (tensor version counters: an in-place write invalidates).  Policy: the first walk
 // builds what a single call of its shape is worth; the second node2vec walk over the same graph also builds the
-// full neighbourhood masks (TRW_PREP_MARKS: about 5x the prepare time, then every later walk is faster);
-// rw.prepare() asks for them up front.  Least-recently-used graphs beyond `capacity` are dropped; entries whose
+// neighbourhood masks of longer rows (TRW_PREP_MARKS: about 3.5x the prepare time, then every later walk is 30 %
+// faster); rw.prepare() asks for them up front, and for TRW_PREP_MARKS_FULL with marks="full".  Least-recently-used graphs beyond `capacity` are dropped; entries whose
 // tensors died are dropped at the next call.  TRW_CACHE=0 (or set_cache(False)) turns the cache off: every
 // call then prepares into its own workspace, as trw_walk_csr_hip does.  Calls on a stream that is being captured
 // into a HIP graph never use the cache (a replay must not depend on memory the cache may drop).
@@ -186,7 +186,8 @@ bool entry_matches(const PreparedGraph &e, const torch::Tensor &rp, const torch:
 void build_blob(PreparedGraph &entry, const torch::Tensor &rp, const torch::Tensor &ci, int32_t what, void *stream)
 {
     const int64_t n_nodes = rp.numel() - 1, nnz = ci.numel();
-    const int32_t ladder[4] = {what, (int32_t)(what & ~TRW_PREP_MARKS), (int32_t)(what & TRW_PREP_UNIFORM), 0};
+    const int32_t ladder[4] = {what, (int32_t)(what & ~(TRW_PREP_MARKS | TRW_PREP_MARKS_FULL)),
+                               (int32_t)(what & TRW_PREP_UNIFORM), 0};
     for (int k = 0; k < 4; ++k) {
         const int32_t w = ladder[k];
         if (k > 0 && w == ladder[k - 1]) continue;
@@ -253,6 +254,7 @@ PreparedUse prepared_for(const torch::Tensor &rp, const torch::Tensor &ci, int32
     if (hit->what >= 0) want |= hit->what;
     // the second node2vec walk over a graph is the sign that it is walked repeatedly: worth the full masks
     if (biased_walk && (want & TRW_PREP_BIASED) && hit->biased_walks >= 1) want |= TRW_PREP_MARKS;
+    if (want & TRW_PREP_MARKS_FULL) want |= TRW_PREP_MARKS;
     if (want & TRW_PREP_MARKS) want |= TRW_PREP_BIASED;
     if (hit->what < 0 || (want & ~hit->what) != 0) build_blob(*hit, rp, ci, want, stream);
     if (biased_walk) ++hit->biased_walks;
@@ -363,7 +365,8 @@ int64_t prepare(const torch::Tensor &row_ptr, const torch::Tensor &col_idx, int6
     TORCH_CHECK(row_ptr.numel() >= 1, "row_ptr must have num_nodes + 1 entries");
     TORCH_CHECK(row_ptr.is_contiguous() && col_idx.is_contiguous(),
                 "prepare() keys on the tensors' storage: row_ptr and col_idx must be contiguous");
-    TORCH_CHECK(what >= 0 && what <= (TRW_PREP_UNIFORM | TRW_PREP_BIASED | TRW_PREP_MARKS), "unknown prepare flags ", what);
+    TORCH_CHECK(what >= 0 && what <= (TRW_PREP_UNIFORM | TRW_PREP_BIASED | TRW_PREP_MARKS | TRW_PREP_MARKS_FULL),
+                "unknown prepare flags ", what);
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(row_ptr.device());
     const auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(row_ptr.device().index());
     TORCH_CHECK(cache_enabled(), "the prepared-graph cache is switched off (TRW_CACHE=0 / set_cache(False))");
@@ -693,6 +696,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.attr("PREP_UNIFORM") = (int64_t)TRW_PREP_UNIFORM;
     m.attr("PREP_BIASED") = (int64_t)TRW_PREP_BIASED;
     m.attr("PREP_MARKS") = (int64_t)TRW_PREP_MARKS;
+    m.attr("PREP_MARKS_FULL") = (int64_t)TRW_PREP_MARKS_FULL;
     m.def("set_rng_mode", [](int64_t mode) {
         TORCH_CHECK(mode == TRW_RNG_AUTO || mode == TRW_RNG_GLIBC || mode == TRW_RNG_WALKER, "unknown rng mode ", mode);
         g_rng_mode.store((int)mode);

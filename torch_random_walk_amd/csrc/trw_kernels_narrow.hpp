@@ -1487,9 +1487,18 @@ biased_mask_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
 #ifndef TRW_POOL_PAIRS
 #define TRW_POOL_PAIRS 2
 #endif
-constexpr int kPoolSlots = TRW_POOL_SLOTS;  // walkers resident per wave (a power of two, >= 128 keeps every phase fed)
+constexpr int kPoolSlots = TRW_POOL_SLOTS;  // walkers resident per wave (<= 128; about 2 per lane keeps every phase fed)
+constexpr int kQueueCap = 128;              // ring capacity of the slot queues (a power of two >= kPoolSlots)
 constexpr int kPoolPairs = TRW_POOL_PAIRS;  // Philox blocks (pairs of trials) per visit of the burst
 constexpr int kPoolWaves = kBlock / 64;
+// A phase runs when its queue holds at least this many slots (or when nothing else can make progress)
+#ifndef TRW_POOL_ISSUE_MIN
+#define TRW_POOL_ISSUE_MIN 48
+#endif
+#ifndef TRW_POOL_TRIAL_MIN
+#define TRW_POOL_TRIAL_MIN 48
+#endif
+constexpr uint32_t kPoolIssueMin = TRW_POOL_ISSUE_MIN, kPoolTrialMin = TRW_POOL_TRIAL_MIN;
 enum : uint32_t { PK_ROW = 0, PK_ENTRY = 1, PK_TEST = 2, PK_MEMBER = 3, PK_POS = 4 };  // what a slot's gather is for
 enum : int {
     PF_T = 0, PF_PREV, PF_START, PF_DEG, PF_Z, PF_POSLO, PF_POSCNT, PF_M0, PF_M1, PF_M2, PF_M3,
@@ -1502,15 +1511,15 @@ enum : int {
 };
 constexpr uint32_t kPfExact = 1u, kPfOdd = 2u;
 
-struct PoolQueue {  // a ring of slot numbers in LDS; head/count are wave-uniform
-    uint32_t *q;
+struct PoolQueue {  // a ring of slot numbers (bytes) in LDS; head/count are wave-uniform
+    uint8_t *q;
     uint32_t head, count;
     // pops up to 64 entries: lane i < n gets one
     __device__ __forceinline__ uint32_t pop(int lane, uint32_t &n, uint32_t &slot)
     {
         n = count < 64u ? count : 64u;
-        slot = q[(head + (uint32_t)lane) & (uint32_t)(kPoolSlots - 1)];
-        head = (head + n) & (uint32_t)(kPoolSlots - 1);
+        slot = q[(head + (uint32_t)lane) & (uint32_t)(kQueueCap - 1)];
+        head = (head + n) & (uint32_t)(kQueueCap - 1);
         count -= n;
         return n;
     }
@@ -1520,7 +1529,7 @@ struct PoolQueue {  // a ring of slot numbers in LDS; head/count are wave-unifor
         const unsigned long long b = __ballot(yes);
         if (b == 0) return;
         const uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-        if (yes) q[(head + count + off) & (uint32_t)(kPoolSlots - 1)] = slot;
+        if (yes) q[(head + count + off) & (uint32_t)(kQueueCap - 1)] = (uint8_t)slot;
         count += (uint32_t)__popcll(b);
     }
 };
@@ -1539,10 +1548,11 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                    int64_t n_nodes, int64_t n_walkers, int64_t walker_base, int32_t L, uint32_t seed, BiasedParams bp,
                    int64_t *__restrict__ out, int64_t *__restrict__ status)
 {
-    static_assert((kPoolSlots & (kPoolSlots - 1)) == 0 && kPoolSlots >= 64, "pool size must be a power of two >= 64");
+    static_assert(kPoolSlots >= 64 && kPoolSlots <= kQueueCap && (kQueueCap & (kQueueCap - 1)) == 0 && kQueueCap <= 256,
+                  "pool size must be 64..128 slots (slot numbers travel as bytes)");
     if (status[kStDescents] != status[kStBoundary]) return;  // unsorted rows: biased_hash_kernel's job
     __shared__ uint32_t pool_mem[kPoolWaves][PF_COUNT][kPoolSlots];
-    __shared__ uint32_t queue_mem[kPoolWaves][3][kPoolSlots];
+    __shared__ uint8_t queue_mem[kPoolWaves][3][kQueueCap];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         status[2] = TRW_RNG_WALKER;
         status[3] = 5;
@@ -1551,7 +1561,7 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t(*P)[kPoolSlots] = pool_mem[wv];
     PoolQueue trial_q = {queue_mem[wv][0], 0u, 0u}, issue_q = {queue_mem[wv][1], 0u, 0u}, free_q = {queue_mem[wv][2], 0u, 0u};
-    for (int i = lane; i < kPoolSlots; i += 64) free_q.q[i] = (uint32_t)i;
+    for (int i = lane; i < kPoolSlots; i += 64) free_q.q[i] = (uint8_t)i;
     free_q.count = kPoolSlots;
     pool_fence();
     const bool band_takes_near = bp.t1 > bp.t2;
@@ -1698,7 +1708,7 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
             const uint32_t keep_count = free_q.count;
             free_q.pop(lane, n, slot);
             if (take < n) {  // hand the unused ones back (they are the last ones popped)
-                free_q.head = (free_q.head + (uint32_t)kPoolSlots - (n - take)) & (uint32_t)(kPoolSlots - 1);
+                free_q.head = (free_q.head + (uint32_t)kQueueCap - (n - take)) & (uint32_t)(kQueueCap - 1);
                 free_q.count = keep_count - take;
             }
             bool to_issue = false, back = false;
@@ -1728,7 +1738,7 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
         if (!more_walkers && free_q.count == (uint32_t)kPoolSlots) break;  // every walker of this wave is done
 
         // ================= issue: gathers for the slots that want one =================
-        if (issue_q.count >= 48u || (issue_q.count > 0u && trial_q.count < 64u)) {
+        if (issue_q.count >= kPoolIssueMin || (issue_q.count > 0u && trial_q.count < kPoolTrialMin)) {
             uint32_t n, slot;
             issue_q.pop(lane, n, slot);
             if ((uint32_t)lane < n) {
@@ -1752,7 +1762,7 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
         }
 
         // ================= burst: trials for a wave of slots that are between gathers =================
-        if (trial_q.count >= 48u || (trial_q.count > 0u && issue_q.count < 48u)) {
+        if (trial_q.count >= kPoolTrialMin || (trial_q.count > 0u && issue_q.count < kPoolIssueMin)) {
             uint32_t n, slot;
             trial_q.pop(lane, n, slot);
             bool busy = (uint32_t)lane < n;
