@@ -438,40 +438,49 @@ def main():
     k_ms = sum(kernel_ms) / max(1, len(kernel_ms))
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
 
-    traffic = None
+    # roofline.traffic / request_rate come from a separate PMC pass of this same command (scripts/profile_gpu.sh ->
+    # profiles/pmc_traffic.json): quoted only while that pass was collected from the kernel sources that are running
+    # now (sha256 over csrc/), null otherwise -- a stale figure is worse than none.
+    traffic, request_rate, traffic_source = None, None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path):
-        try:
-            with open(pmc_path) as f:
-                traffic = json.load(f).get(args.workload, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-
-    # The walk kernels are divergent gathers: what bounds them is the rate of L2-miss requests the memory
-    # system sustains (scripts/machine_probe.hip measures it on the box: the same for 4-, 8- and 16-byte
-    # gathers, falling slowly with the footprint), not bytes.  Quote the kernel's miss rate (PMC pass of
-    # the same command, profiles/pmc_traffic.json) against that measured ceiling next to the HBM roofline.
-    request_rate = None
     try:
+        import hashlib
+        h = hashlib.sha256()
+        cdir = os.path.join(ROOT, "torch_random_walk_amd", "csrc")
+        for name in sorted(os.listdir(cdir)):
+            if name.endswith((".hip", ".hpp", ".cpp")) and name != "torch_rw_native.cpp":
+                with open(os.path.join(cdir, name), "rb") as f:
+                    h.update(f.read())
+        now_sha = h.hexdigest()
         with open(pmc_path) as f:
-            misses = json.load(f).get(args.workload, {}).get("TCC_MISS")
-        ceiling, copy_gbs = None, None
-        with open(os.path.join(ROOT, "profiles", "r01_machine_probe.txt")) as f:
-            for ln in f:
-                tok = ln.split()
-                if ln.startswith("stream_copy"):
-                    copy_gbs = float(ln.split("per copy,")[1].split()[0])
-                elif len(tok) >= 5 and tok[1] == "MB" and int(tok[0]) >= 4096:
-                    best = max(float(x) for x in tok[2:])
-                    ceiling = best if ceiling is None else min(ceiling, best)  # the largest footprints
-        if misses and ceiling and k_ms > 0:
-            request_rate = dict(l2_misses_per_launch=misses, achieved_per_s=misses / (k_ms * 1e-3),
-                                ceiling_per_s=ceiling, frac=misses / (k_ms * 1e-3) / ceiling,
-                                measured_stream_copy_GBps=copy_gbs,
-                                source="profiles/pmc_traffic.json (TCC_MISS) / profiles/r01_machine_probe.txt "
-                                       "(dependent random gathers over >= 4 GB, 8 waves per SIMD)")
-    except Exception:
-        request_rate = None
+            ent = json.load(f).get(args.workload, {})
+        fresh = bool(ent) and ent.get("sources_sha256") == now_sha and ent.get("kernel", "") in kernel_name
+        traffic_source = dict(file="profiles/pmc_traffic.json", tag=ent.get("tag"), kernel=ent.get("kernel"),
+                              sources_sha256=ent.get("sources_sha256"), current_sources_sha256=now_sha,
+                              matches_current_sources=fresh)
+        if fresh:
+            traffic = ent.get("hbm_bytes_per_launch")
+            misses = ent.get("TCC_MISS")
+            # The gather kernels are bound by the rate of L2-miss requests the memory system sustains
+            # (scripts/machine_probe.hip measures it on the box: the same for 4-, 8- and 16-byte gathers), not by
+            # bytes: quote the kernel's miss rate against that measured ceiling next to the HBM roofline.
+            ceiling, copy_gbs = None, None
+            with open(os.path.join(ROOT, "profiles", "r01_machine_probe.txt")) as f:
+                for ln in f:
+                    tok = ln.split()
+                    if ln.startswith("stream_copy"):
+                        copy_gbs = float(ln.split("per copy,")[1].split()[0])
+                    elif len(tok) >= 5 and tok[1] == "MB" and int(tok[0]) >= 4096:
+                        best = max(float(x) for x in tok[2:])
+                        ceiling = best if ceiling is None else min(ceiling, best)  # the largest footprints
+            if misses and ceiling and k_ms > 0:
+                request_rate = dict(l2_misses_per_launch=misses, achieved_per_s=misses / (k_ms * 1e-3),
+                                    ceiling_per_s=ceiling, frac=misses / (k_ms * 1e-3) / ceiling,
+                                    measured_stream_copy_GBps=copy_gbs,
+                                    source="profiles/pmc_traffic.json (TCC_MISS) / profiles/r01_machine_probe.txt "
+                                           "(dependent random gathers over >= 4 GB, 8 waves per SIMD)")
+    except Exception as e:   # noqa: BLE001 -- the PMC figures are optional
+        traffic_source = dict(file="profiles/pmc_traffic.json", error=repr(e))
 
     # ---- CPU baseline: the reference's algorithm on a bounded sample (rank 0, N = 1 only) ------
     cpu = None
@@ -612,6 +621,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "units_per_launch": steps_per_launch,
                 "kernel_ms": k_ms,

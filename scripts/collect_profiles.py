@@ -27,6 +27,20 @@ DOMINANT = {"rmat10m_biased": ("biased_pool_kernel", "biased_mask_kernel", "bias
             "er100k_uniform": ("uniform_glibc_rows_kernel", "uniform_glibc_kernel", "uniform_glibc_ext_kernel"),
             "kg5m_triples": ("triples_walker_kernel",), "elist_rmat1m_biased": ("elist_walk_kernel",),
             "elist_rmat1m_uniform": ("elist_walk_kernel",), "windows_1m": ("glibc_fill_mod_kernel",)}
+
+
+def sources_sha():
+    """sha256 over the kernel sources: bench.py quotes a PMC figure only while it was collected from these."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "torch_random_walk_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp", ".cpp")) and name != "torch_rw_native.cpp":
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
 traffic_path = os.path.join(DST, "pmc_traffic.json")
 base_path = traffic_path if os.path.exists(traffic_path) else os.path.join(ROOT, "profiles", "pmc_traffic.json")
 traffic = json.load(open(base_path)) if os.path.exists(base_path) else {}
@@ -59,6 +73,7 @@ for wl in argv[2:]:
         # the measured 6.3 TB/s), so no doubling is applied here ("Traffic").
         traffic[wl] = {
             "tag": tag,
+            "sources_sha256": sources_sha(),
             "kernel": names.get("FETCH_SIZE", DOMINANT[wl][0]),
             "FETCH_SIZE_KiB": vals["FETCH_SIZE"], "WRITE_SIZE_KiB": vals["WRITE_SIZE"],
             "hbm_bytes_per_launch": (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,

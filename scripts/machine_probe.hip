@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #define CHECK(x)                                                                         \
@@ -62,9 +63,12 @@ __global__ void __launch_bounds__(256) gather_kernel(const uint32_t *__restrict_
             } else if (kBytes == 8) {
                 const u32x2 v = *reinterpret_cast<const u32x2 *>(p);
                 got[k] = v.x ^ v.y;
-            } else {
+            } else if (kBytes == 16) {
                 const u32x4 v = *reinterpret_cast<const u32x4 *>(p);
                 got[k] = v.x ^ v.y ^ v.z ^ v.w;
+            } else {  // 32 bytes: two 16-byte loads of one aligned 32-byte record (the biased walk's fat entries)
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(p), w = *reinterpret_cast<const u32x4 *>(p + 4);
+                got[k] = v.x ^ v.y ^ v.z ^ v.w ^ w.x ^ w.y ^ w.z ^ w.w;
             }
         }
 #pragma unroll
@@ -102,6 +106,28 @@ int main(int argc, char **argv)
     CHECK(hipGetDeviceProperties(&prop, 0));
     printf("# device: %s, %d CUs\n", prop.name, prop.multiProcessorCount);
 
+    // ---- (0) "one <footprint MB> <bytes>": a single launch with a known number of gathers, to be run under
+    //      rocprofv3 --pmc FETCH_SIZE / TCC_MISS_sum (scripts/probe_fetch_granule.sh): FETCH_SIZE*1024/gathers is
+    //      what ONE L2 miss of a random gather moves from HBM on this part (64 or 128 bytes?)
+    if (argc > 3 && std::string(argv[1]) == "one") {
+        const size_t fp = (size_t)strtoull(argv[2], nullptr, 10) << 20;
+        const int bytes = atoi(argv[3]);
+        uint32_t *buf, *sink;
+        CHECK(hipMalloc(&buf, fp));
+        CHECK(hipMalloc(&sink, 256));
+        fill_kernel<<<4096, 256>>>(buf, fp / 4);
+        CHECK(hipDeviceSynchronize());
+        const int blocks = prop.multiProcessorCount * 8, iters = 400;
+        double rate = 0;
+        if (bytes == 4) rate = run_gather<4, 1>(buf, fp, blocks, iters, sink);
+        else if (bytes == 16) rate = run_gather<16, 1>(buf, fp, blocks, iters, sink);
+        else rate = run_gather<32, 1>(buf, fp, blocks, iters, sink);
+        // run_gather launches a warm-up of iters/4+1 and the timed launch of iters: the LARGER dispatch is the timed one
+        printf("one: footprint %zu MB, %d-byte gathers, timed launch = %.0f gathers, %.3e gathers/s\n", fp >> 20, bytes,
+               (double)blocks * 256.0 * iters, rate);
+        return 0;
+    }
+
     // ---- (1) streaming copy ----
     {
         const size_t bytes = (size_t)4 << 30;
@@ -137,7 +163,8 @@ int main(int argc, char **argv)
     const int blocks = prop.multiProcessorCount * 8;  // 8 waves per SIMD, as the walk kernels run
     printf("# gathers/s by footprint; lanes=%d (8 waves/SIMD); bytes per gather x chains in flight per lane\n",
            blocks * 256);
-    printf("%10s %12s %12s %12s %12s %12s %12s\n", "footprint", "4Bx1", "8Bx1", "16Bx1", "16Bx2", "16Bx4", "4Bx4");
+    printf("%10s %12s %12s %12s %12s %12s %12s %12s\n", "footprint", "4Bx1", "8Bx1", "16Bx1", "16Bx2", "16Bx4", "4Bx4",
+           "32Bx1");
     for (size_t mb = 4; mb <= max_mb; mb *= 4) {
         const size_t fp = mb << 20;
         const int iters = 400;
@@ -147,7 +174,8 @@ int main(int argc, char **argv)
         const double r162 = run_gather<16, 2>(buf, fp, blocks, iters / 2, sink);
         const double r164 = run_gather<16, 4>(buf, fp, blocks, iters / 4, sink);
         const double r44 = run_gather<4, 4>(buf, fp, blocks, iters / 4, sink);
-        printf("%8zu MB %12.3e %12.3e %12.3e %12.3e %12.3e %12.3e\n", mb, r41, r81, r161, r162, r164, r44);
+        const double r321 = run_gather<32, 1>(buf, fp, blocks, iters, sink);
+        printf("%8zu MB %12.3e %12.3e %12.3e %12.3e %12.3e %12.3e %12.3e\n", mb, r41, r81, r161, r162, r164, r44, r321);
         fflush(stdout);
     }
     CHECK(hipFree(buf));
