@@ -74,7 +74,7 @@ def test_workspace_bytes():
     shadow = 4 * (n + 1) + 4 * nnz
     stage = 4 * N * (L + 1)
     assert f(n, nnz, 0, 5, 1.0, 1.0, 0) >= 256
-    assert f(n, nnz, N, L, 0.5, 2.0, 1) == head                       # serial glibc replay: int64 kernels, no shadow
+    assert f(1000, 10**8, 5, 6, 0.5, 2.0, 1) == head                  # short serial glibc replay: int64 kernels, no shadow
     assert f(n, nnz, N, L, 1.0, 1.0, 2) == head                       # uniform on the walker stream: int64 kernels
     table = 16 * 1024                                                 # edge table: >= 3 slots per edge, >= 1024 slots
     fat = 32 * nnz                                                    # 32-byte entries of the biased walk
@@ -92,7 +92,8 @@ def test_workspace_bytes():
     assert w(N, L, 0.5, 2.0, 2) == 256 and 256 + N * 124 <= w(N, L, 1.0, 1.0, 0) < 256 + N * 124 + 1024
     plan = lib.trw_prepare_plan
     assert plan(n, nnz, N, L, 0.5, 2.0, 2) == 2 and plan(1000, 10**6, 100, L, 0.5, 2.0, 2) == 0
-    assert plan(n, nnz, N, L, 0.5, 2.0, 1) == -1 and plan(n, nnz, N, L, 1.0, 1.0, 2) == -2
+    assert plan(1000, 10**8, 5, 6, 0.5, 2.0, 1) == -1 and plan(n, nnz, N, L, 1.0, 1.0, 2) == -2
+    assert plan(n, nnz, N, L, 0.5, 2.0, 1) == 2          # a serial replay of this many steps rides the prepared graph
     # a graph the size of BASELINE configs[3] keeps the table path: 2^32 slots (64-bit slot arithmetic)
     big = g(111_000_000, 1_711_000_000, 2)
     assert 16 * 2**32 + 32 * 1_711_000_000 < big < 16 * 2**32 + 32 * 1_711_000_000 + 9 * 10**9

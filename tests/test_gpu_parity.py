@@ -163,6 +163,27 @@ def test_biased_glibc_serial_replay_equals_reference_semantics(rw, p, q):
     assert (got == ref).all()
 
 
+@pytest.mark.parametrize("env", [{}, {"TRW_WAVE_REPLAY": "0"}, {"TRW_HASH": "0"}, {"TRW_COMMON_MAX": "0"}])
+def test_biased_glibc_serial_replay_hubs_filters_and_unsorted_rows(rw, env, monkeypatch):
+    """The serial chain replayed by a whole wave (64 speculative trials per round over the prepared entries) and by
+    one lane over the int64 arrays: hub rows (filter masks: candidates checked against the table), long rows,
+    multi-edges, unsorted rows (one-lane kernel) -- the reference's single stream either way."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cases = [hub_graph(700, 5), random_graph(300, 150, 3), random_graph(300, 5, 4, sort_rows=False)]
+    rp2 = np.array([0, 4, 6, 8], dtype=np.int64)
+    ci2 = np.array([1, 1, 1, 2, 0, 2, 0, 1], dtype=np.int64)
+    cases.append((rp2, ci2))
+    for rp, ci in cases:
+        n = len(rp) - 1
+        tg = np.random.default_rng(6).integers(0, n, 120)
+        for p, q in ((0.25, 4.0), (4.0, 0.25), (0.7, 0.5)):
+            ref = O.walk(rp, ci, tg, p, q, 40, 10, rng_mode=O.RNG_GLIBC_SEQ)
+            for _ in range(2):   # second call: prepared graph from the cache, with the neighbourhood masks
+                got = _hip(rw, rp, ci, tg, p, q, 40, 10, rng_mode=rw.RNG_GLIBC)
+                assert (got == ref).all()
+
+
 def test_auto_mode_rule(rw):
     """AUTO: biased walks replay the reference's stream up to its parallel_for grain
     (32768/(L+1) walkers, rw_cpu.cpp:137), and use the per-walker stream beyond."""

@@ -324,7 +324,10 @@ torch::Tensor walk_ex(const torch::Tensor &row_ptr, const torch::Tensor &col_idx
     void *const hs = (void *)stream.stream();
     // what a call of this shape is worth preparing; < 0: it runs the int64 kernels and wants no shadow at all
     const int32_t needed = trw_prepare_plan(n_nodes, nnz, n_walkers, (int32_t)walk_length, p, q, (int32_t)rng_mode);
-    const bool biased_parallel = !(p == 1.0 && q == 1.0) && needed != TRW_PREP_ORDER_ONLY;
+    // (a serial replay rides a prepared graph too, but it is no sign that the graph is worth the full masks)
+    const bool serial_replay = rng_mode == TRW_RNG_GLIBC ||
+                               (rng_mode == TRW_RNG_AUTO && walker_base == 0 && n_walkers <= 32768 / (walk_length + 1));
+    const bool biased_parallel = !(p == 1.0 && q == 1.0) && !serial_replay;
     PreparedUse prepared;
     // (a strided input was copied by .contiguous() above: a temporary is not worth a cache entry)
     if (n_walkers > 0 && needed >= 0 && rp.is_same(row_ptr) && ci.is_same(col_idx))

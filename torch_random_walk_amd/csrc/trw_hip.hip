@@ -194,8 +194,15 @@ int32_t plan_what(int64_t n_nodes, int64_t nnz, int64_t n_walkers, int32_t L, bo
     // the kernels that index the caller's int64 arrays directly want no shadow: the uniform walk on the per-walker
     // stream nothing at all, the biased ones (serial replay, graphs beyond 2^31/2^32) the row order
     if (uniform && rng_mode == TRW_RNG_WALKER) return TRW_PREP_NOTHING;
-    if (!uniform && rng_mode == TRW_RNG_GLIBC) return TRW_PREP_ORDER_ONLY;
     if (!graph_fits_narrow(n_nodes, nnz)) return uniform ? TRW_PREP_NOTHING : TRW_PREP_ORDER_ONLY;
+    if (!uniform && rng_mode == TRW_RNG_GLIBC) {
+        // The serial replay: one lane over the int64 arrays costs about 10 us per step on a large graph (dependent
+        // gathers and a bisection per trial); the wave-cooperative replay over a prepared graph about 1.5 us, and
+        // the prepare pass about a third of a nanosecond per entry -- worth it from nnz/16384 steps.
+        const long forced = env_long("TRW_HASH", 0, 1, -1);
+        const bool worth = (__int128)n_walkers * L * 16384 >= (__int128)nnz;
+        return (forced == 1 || (forced == -1 && worth)) ? TRW_PREP_BIASED : TRW_PREP_ORDER_ONLY;
+    }
     if (uniform) {
         const long forced = env_long("TRW_EXT", 0, 1, -1);
         const bool big = (size_t)(n_nodes + nnz) * 4 > ((size_t)32 << 20);  // the XCDs' aggregate L2
@@ -634,8 +641,16 @@ static int walk_prepared(const void *prepared, size_t prepared_bytes, int32_t wh
     } else if (mode == TRW_RNG_GLIBC) {
         SeedWindow sw;
         trw::seed_window(seed, sw.w);
+        // sorted graph with a table and fat entries: the whole wave replays the chain (64 speculative trials at a
+        // time); anything else, one lane over the int64 arrays.  Each kernel returns at once when the graph is not
+        // its kind (the row order is known on the device only).
+        const bool wave_replay = pl.narrow && pl.biased && env_long("TRW_WAVE_REPLAY", 0, 1, 1) == 1;
+        if (wave_replay)
+            biased_glibc_wave_kernel<<<1, 64, 0, stream>>>(row32, (const u32x4_a16 *)(pw + pl.off_ext32), table,
+                                                          pl.hash_mask, targets, n_nodes, n_walkers, walk_length, sw,
+                                                          bp, out, status);
         biased_glibc_seq_kernel<<<1, 64, 0, stream>>>(row_ptr, col_idx, targets, n_nodes, nnz, n_walkers,
-                                                     walk_length, sw, th, out, status);
+                                                     walk_length, sw, th, wave_replay ? 1 : 0, out, status);
     } else if (pl.narrow && pl.biased) {
         // persistent lanes: walkers are dealt out by a device counter (status[kStNextWalker])
         int64_t blocks = (n_walkers + kBlock - 1) / kBlock;

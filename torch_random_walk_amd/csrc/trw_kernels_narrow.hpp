@@ -21,8 +21,6 @@
 
 namespace {
 
-constexpr int kStDescents = 8;    // status slot: adjacent pairs col[e] > col[e+1]
-constexpr int kStBoundary = 9;    // status slot: such pairs that straddle a row boundary
 
 // ---------------------------------------------------------------------------
 // Shadow CSR
@@ -1862,6 +1860,155 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
             atomicAdd((unsigned long long *)&status[7], (unsigned long long)d);
         }
     }
+}
+
+// ===========================================================================
+// Biased walk, reference-exact: the serial glibc chain replayed by a whole wave
+// ===========================================================================
+// TRW_RNG_GLIBC on a biased walk is ONE stream consumed walker after walker, trial after trial (rw_cpu.cpp:118,
+// :166-195): which draws a trial sees depends on how many trials everything before it took, so walkers cannot
+// run side by side.  What CAN run side by side is the work inside one step: the stream's VALUES do not depend on
+// the walk, so the wave evaluates the next 64 trials of the current step at once -- lane k looks at draws
+// pos+2k, pos+2k+1 and decides its trial from the prepared entry's rpos / mask exactly as biased_mask_kernel
+// does -- and the first lane whose trial accepts is the step (everything after it was speculation).  Trials
+// whose mask bit is only a filter are resolved for all such lanes in parallel (candidate entry + table probe)
+// before the first definite accept is taken.  One dependent gather per step is left: the accepted entry.
+// The generator itself is three lanes wide: r[k] = r[k-3] + r[k-31] gives r[k], r[k+1], r[k+2] from values
+// that exist already; the raw words go into an LDS ring indexed by stream position.
+// Sorted rows + prepared table and fat entries only; anything else runs biased_glibc_seq_kernel (one lane).
+constexpr int kGlRing = 4096;  // stream positions held in LDS (a power of two)
+
+__global__ void __launch_bounds__(64)
+biased_glibc_wave_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restrict__ ext,
+                         const uint32_t *__restrict__ table, uint64_t mask, const int64_t *__restrict__ targets,
+                         int64_t n_nodes, int64_t n_walkers, int32_t L, SeedWindow sw, BiasedParams bp,
+                         int64_t *__restrict__ out, int64_t *__restrict__ status)
+{
+    if (!rows_sorted(status)) return;  // biased_glibc_seq_kernel's job
+    __shared__ uint32_t R[kGlRing];    // R[i & (kGlRing-1)] = generator word of rand() call number i
+    const int lane = threadIdx.x;
+    constexpr uint32_t M = kGlRing - 1;
+    if (lane == 0) {
+        status[2] = TRW_RNG_GLIBC;
+        status[3] = 6;
+    }
+    if (lane < kGlDeg) R[(uint32_t)(kGlRing - kGlDeg + lane) & M] = sw.w[lane];  // calls -31 .. -1
+    pool_fence();
+    uint64_t pos = 0, gen = 0;  // next draw to consume / to generate (wave-uniform)
+    auto need = [&](uint64_t upto) {
+        while (gen < upto) {
+            if (lane < kGlSep) {
+                const uint32_t i = (uint32_t)gen + (uint32_t)lane;
+                R[i & M] = R[(i - kGlDeg) & M] + R[(i - kGlSep) & M];
+            }
+            gen += kGlSep;
+        }
+        pool_fence();
+    };
+    auto draw = [&](uint64_t at) { return R[(uint32_t)at & M] >> 1; };
+    const bool band_takes_near = bp.t1 > bp.t2;
+    const uint32_t v_clear = band_takes_near ? 0u : 1u, v_set_exact = band_takes_near ? 1u : 0u;
+
+    uint32_t st = 0;
+    for (int64_t i = 0; i < n_walkers && !st; ++i) {
+        int64_t *row = out + i * (int64_t)(L + 1);
+        const int64_t tg = targets[i];
+        if (lane == 0) row[0] = tg;
+        if ((uint64_t)tg >= (uint64_t)n_nodes) {  // the chain's draw positions are undefined past a fault
+            for (int32_t c = 1 + lane; c <= L; c += 64) row[c] = tg;
+            st |= TRW_ST_NODE_RANGE;
+            break;
+        }
+        uint32_t t = (uint32_t)tg, prev = t, p_start = 0, p_deg = 0, pos_lo = 0, pos_cnt = 0;
+        uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+        bool exact = false;
+        FastMod fm;
+        // every lane loads the SAME entry (one request) and steps the replicated state
+        auto step_onto = [&](uint32_t entry, int32_t s) {
+            const u32x4_a16 e0 = ext[2 * (size_t)entry], e1 = ext[2 * (size_t)entry + 1];
+            if (lane == 0) row[s] = (int64_t)e0.x;
+            t = prev;
+            prev = e0.x;
+            p_start = e0.y;
+            p_deg = e0.z & ~kMaskIsFilter;
+            exact = (e0.z & kMaskIsFilter) == 0u;
+            m0 = e1.x;
+            m1 = e1.y;
+            m2 = e1.z;
+            m3 = e1.w;
+            pos_lo = e0.w & 0x0FFFFFFFu;
+            pos_cnt = e0.w >> 28;
+            if (p_deg == 0) return;
+            fm.init(p_deg);
+            if (e0.w == kRposLookup) {  // where t sits in prev's row: ask the table
+                uint32_t lo = 0, cnt = 0;
+                const bool found = edge_table_find(table, mask, prev, t, lo, cnt);
+                pos_lo = found ? lo : 0u;
+                pos_cnt = found ? cnt : 0u;
+            }
+        };
+        // step 1: uniform neighbour of the start node, one draw (rw_cpu.cpp:159)
+        {
+            uint32_t start, deg;
+            load_row32(row32, t, start, deg);
+            if (deg == 0) {  // rw_cpu.cpp:20 divides by zero here
+                st |= TRW_ST_DEGREE0;
+                break;
+            }
+            need(pos + 1);
+            const uint32_t r0 = draw(pos);
+            pos += 1;
+            step_onto(start + r0 % deg, 1);
+        }
+        for (int32_t s = 2; s <= L && !st; ++s) {
+            if (p_deg == 0) {
+                st |= TRW_ST_DEGREE0;
+                break;
+            }
+            uint32_t rejected = 0, take = 0;
+            while (true) {  // 64 trials at a time
+                need(pos + 128);
+                const uint32_t rc = draw(pos + 2 * (uint64_t)lane), ru = draw(pos + 2 * (uint64_t)lane + 1);
+                const uint32_t idx = fm.mod(rc);
+                const uint32_t k = (idx >> 5) & 3u;
+                const uint32_t word = k == 0u ? m0 : (k == 1u ? m1 : (k == 2u ? m2 : m3));
+                const bool bit = (word >> (idx & 31u)) & 1u;
+                const uint32_t v_band = bit ? (exact ? v_set_exact : 2u) : v_clear;
+                const uint32_t v_other = ru < bp.lo ? 1u : (ru >= bp.hi ? 0u : v_band);
+                const uint32_t verdict = (idx - pos_lo < pos_cnt) ? (ru < bp.t0 ? 1u : 0u) : v_other;
+                unsigned long long accepts = __ballot(verdict == 1u), tests = __ballot(verdict == 2u);
+                while (true) {  // settle the filter-only trials that come before the first definite accept
+                    const int fa = accepts ? (int)__ffsll((long long)accepts) - 1 : 64;
+                    const unsigned long long before = fa >= 64 ? ~0ull : ((1ull << fa) - 1ull);
+                    const unsigned long long pend = tests & before;
+                    if (pend == 0) break;
+                    bool ok = false;
+                    if ((pend >> lane) & 1ull) {
+                        const uint32_t x = ext[2 * (size_t)(p_start + idx)].x;
+                        uint32_t lo, cnt;
+                        ok = edge_table_find(table, mask, t, x, lo, cnt) == band_takes_near;
+                    }
+                    accepts |= __ballot(ok);
+                    tests &= ~pend;
+                }
+                if (accepts) {
+                    const int f = (int)__ffsll((long long)accepts) - 1;
+                    take = p_start + (uint32_t)__shfl((int)idx, f);
+                    pos += 2 * (uint64_t)(f + 1);
+                    break;
+                }
+                pos += 128;
+                rejected += 64;
+                if (rejected >= kTrialCap) {
+                    st |= (uint32_t)kStTrialCap;
+                    take = p_start + (uint32_t)__shfl((int)idx, 63);
+                    break;
+                }
+            }
+            step_onto(take, s);
+        }
+    }
+    if (st && lane == 0) atomicOr((unsigned long long *)&status[0], (unsigned long long)st);
 }
 
 }  // namespace

@@ -17,6 +17,14 @@ using trw::kJumpRow;
 constexpr int kBlock = 256;          // 4 waves of 64
 constexpr int kStatusBytes = 256;    // status block at the head of the workspace
 constexpr uint32_t kTrialCap = 1u << 20;
+constexpr int kStDescents = 8;    // status slot: adjacent pairs col[e] > col[e+1]   (uint32 shadow pass)
+constexpr int kStBoundary = 9;    // status slot: such pairs that straddle a row boundary
+// Rows are all sorted <=> the int64 probe raised no flag (status[1]) and every descent the shadow pass counted sits
+// on a row boundary; whichever of the two passes did not run left its slots zero.
+__device__ __forceinline__ bool rows_sorted(const int64_t *status)
+{
+    return status[1] == 0 && status[kStDescents] == status[kStBoundary];
+}
 constexpr int64_t kStTrialCap = TRW_ST_TRIAL_CAP;
 
 // x^(d*256^k) mod (x^31 - x^28 - 1), see glibc_jump.hpp.  Uploaded once per device.
@@ -396,7 +404,7 @@ biased_walker_wide_kernel(const int64_t *__restrict__ row_ptr, const int64_t *__
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i == 0) status[2] = TRW_RNG_WALKER;
-    const bool sorted = (status[1] == 0);
+    const bool sorted = rows_sorted(status);
     uint32_t st = 0;
     uint32_t n_trials = 0, n_member = 0, n_probes = 0;
     uint64_t n_refscan = 0;
@@ -491,13 +499,14 @@ biased_walker_wide_kernel(const int64_t *__restrict__ row_ptr, const int64_t *__
 __global__ void __launch_bounds__(64)
 biased_glibc_seq_kernel(const int64_t *__restrict__ row_ptr, const int64_t *__restrict__ col_idx,
                         const int64_t *__restrict__ targets, int64_t n_nodes, int64_t nnz, int64_t n_walkers,
-                        int32_t L, SeedWindow sw, Thresholds th, int64_t *__restrict__ out,
+                        int32_t L, SeedWindow sw, Thresholds th, int32_t only_unsorted, int64_t *__restrict__ out,
                         int64_t *__restrict__ status)
 {
     __shared__ uint32_t w[kGlDeg];
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const bool sorted = rows_sorted(status);
+    if (only_unsorted && sorted) return;  // the wave-cooperative replay (biased_glibc_wave_kernel) has this graph
     status[2] = TRW_RNG_GLIBC;
-    const bool sorted = (status[1] == 0);
     GlibcSerial glibc;
     glibc.init(w, sw);
     auto next = [&]() -> uint32_t { return glibc.next(); };
