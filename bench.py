@@ -49,6 +49,10 @@ WORKLOADS = {
     # nodes (at 8 GPUs: the whole graph once), CSR replicated
     "papers100m_uniform": dict(graph="rmat", nodes=111_000_000, edges=1_600_000_000, p=1.0, q=1.0, walks_per_node=1,
                                shard_of=8),
+    # the node2vec walk at that scale: one GPU's shard of the start nodes, p=0.25 q=4 -- the edge
+    # table has 2^32 slots (64-bit slot arithmetic), prepared graph 131 GB beside the 14.6 GB CSR
+    "papers100m_biased": dict(graph="rmat", nodes=111_000_000, edges=1_600_000_000, p=0.25, q=4.0, walks_per_node=1,
+                              shard_of=8),
     # the same graph with ALL its start nodes on one GPU (72 GB of walks next to the 14 GB graph): what 288 GB allows
     "papers100m_full": dict(graph="rmat", nodes=111_000_000, edges=1_600_000_000, p=1.0, q=1.0, walks_per_node=1),
     # BASELINE configs[4]: knowledge-graph triples path (the reference's triples walk is uniform only,
