@@ -366,11 +366,39 @@ def main():
         n_win = B * (L + 1 - ws_ + 1)
         alg_bytes = n_win * (8 * ws_ + 8 * ws_ + 8 * (ws_ - 1))
         kernel_name = "glibc_fill_mod_kernel+windows_gather_kernel"
-    elif elist:
-        # uniform: per step 16 B index pair + 16 B edge row + 8 B stored; the biased walk's data-dependent reads
-        # are not counted yet (first, untuned kernel): a lower bound
+    elif elist and uniform:
+        # uniform: per step 16 B index pair + 16 B edge row + 8 B stored
         alg_bytes = B * (16 + 40 * L)
         kernel_name = "elist_walk_kernel"
+    elif elist:
+        # biased: the counting variant of the kernel through the C ABI (same walks), then bytes the algorithm as run
+        # must move: per walker 8 B target + 8 B index pair; 8 B per stored column; 64 B per entry gathered (every
+        # accepted offset + the candidates the masks could not decide); 16 B per table slot read
+        lib.trw_walk_edge_list_workspace_bytes.restype = ctypes.c_size_t
+        lib.trw_walk_edge_list_workspace_bytes.argtypes = [ctypes.c_int64] * 3 + [ctypes.c_int32, ctypes.c_int64, ctypes.c_int32]
+        nbytes = lib.trw_walk_edge_list_workspace_bytes(nnz, n, B, L, pad, mode)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        out = torch.empty((B, L + 1), dtype=torch.int64, device=dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        lib.trw_profile_enable(2)
+        rc = lib.trw_walk_edge_list_hip(el_edges.data_ptr(), nnz, el_index.data_ptr(), n, targets.data_ptr(), B, walker_base,
+                                        p, q, L, args.seed, pad, 1, mode, out.data_ptr(), ws.data_ptr(), nbytes, stream)
+        assert rc == 0, lib.trw_last_error()
+        c = (ctypes.c_uint64 * 4)()
+        assert lib.trw_walk_counters(ws.data_ptr(), stream, c) == 0
+        stw = (ctypes.c_int64 * 4)()
+        assert lib.trw_walk_status(ws.data_ptr(), stream, stw) == 0
+        lib.trw_profile_enable(0)
+        assert torch.equal(out, walks), "counting variant of the kernel produced different walks"
+        trials, fetches, tests, probes = (int(x) for x in c)
+        if int(stw[3]) == 5:
+            kernel_name = "elist_pool_kernel"
+            counters = dict(trials=trials, entry_gathers=fetches, candidates_tested=tests, table_slots=probes)
+            alg_bytes = B * 16 + 8 * B * (L + 1) + 64 * fetches + 16 * probes
+        else:   # the lane-per-walker kernel loads every candidate (4 B) and an 8-byte index pair per step
+            kernel_name = "elist_walk_kernel"
+            alg_bytes = B * (16 + 40 * L)
+        del out, ws
     elif kg:
         # per LIVE hop (not yet on the padding id / a dead end): 16 B index pair + 16 B (relation, tail);
         # per hop 16 B stored; per walker 8 B target + 8 B column 0.  Hops after a dead end read nothing.
@@ -396,9 +424,13 @@ def main():
                        3: "uniform_glibc_rows_kernel<true>"}[int(stw[3])]
         del out, ws
     else:
-        # the counting variant of the kernel over a graph prepared exactly as the timed calls' was
+        # the counting variant of the kernel over a graph prepared exactly as the timed calls' was (their cached
+        # prepared graph is dropped first: two of them need not fit side by side)
         cached = [i for i in rw.cache_info() if i[0] == n and i[1] == nnz]
         what = int(cached[0][2]) if cached else int(lib.trw_prepare_plan(n, nnz, B, L, p, q, mode))
+        chk = None
+        rw.clear_cache()
+        torch.cuda.empty_cache()
         stream = torch.cuda.current_stream().cuda_stream
         pbytes = lib.trw_prepare_csr_bytes(n, nnz, what)
         blob = torch.empty(pbytes, dtype=torch.uint8, device=dev)

@@ -22,10 +22,10 @@ if "--dst" in argv:
     DST = os.path.abspath(argv[k + 1])
     del argv[k:k + 2]
 tag = argv[1]
-DOMINANT = {"rmat10m_biased": ("biased_pool_kernel", "biased_mask_kernel", "biased_hash_kernel", "biased_walker_kernel"),
+DOMINANT = {"elist_rmat1m_biased": ("elist_pool_kernel", "elist_walk_kernel"), "rmat10m_biased": ("biased_pool_kernel", "biased_mask_kernel", "biased_hash_kernel", "biased_walker_kernel"),
             "rmat10m_uniform": ("uniform_glibc_rows_kernel", "uniform_glibc_ext_kernel", "uniform_glibc_kernel"),
             "er100k_uniform": ("uniform_glibc_rows_kernel", "uniform_glibc_kernel", "uniform_glibc_ext_kernel"),
-            "kg5m_triples": ("triples_walker_kernel",), "elist_rmat1m_biased": ("elist_walk_kernel",),
+            "kg5m_triples": ("triples_walker_kernel",), 
             "elist_rmat1m_uniform": ("elist_walk_kernel",), "windows_1m": ("glibc_fill_mod_kernel",)}
 
 

@@ -16,7 +16,7 @@ def short(name):
               "biased_hash_kernel", "biased_mask_kernel", "biased_pool_kernel", "edge_table_build_kernel", "csr_ext32_heavy_kernel", "csr_ext32_kernel",
               "csr_ext_kernel", "fill_kernel", "status_seed_kernel",
               "triples_windows_gather_kernel", "cbow_negative", "triples_glibc_seq_kernel", "elist_glibc_seq_kernel",
-              "triples_walker_kernel", "triples_shadow_kernel", "elist_walk_kernel", "elist_shadow_kernel",
+              "triples_walker_kernel", "triples_shadow_kernel", "elist_pool_kernel", "elist_ext_kernel", "elist_walk_kernel", "elist_shadow_kernel",
               "elist_table_build_kernel", "glibc_fill_mod_kernel", "windows_gather_kernel"):
         if k in name:
             tail = name[name.index(k):]

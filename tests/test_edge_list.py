@@ -123,7 +123,8 @@ def test_gpu_all_reference_goldens(egold):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{}, {"TRW_FORCE_WIDE": "1"}, {"TRW_HASH": "0"}, {"TRW_HASH": "1"}])
+@pytest.mark.parametrize("env", [{}, {"TRW_FORCE_WIDE": "1"}, {"TRW_HASH": "0"}, {"TRW_HASH": "1"}, {"TRW_ELPOOL": "0"},
+                                 {"TRW_ELPOOL": "1", "TRW_ELPOOL_BLOCKS": "1"}])
 @pytest.mark.parametrize("p,q", [(1.0, 1.0), (0.25, 4.0), (0.7, 0.2), (4.0, 0.25)])
 @pytest.mark.parametrize("restart", [True, False])
 def test_gpu_walker_stream_equals_oracle(env, p, q, restart, monkeypatch):
@@ -140,6 +141,35 @@ def test_gpu_walker_stream_equals_oracle(env, p, q, restart, monkeypatch):
                                rng_mode=O.RNG_WALKER, walker_base=77)
         got = rw.walk_edge_list_ex(*d, p, q, L, 5, pad, restart=restart, walker_base=77, rng_mode=rw.RNG_WALKER)
         assert (got.cpu().numpy() == ref).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pool", ["0", "1"])
+def test_gpu_long_ranges_pad_tails_and_single_edges(pool, monkeypatch):
+    """The prepared entries' corner cases: ranges beyond 128 edges (filter masks: candidates are looked at), tails
+    that ARE the padding id, heads with exactly one edge (no candidate draw), multi-edges, self loops -- with and
+    without restart, bit for bit the oracle's walks."""
+    from torch_rw import rw, utils
+    monkeypatch.setenv("TRW_ELPOOL", pool)
+    rng = np.random.default_rng(5)
+    n, pad = 400, 400
+    src = np.concatenate([rng.integers(0, 20, 6000),            # 20 hubs with ~300 edges each
+                          rng.integers(20, n, 1500),             # sparse rest: many single-edge heads and dead ends
+                          np.arange(30, 60), np.arange(60, 90)])
+    dst = np.concatenate([rng.integers(0, n, 6000), rng.integers(0, n, 1500),
+                          np.full(30, pad),                      # tails that are the padding id
+                          np.arange(60, 90)])                    # self loops
+    edges = torch.as_tensor(np.stack([src, dst], 1), dtype=torch.int64)
+    index, edges_sorted = utils.build_node_edge_index(edges, torch.arange(n))
+    tg = rng.integers(0, n, 4000)
+    tg[::31] = pad
+    d = [edges_sorted.to(DEV), index.to(DEV), torch.as_tensor(tg).to(DEV)]
+    for p, q in ((0.25, 4.0), (4.0, 0.25), (0.7, 0.2)):
+        for restart in (True, False):
+            ref = O.walk_edge_list(edges_sorted.numpy(), index.numpy(), tg, p, q, 30, 5, pad, restart=restart,
+                                   rng_mode=O.RNG_WALKER, walker_base=11)
+            got = rw.walk_edge_list_ex(*d, p, q, 30, 5, pad, restart=restart, walker_base=11, rng_mode=rw.RNG_WALKER)
+            assert (got.cpu().numpy() == ref).all(), (p, q, restart)
 
 
 @pytest.mark.gpu

@@ -148,6 +148,7 @@ struct PreparedGraph {
     void *ready = nullptr;        // event recorded after the prepare kernels
     void *built_on = nullptr;     // the stream they ran on
     int64_t biased_walks = 0;
+    int32_t refused = 0;          // TRW_PREP_* bits whose allocation failed once: not asked for again
     bool pinned = false;          // rw.prepare(): not upgraded/evicted behind the caller's back
     PreparedGraph(c10::weak_intrusive_ptr<c10::StorageImpl> a, c10::weak_intrusive_ptr<c10::StorageImpl> b)
         : rp_storage(std::move(a)), ci_storage(std::move(b)) {}
@@ -186,6 +187,10 @@ bool entry_matches(const PreparedGraph &e, const torch::Tensor &rp, const torch:
 void build_blob(PreparedGraph &entry, const torch::Tensor &rp, const torch::Tensor &ci, int32_t what, void *stream)
 {
     const int64_t n_nodes = rp.numel() - 1, nnz = ci.numel();
+    // The old blob goes first: an upgrade rebuilds everything, and on a graph the size of BASELINE configs[3] old and
+    // new blob (131 GB each) do not fit side by side.  (A call still walking over the old one holds its own reference.)
+    entry.blob = torch::Tensor();
+    entry.what = -100;
     const int32_t ladder[4] = {what, (int32_t)(what & ~(TRW_PREP_MARKS | TRW_PREP_MARKS_FULL)),
                                (int32_t)(what & TRW_PREP_UNIFORM), 0};
     for (int k = 0; k < 4; ++k) {
@@ -207,6 +212,7 @@ void build_blob(PreparedGraph &entry, const torch::Tensor &rp, const torch::Tens
         entry.built_on = stream;
         entry.blob = blob;
         entry.what = w;
+        entry.refused |= what & ~w;  // what did not fit is not tried again for this graph
         return;
     }
 }
@@ -254,8 +260,10 @@ PreparedUse prepared_for(const torch::Tensor &rp, const torch::Tensor &ci, int32
     if (hit->what >= 0) want |= hit->what;
     // the second node2vec walk over a graph is the sign that it is walked repeatedly: worth the full masks
     if (biased_walk && (want & TRW_PREP_BIASED) && hit->biased_walks >= 1) want |= TRW_PREP_MARKS;
+    want &= ~hit->refused;
     if (want & TRW_PREP_MARKS_FULL) want |= TRW_PREP_MARKS;
     if (want & TRW_PREP_MARKS) want |= TRW_PREP_BIASED;
+    want &= ~hit->refused;
     if (hit->what < 0 || (want & ~hit->what) != 0) build_blob(*hit, rp, ci, want, stream);
     if (biased_walk) ++hit->biased_walks;
     hit->pinned = hit->pinned || pin;

@@ -348,7 +348,8 @@ struct EdgeListPlan {
     bool narrow = false;
     bool hash = false;
     uint32_t hash_mask = 0;
-    size_t off_tail32 = 0, off_ix32 = 0, off_table = 0, total = 0;
+    bool ent = false;  // 64-byte per-edge entries: the walker-pool kernel
+    size_t off_tail32 = 0, off_ix32 = 0, off_table = 0, off_ent = 0, total = 0;
 };
 
 EdgeListPlan make_elist_plan(int64_t n_edges, int64_t n_nodes, int64_t n_walkers, int32_t L, int64_t padding_idx,
@@ -380,6 +381,14 @@ EdgeListPlan make_elist_plan(int64_t n_edges, int64_t n_nodes, int64_t n_walkers
                 pl.hash_mask = (uint32_t)(cap - 1);
                 pl.off_table = off;
                 off += (size_t)cap * 16;
+                // the entries cost a pass with about 10 table probes per edge: from nnz/4 steps on (TRW_ELPOOL=0/1 forces)
+                const long pforced = env_long("TRW_ELPOOL", 0, 1, -1);
+                const bool pworth = (__int128)n_walkers * L * 4 >= (__int128)n_edges && n_walkers < ((int64_t)1 << 32);
+                if (rng_mode != TRW_RNG_GLIBC && (pforced == 1 || (pforced == -1 && pworth))) {
+                    pl.ent = true;
+                    pl.off_ent = off;
+                    off += align_up((size_t)n_edges * 64 + 64, 256);
+                }
             }
         }
     }
@@ -906,6 +915,10 @@ int trw_walk_edge_list_hip(const int64_t *edges, int64_t n_edges, const int64_t 
             elist_table_build_kernel<<<stream_grid(n_edges), kBlock, 0, stream>>>(
                 edges, n_edges, n_nodes, (const uint32_t *)(ws + pl.off_tail32),
                 (const u32x2_a8 *)(ws + pl.off_ix32), el_table, pl.hash_mask);
+            if (pl.ent && mode == TRW_RNG_WALKER)
+                elist_ext_kernel<<<stream_grid(n_edges), kBlock, 0, stream>>>(
+                    edges, n_edges, n_nodes, (uint32_t)padding_idx, (const uint32_t *)(ws + pl.off_tail32),
+                    (const u32x2_a8 *)(ws + pl.off_ix32), el_table, pl.hash_mask, (u32x4_a16 *)(ws + pl.off_ent));
         }
     }
     prof_mark(1, stream);
@@ -919,7 +932,22 @@ int trw_walk_edge_list_hip(const int64_t *edges, int64_t n_edges, const int64_t 
             elist_walk_kernel<false, true><<<walker_grid, kBlock, 0, stream>>>(
                 narrow, targets, n_walkers, walker_base, walk_length, padding_idx, restart, (uint32_t)seed, bp,
                 el_table, pl.hash_mask, out, status);
-        else
+        else if (pl.ent) {
+            // walker pool over the prepared entries: 2 workgroups per CU (a wave's pool: 96 walkers x 26 words + windows)
+            int64_t pblocks = (n_walkers + (int64_t)kPoolWaves * kElSlots - 1) / ((int64_t)kPoolWaves * kElSlots);
+            const int64_t president = (int64_t)device_cu_count() * env_long("TRW_ELPOOL_BLOCKS", 1, 4, 2);
+            if (pblocks > president) pblocks = president;
+            if (g_prof.count)
+                elist_pool_kernel<true><<<(unsigned)pblocks, kBlock, 0, stream>>>(
+                    (const u32x2_a8 *)(ws + pl.off_ix32), (const u32x4_a16 *)(ws + pl.off_ent), el_table, pl.hash_mask,
+                    targets, n_nodes, n_walkers, walker_base, walk_length, (uint32_t)padding_idx, restart, (uint32_t)seed,
+                    bp, out, status);
+            else
+                elist_pool_kernel<false><<<(unsigned)pblocks, kBlock, 0, stream>>>(
+                    (const u32x2_a8 *)(ws + pl.off_ix32), (const u32x4_a16 *)(ws + pl.off_ent), el_table, pl.hash_mask,
+                    targets, n_nodes, n_walkers, walker_base, walk_length, (uint32_t)padding_idx, restart, (uint32_t)seed,
+                    bp, out, status);
+        } else
             elist_walk_kernel<true, true><<<walker_grid, kBlock, 0, stream>>>(
                 narrow, targets, n_walkers, walker_base, walk_length, padding_idx, restart, (uint32_t)seed, bp,
                 el_table, pl.hash_mask, out, status);

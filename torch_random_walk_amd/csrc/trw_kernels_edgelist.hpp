@@ -49,10 +49,13 @@ elist_shadow_kernel(const int64_t *__restrict__ edges, int64_t n_edges, const in
     if (st) atomicOr((unsigned long long *)&status[0], (unsigned long long)st);
 }
 
-// is_neighbor(x, t) looks at t's edges [first, last) -- never the last one (rw_cpu_edge_list.cpp:51).  That
-// exact set, {(head, tail) of every edge that is not its head's last}, goes into the same open-addressing
-// table the CSR walk uses (slots of {u, v, -, -}, all 0xFF when empty), so the test is one probe instead
-// of a scan of t's edges.
+// The edge table of the edge-list walk: one slot {u, v, ~posmask, ~flags} per distinct (head, tail) pair, every
+// edge included (all bytes 0xFF when empty).  Words 2 and 3 are kept INVERTED so that the fill value means
+// "nothing yet" and concurrent inserts of the same pair only ever clear bits (atomicAnd):
+//   posmask bit b   some occurrence of v sits at an offset == b (mod 32) of u's edge range -- tails are in input
+//                   order there, not sorted, so "where is v in u's range" is a set of offsets, kept modulo 32
+//   flags bit 0     some occurrence is not u's last edge: is_neighbor(x, t) looks at t's edges [first, last) --
+//                   never the last one (rw_cpu_edge_list.cpp:51) -- so THIS bit is the reference's membership test
 __global__ void __launch_bounds__(kBlock)
 elist_table_build_kernel(const int64_t *__restrict__ edges, int64_t n_edges, int64_t n_nodes,
                          const uint32_t *__restrict__ tail32, const u32x2_a8 *__restrict__ ix32,
@@ -63,28 +66,47 @@ elist_table_build_kernel(const int64_t *__restrict__ edges, int64_t n_edges, int
         const int64_t head = edges[2 * e];
         if ((uint64_t)head >= (uint64_t)n_nodes) continue;  // never indexed by a walk
         const u32x2_a8 ix = ix32[head];
-        if (ix.x == kNoEdge || (uint32_t)e < ix.x || (uint32_t)e >= ix.y) continue;  // outside [first, last)
+        if (ix.x == kNoEdge || (uint32_t)e < ix.x || (uint32_t)e > ix.y) continue;  // outside the head's range
         const uint32_t u = (uint32_t)head, v = tail32[e];
         const unsigned long long key = ((unsigned long long)v << 32) | u;
         uint32_t slot = edge_hash(u, v) & mask;
         while (true) {
-            const unsigned long long old = atomicCAS((unsigned long long *)(table + 4 * (size_t)slot), ~0ull, key);
-            if (old == ~0ull || old == key) break;
+            uint32_t *ent = table + 4 * (size_t)slot;
+            const unsigned long long old = atomicCAS((unsigned long long *)ent, ~0ull, key);
+            if (old == ~0ull || old == key) {
+                atomicAnd(ent + 2, ~(1u << (((uint32_t)e - ix.x) & 31u)));
+                if ((uint32_t)e != ix.y) atomicAnd(ent + 3, ~1u);
+                break;
+            }
             slot = (slot + 1) & mask;
         }
     }
 }
 
-__device__ __forceinline__ bool elist_table_contains(const uint32_t *__restrict__ table, uint32_t mask, uint32_t u,
-                                                     uint32_t v)
+// the slot of pair (u, v): false when absent; posmask / in_range as described above
+__device__ __forceinline__ bool elist_table_find(const uint32_t *__restrict__ table, uint32_t mask, uint32_t u,
+                                                 uint32_t v, uint32_t &posmask, bool &in_range)
 {
     uint32_t slot = edge_hash(u, v) & mask;
     while (true) {
-        const u32x2_a8 kv = *reinterpret_cast<const u32x2_a8 *>(table + 4 * (size_t)slot);
-        if (kv.x == 0xFFFFFFFFu) return false;
-        if (kv.x == u && kv.y == v) return true;
+        const u32x4_a16 kv = *reinterpret_cast<const u32x4_a16 *>(table + 4 * (size_t)slot);
+        if (kv.x == 0xFFFFFFFFu && kv.y == 0xFFFFFFFFu) return false;
+        if (kv.x == u && kv.y == v) {
+            posmask = ~kv.z;
+            in_range = (kv.w & 1u) == 0u;
+            return true;
+        }
         slot = (slot + 1) & mask;
     }
+}
+
+// is_neighbor(x, t) of the reference: is v a tail of one of u's edges other than its last?
+__device__ __forceinline__ bool elist_table_contains(const uint32_t *__restrict__ table, uint32_t mask, uint32_t u,
+                                                     uint32_t v)
+{
+    uint32_t pm;
+    bool in_range = false;
+    return elist_table_find(table, mask, u, v, pm, in_range) && in_range;
 }
 
 // Uniform views of the two layouts: node ids as int64, "no edges" as first < 0.
@@ -372,6 +394,577 @@ elist_glibc_seq_kernel(EdgeListView<false> g, const int64_t *__restrict__ target
         }
     }
     if (st) atomicOr((unsigned long long *)&status[0], (unsigned long long)st);
+}
+
+// ===========================================================================
+// Biased edge-list walk over prepared entries: walker pool (cf. biased_pool_kernel, trw_kernels_narrow.hpp)
+// ===========================================================================
+// One 64-byte entry per edge e = (u -> v), everything the step after u -> v needs (t = u, prev = v):
+//     word 0..3    v, first(v), cnt(v) (edges of v; 0: none), flags
+//     word 4..7    nb mask: bit (j & 127) = "the tail at offset j of v's range is in u's edges [first, last)"
+//                  -- the reference's is_neighbor(x, t), rw_cpu_edge_list.cpp:37-62, last edge excluded
+//     word 8..11   t mask:  bit (j & 127) = "the tail at offset j of v's range is u" -- tails keep their input
+//                  order, so the offsets that hold t are a set, not a run
+//     word 12      the only tail of v when cnt(v) == 1 (that step has a fixed candidate and draws nothing for it)
+// Exact for cnt(v) <= 128 (the range is scanned); for longer ranges both masks are 32-bit filters replicated
+// four times, built from the table's position masks by walking u's edges (kElFilter: clear = certainly not,
+// set = load the candidate and see); a range that holds the padding id as a tail is all "see" (kElHasPad).
+constexpr uint32_t kElFilter = 1u, kElHasPad = 2u;
+constexpr uint32_t kElFilterWalk = 256u;  // longest u range walked for a filter mask; all-ones beyond
+
+__global__ void __launch_bounds__(kBlock)
+elist_ext_kernel(const int64_t *__restrict__ edges, int64_t n_edges, int64_t n_nodes, uint32_t pad,
+                 const uint32_t *__restrict__ tail32, const u32x2_a8 *__restrict__ ix32,
+                 const uint32_t *__restrict__ table, uint32_t mask, u32x4_a16 *__restrict__ ent)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n_edges; e += stride) {
+        const int64_t head = edges[2 * e];
+        const uint32_t v = tail32[e];
+        uint32_t first = kNoEdge, cnt = 0, flags = 0, only = 0;
+        Mask128 nb, tm;
+        nb.clear();
+        tm.clear();
+        if (v != pad && v < (uint32_t)n_nodes && (uint64_t)head < (uint64_t)n_nodes) {
+            const uint32_t u = (uint32_t)head;
+            const u32x2_a8 ix = ix32[v];
+            if (ix.x != kNoEdge) {
+                first = ix.x;
+                cnt = ix.y - ix.x + 1u;
+            }
+            if (cnt == 1u) only = tail32[first];
+            uint32_t pm;
+            bool in_range;
+            if (cnt >= 1u && cnt <= 128u) {
+                for (uint32_t j = 0; j < cnt; ++j) {
+                    const uint32_t x = tail32[first + j];
+                    if (x == pad) flags |= kElHasPad;
+                    if (x == u) tm.set(j);
+                    if (elist_table_contains(table, mask, u, x)) nb.set(j);
+                }
+            } else if (cnt > 128u) {
+                flags |= kElFilter;
+                if (elist_table_find(table, mask, v, pad, pm, in_range)) flags |= kElHasPad;
+                uint32_t t32 = 0u, n32 = 0xFFFFFFFFu;
+                if (elist_table_find(table, mask, v, u, pm, in_range)) t32 = pm;
+                const u32x2_a8 ux = ix32[u];
+                if (ux.x != kNoEdge && ux.y - ux.x <= kElFilterWalk) {
+                    n32 = 0u;
+                    for (uint32_t k = ux.x; k < ux.y; ++k)  // u's edges [first, last): the last one never counts
+                        if (elist_table_find(table, mask, v, tail32[k], pm, in_range)) n32 |= pm;
+                }
+                for (int k = 0; k < 4; ++k) {
+                    tm.w[k] = t32;
+                    nb.w[k] = n32;
+                }
+            }
+            if (flags & kElHasPad) {
+                flags |= kElFilter;
+                nb.fill();
+                tm.fill();
+            }
+        }
+        u32x4_a16 a = {v, first, cnt, flags}, b = {nb.w[0], nb.w[1], nb.w[2], nb.w[3]},
+                  c = {tm.w[0], tm.w[1], tm.w[2], tm.w[3]}, d = {only, 0u, 0u, 0u};
+        ent[4 * (size_t)e] = a;
+        ent[4 * (size_t)e + 1] = b;
+        ent[4 * (size_t)e + 2] = c;
+        ent[4 * (size_t)e + 3] = d;
+    }
+}
+
+#ifndef TRW_ELPOOL_SLOTS
+#define TRW_ELPOOL_SLOTS 96
+#endif
+constexpr int kElSlots = TRW_ELPOOL_SLOTS;  // walkers resident per wave
+constexpr int kElWin = 12;                  // draws a burst can see: the slot's current Philox block + the next two
+enum : uint32_t { EK_RANGE = 0, EK_ENTRY, EK_TEST, EK_MEMBER, EK_FIXNB, EK_PEEK, EK_NOENTRY };
+enum : int {
+    EF_T = 0, EF_PREV, EF_FIRST, EF_CNT, EF_Z, EF_NB0, EF_NB1, EF_NB2, EF_NB3, EF_TM0, EF_TM1, EF_TM2, EF_TM3,
+    EF_FLAGS,  // bit 0 kElFilter, bit 1 kElHasPad, bit 2 this step has a FIXED candidate, bits 4..7 EK_*, bits 8.. probe count
+    EF_S, EF_REJ, EF_WALKER, EF_C0, EF_C1, EF_C2, EF_C3,
+    EF_D,      // draws the walker has consumed (the Philox block in C0..C3 is block D / 4)
+    EF_X,      // fixed step: the node an accepted trial selects; table probes: the node asked about
+    EF_AT,     // entry to gather (kNoEdge: the selected node is reached without an entry -- padding, restart)
+    EF_AUX,    // fixed step: accept iff draw < AUX; candidate under test: its acceptance draw
+    EF_JUMP,   // where a walk goes from the padding id: its start node (restart) or the padding id
+    EF_COUNT
+};
+constexpr uint32_t kEfFixed = 4u;
+
+template <bool kCount>
+__global__ void __launch_bounds__(kBlock)
+elist_pool_kernel(const u32x2_a8 *__restrict__ ix32, const u32x4_a16 *__restrict__ ent,
+                  const uint32_t *__restrict__ table, uint32_t mask, const int64_t *__restrict__ targets,
+                  int64_t n_nodes, int64_t n_walkers, int64_t walker_base, int32_t L, uint32_t pad, int32_t restart,
+                  uint32_t seed, BiasedParams bp, int64_t *__restrict__ out, int64_t *__restrict__ status)
+{
+    static_assert(kElSlots >= 64 && kElSlots <= kQueueCap, "pool size must be 64..128 slots");
+    __shared__ uint32_t pool_mem[kPoolWaves][EF_COUNT][kElSlots];
+    __shared__ uint32_t win_mem[kPoolWaves][kElWin][64];
+    __shared__ uint8_t queue_mem[kPoolWaves][3][kQueueCap];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        status[2] = TRW_RNG_WALKER;
+        status[3] = 5;
+    }
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t(*P)[kElSlots] = pool_mem[wv];
+    uint32_t(*W)[64] = win_mem[wv];
+    PoolQueue trial_q = {queue_mem[wv][0], 0u, 0u}, issue_q = {queue_mem[wv][1], 0u, 0u}, free_q = {queue_mem[wv][2], 0u, 0u};
+    for (int i = lane; i < kElSlots; i += 64) free_q.q[i] = (uint8_t)i;
+    free_q.count = kElSlots;
+    pool_fence();
+    const bool band_takes_near = bp.t1 > bp.t2;
+    const uint32_t v_clear = band_takes_near ? 0u : 1u, v_set = band_takes_near ? 1u : 0u;
+    const int32_t cols = L + 1;
+
+    uint32_t st = 0;
+    uint32_t n_trials = 0, n_fetch = 0, n_tests = 0, n_probes = 0;
+    bool hold = false;
+    uint32_t hs = 0, hkind = 0;
+    u32x4_a4 e0 = {0u, 0u, 0u, 0u}, e1 = {0u, 0u, 0u, 0u}, e2 = {0u, 0u, 0u, 0u}, e3 = {0u, 0u, 0u, 0u};
+    bool more_walkers = true;
+
+    auto row_of = [&](uint32_t slot) { return out + (int64_t)P[EF_WALKER][slot] * cols; };
+    auto set_kind = [&](uint32_t slot, uint32_t keep_bits, uint32_t kind) { P[EF_FLAGS][slot] = (keep_bits & 15u) | (kind << 4); };
+    // accept threshold of a FIXED candidate x for a walker whose t is `t` (rw_cpu_edge_list.cpp:204-231 with x constant):
+    //   x is the padding id -> t0;  else max(x == t ? t0 : 0, is_neighbor ? t1 : t2)
+    auto fixed_threshold = [&](uint32_t x, uint32_t t, bool nb) {
+        if (x == pad) return bp.t0;
+        const uint32_t cls = nb ? bp.t1 : bp.t2;
+        return (x == t && bp.t0 > cls) ? bp.t0 : cls;
+    };
+    // The walker of `slot` now stands on PREV without an entry describing it (it came through the padding id or a
+    // restart): decide what its next step looks like.  Returns 0 -> trial queue, 1 -> issue queue.
+    auto arrive_bare = [&](uint32_t slot) -> int {
+        const uint32_t prev = P[EF_PREV][slot], jump = P[EF_JUMP][slot];
+        if (prev == pad) {  // the candidate is the jump node, no draw for it (rw_cpu_edge_list.cpp:14-16)
+            P[EF_X][slot] = jump;
+            P[EF_AT][slot] = kNoEdge;
+            if (jump == pad) {
+                P[EF_AUX][slot] = bp.t0;
+                set_kind(slot, kEfFixed, 0u);
+                return 0;
+            }
+            set_kind(slot, kEfFixed, EK_FIXNB);  // is the jump node a neighbour of t?
+            return 1;
+        }
+        set_kind(slot, 0u, EK_RANGE);  // a real node: its edge range first
+        return 1;
+    };
+    // ... with its range and masks in the slot (FIRST, CNT, masks, flag bits 0..1): fixed or multi-candidate step
+    auto classify = [&](uint32_t slot, uint32_t only_tail, bool have_only) -> int {
+        const uint32_t cnt = P[EF_CNT][slot], t = P[EF_T][slot], jump = P[EF_JUMP][slot];
+        const uint32_t fbits = P[EF_FLAGS][slot] & 3u;
+        if (cnt == 0u) {  // dead end: the candidate is the padding id
+            P[EF_X][slot] = (pad == t) ? pad : jump;
+            P[EF_AT][slot] = kNoEdge;
+            P[EF_AUX][slot] = bp.t0;
+            set_kind(slot, fbits | kEfFixed, 0u);
+            return 0;
+        }
+        if (cnt == 1u) {  // one edge: the candidate is its tail, no draw for it (cpu_utils.cpp:4-5)
+            if (!have_only) {
+                P[EF_AT][slot] = P[EF_FIRST][slot];
+                set_kind(slot, fbits | kEfFixed, EK_PEEK);
+                return 1;
+            }
+            if (only_tail == pad) {
+                P[EF_X][slot] = (pad == t) ? pad : jump;
+                P[EF_AT][slot] = kNoEdge;
+                P[EF_AUX][slot] = bp.t0;
+                set_kind(slot, fbits | kEfFixed, 0u);
+                return 0;
+            }
+            P[EF_X][slot] = only_tail;
+            P[EF_AT][slot] = P[EF_FIRST][slot];
+            if (fbits & kElFilter) {  // (cannot happen for an entry-described range of one edge, kept for the bare path)
+                set_kind(slot, fbits | kEfFixed, EK_FIXNB);
+                return 1;
+            }
+            const bool is_t = P[EF_TM0][slot] & 1u, nb = P[EF_NB0][slot] & 1u;
+            const uint32_t cls = nb ? bp.t1 : bp.t2;
+            P[EF_AUX][slot] = (is_t && bp.t0 > cls) ? bp.t0 : cls;
+            set_kind(slot, fbits | kEfFixed, 0u);
+            return 0;
+        }
+        FastMod fm;
+        fm.init(cnt);
+        P[EF_Z][slot] = fm.z;
+        set_kind(slot, fbits, 0u);
+        return 0;
+    };
+    // the walker of `slot` takes `node` as column S without an entry for it
+    auto step_bare = [&](uint32_t slot, uint32_t node, bool &to_free) -> int {
+        int32_t s = (int32_t)P[EF_S][slot];
+        row_of(slot)[s] = (int64_t)node;
+        ++s;
+        P[EF_S][slot] = (uint32_t)s;
+        P[EF_T][slot] = P[EF_PREV][slot];
+        P[EF_PREV][slot] = node;
+        P[EF_REJ][slot] = 0u;
+        if (s > L) {
+            to_free = true;
+            return -1;
+        }
+        return arrive_bare(slot);
+    };
+    // ... onto the entry in e0..e3
+    auto step_entry = [&](uint32_t slot, bool &to_free) -> int {
+        const uint32_t x = e0.x;
+        int32_t s = (int32_t)P[EF_S][slot];
+        row_of(slot)[s] = (int64_t)x;
+        ++s;
+        P[EF_S][slot] = (uint32_t)s;
+        P[EF_T][slot] = P[EF_PREV][slot];
+        P[EF_PREV][slot] = x;
+        P[EF_REJ][slot] = 0u;
+        if (s > L) {
+            to_free = true;
+            return -1;
+        }
+        if (x == pad) return arrive_bare(slot);
+        P[EF_FIRST][slot] = e0.y;
+        P[EF_CNT][slot] = e0.z;
+        P[EF_NB0][slot] = e1.x;
+        P[EF_NB1][slot] = e1.y;
+        P[EF_NB2][slot] = e1.z;
+        P[EF_NB3][slot] = e1.w;
+        P[EF_TM0][slot] = e2.x;
+        P[EF_TM1][slot] = e2.y;
+        P[EF_TM2][slot] = e2.z;
+        P[EF_TM3][slot] = e2.w;
+        P[EF_FLAGS][slot] = e0.w & 3u;
+        return classify(slot, e3.x, true);
+    };
+
+    while (true) {
+        // ================= adopt =================
+        {
+            bool to_trial = false, to_issue = false, to_free = false;
+            if (hold) {
+                const uint32_t slot = hs;
+                int where = -1;  // 0 trial queue, 1 issue queue, -1 neither (freed)
+                const uint32_t flags = P[EF_FLAGS][slot];
+                if (hkind == EK_RANGE) {  // e0.x, e0.y = (first, last) of PREV
+                    const uint32_t first = e0.x, cnt = first == kNoEdge ? 0u : e0.y - e0.x + 1u;
+                    if (P[EF_S][slot] == 1u) {  // the first step samples a neighbour of the start node outright (:188)
+                        if (cnt == 0u) {
+                            where = step_bare(slot, pad, to_free);
+                        } else {
+                            uint32_t idx = 0u;
+                            if (cnt > 1u) {  // draw 0 (a single edge is taken without a draw, cpu_utils.cpp:4-5)
+                                P[EF_D][slot] = 1u;
+                                idx = (P[EF_C0][slot] >> 1) % cnt;
+                            }
+                            P[EF_AT][slot] = first + idx;
+                            set_kind(slot, 0u, EK_ENTRY);
+                            if (kCount) ++n_fetch;
+                            where = 1;
+                        }
+                    } else {  // a node reached without an entry: no masks -- every candidate is looked at
+                        P[EF_FIRST][slot] = first;
+                        P[EF_CNT][slot] = cnt;
+                        P[EF_NB0][slot] = P[EF_NB1][slot] = P[EF_NB2][slot] = P[EF_NB3][slot] = 0xFFFFFFFFu;
+                        P[EF_TM0][slot] = P[EF_TM1][slot] = P[EF_TM2][slot] = P[EF_TM3][slot] = 0xFFFFFFFFu;
+                        P[EF_FLAGS][slot] = kElFilter | kElHasPad;
+                        where = classify(slot, 0u, false);
+                    }
+                } else if (hkind == EK_ENTRY) {
+                    where = step_entry(slot, to_free);
+                } else if (hkind == EK_NOENTRY) {
+                    where = step_bare(slot, P[EF_X][slot], to_free);
+                } else if (hkind == EK_PEEK) {  // e0.x = the only tail of PREV
+                    const uint32_t x = e0.x, t = P[EF_T][slot];
+                    if (x == pad) {
+                        P[EF_X][slot] = (pad == t) ? pad : P[EF_JUMP][slot];
+                        P[EF_AT][slot] = kNoEdge;
+                        P[EF_AUX][slot] = bp.t0;
+                        set_kind(slot, flags, 0u);
+                        where = 0;
+                    } else {
+                        P[EF_X][slot] = x;
+                        set_kind(slot, flags, EK_FIXNB);
+                        where = 1;
+                    }
+                } else if (hkind == EK_TEST) {  // e0.. = a candidate the masks could not decide: the reference's own tests
+                    if (kCount) ++n_tests;
+                    const uint32_t x = e0.x, t = P[EF_T][slot], ru = P[EF_AUX][slot];
+                    const uint32_t idx = P[EF_AT][slot] - P[EF_FIRST][slot];
+                    const uint32_t k = (idx >> 5) & 3u;
+                    const uint32_t word = P[EF_NB0 + (int)k][slot];
+                    const bool nb_bit = (word >> (idx & 31u)) & 1u;
+                    int verdict;  // 0 reject, 1 accept the entry, 2 accept the jump node, 3 ask the table
+                    if (x == t && ru < bp.t0) verdict = 1;
+                    else if (x == pad) verdict = ru < bp.t0 ? 2 : 0;
+                    else if (ru < bp.lo) verdict = 1;
+                    else if (ru >= bp.hi) verdict = 0;
+                    else if (!nb_bit) verdict = band_takes_near ? 0 : 1;
+                    else verdict = 3;
+                    if (verdict == 1) {
+                        where = step_entry(slot, to_free);
+                    } else if (verdict == 2) {
+                        where = step_bare(slot, P[EF_JUMP][slot], to_free);
+                    } else if (verdict == 3) {
+                        P[EF_X][slot] = x;
+                        set_kind(slot, flags, EK_MEMBER);
+                        where = 1;
+                    } else {
+                        const uint32_t rej = P[EF_REJ][slot] + 1u;
+                        P[EF_REJ][slot] = rej;
+                        if (rej >= kTrialCap) {
+                            st |= (uint32_t)kStTrialCap;
+                            where = step_entry(slot, to_free);
+                        } else {
+                            set_kind(slot, flags, 0u);
+                            where = 0;
+                        }
+                    }
+                } else {  // EK_MEMBER / EK_FIXNB: e0 = one table slot {u, v, ~posmask, ~flags}
+                    if (kCount) ++n_probes;
+                    const uint32_t t = P[EF_T][slot], x = P[EF_X][slot];
+                    const bool empty = e0.x == 0xFFFFFFFFu;
+                    const bool match = e0.x == t && e0.y == x;
+                    if (!empty && !match) {
+                        P[EF_FLAGS][slot] = flags + 256u;  // next slot of the probe chain
+                        where = 1;
+                    } else {
+                        const bool nb = match && (e0.w & 1u) == 0u;
+                        if (hkind == EK_FIXNB) {
+                            P[EF_AUX][slot] = fixed_threshold(x, t, nb);
+                            set_kind(slot, flags, 0u);
+                            where = 0;
+                        } else if (nb == band_takes_near) {  // the draw sat inside the band: accepted, gather the entry again
+                            set_kind(slot, flags, EK_ENTRY);
+                            if (kCount) ++n_fetch;
+                            where = 1;
+                        } else {
+                            const uint32_t rej = P[EF_REJ][slot] + 1u;
+                            P[EF_REJ][slot] = rej;
+                            if (rej >= kTrialCap) {
+                                st |= (uint32_t)kStTrialCap;
+                                set_kind(slot, flags, EK_ENTRY);
+                                where = 1;
+                            } else {
+                                set_kind(slot, flags, 0u);
+                                where = 0;
+                            }
+                        }
+                    }
+                }
+                to_trial = where == 0;
+                to_issue = where == 1;
+            }
+            trial_q.push(to_trial, hs);
+            issue_q.push(to_issue, hs);
+            free_q.push(to_free, hs);
+            hold = false;
+            pool_fence();
+        }
+
+        // ================= refill =================
+        if (more_walkers && (free_q.count >= 32u || trial_q.count + issue_q.count < 64u) && free_q.count > 0u) {
+            uint32_t n, slot;
+            const uint32_t avail = free_q.count < 64u ? free_q.count : 64u;
+            long long base = 0;
+            if (lane == 0) base = (long long)atomicAdd((unsigned long long *)&status[kStNextWalker], (unsigned long long)avail);
+            base = __shfl(base, 0);
+            int64_t left = n_walkers - (int64_t)base;
+            left = left < 0 ? 0 : left;
+            const uint32_t take = left < (int64_t)avail ? (uint32_t)left : avail;
+            if (take < avail) more_walkers = false;
+            const uint32_t keep_count = free_q.count;
+            free_q.pop(lane, n, slot);
+            if (take < n) {
+                free_q.head = (free_q.head + (uint32_t)kQueueCap - (n - take)) & (uint32_t)(kQueueCap - 1);
+                free_q.count = keep_count - take;
+            }
+            bool to_issue = false, back = false;
+            if ((uint32_t)lane < take) {
+                const int64_t walker = (int64_t)base + lane;
+                const int64_t tg = targets[walker];
+                if (tg != (int64_t)pad && (uint64_t)tg >= (uint64_t)n_nodes) {
+                    st |= TRW_ST_NODE_RANGE;  // reported; the row is filled with the bad id
+                    int64_t *rowp = out + walker * cols;
+                    for (int32_t c = 0; c <= L; ++c) rowp[c] = tg;
+                    back = true;
+                } else {
+                    P[EF_WALKER][slot] = (uint32_t)walker;
+                    out[walker * cols] = tg;  // column 0
+                    P[EF_JUMP][slot] = restart ? (uint32_t)tg : pad;  // rw_cpu_edge_list.cpp:103-108
+                    P[EF_PREV][slot] = (uint32_t)tg;
+                    P[EF_T][slot] = (uint32_t)tg;
+                    P[EF_S][slot] = 1u;
+                    P[EF_REJ][slot] = 0u;
+                    P[EF_D][slot] = 0u;
+                    uint32_t blk[4];  // the slot always holds the Philox block its next draw lives in
+                    walker_block((uint64_t)walker_base + (uint64_t)walker, 0u, seed, blk);
+                    P[EF_C0][slot] = blk[0];
+                    P[EF_C1][slot] = blk[1];
+                    P[EF_C2][slot] = blk[2];
+                    P[EF_C3][slot] = blk[3];
+                    if ((uint32_t)tg == pad) {  // step 1 from the padding id goes to the jump node (= the padding id)
+                        P[EF_X][slot] = pad;
+                        set_kind(slot, 0u, EK_NOENTRY);
+                    } else {
+                        set_kind(slot, 0u, EK_RANGE);
+                    }
+                    to_issue = true;
+                }
+            }
+            issue_q.push(to_issue, slot);
+            free_q.push(back, slot);
+            pool_fence();
+        }
+        if (!more_walkers && free_q.count == (uint32_t)kElSlots) break;
+
+        // ================= issue =================
+        if (issue_q.count >= kPoolIssueMin || (issue_q.count > 0u && trial_q.count < kPoolTrialMin)) {
+            uint32_t n, slot;
+            issue_q.pop(lane, n, slot);
+            if ((uint32_t)lane < n) {
+                const uint32_t flags = P[EF_FLAGS][slot];
+                const uint32_t kind = (flags >> 4) & 15u;
+                if (kind == EK_ENTRY || kind == EK_TEST || kind == EK_PEEK) {
+                    const uint32_t *addr = reinterpret_cast<const uint32_t *>(ent + 4 * (size_t)P[EF_AT][slot]);
+                    e0 = *reinterpret_cast<const u32x4_a4 *>(addr);
+                    if (kind != EK_PEEK) {
+                        e1 = *reinterpret_cast<const u32x4_a4 *>(addr + 4);
+                        e2 = *reinterpret_cast<const u32x4_a4 *>(addr + 8);
+                        e3 = *reinterpret_cast<const u32x4_a4 *>(addr + 12);
+                    }
+                } else if (kind == EK_RANGE) {
+                    const u32x2_a8 ix = ix32[P[EF_PREV][slot]];
+                    e0.x = ix.x;
+                    e0.y = ix.y;
+                } else if (kind == EK_MEMBER || kind == EK_FIXNB) {
+                    const uint32_t s0 = edge_hash(P[EF_T][slot], P[EF_X][slot]);
+                    e0 = *reinterpret_cast<const u32x4_a4 *>(table + 4 * (size_t)((s0 + (flags >> 8)) & mask));
+                }  // EK_NOENTRY: nothing to load
+                hold = true;
+                hs = slot;
+                hkind = kind;
+            }
+        }
+
+        // ================= burst =================
+        if (trial_q.count >= kPoolTrialMin || (trial_q.count > 0u && issue_q.count < kPoolIssueMin)) {
+            uint32_t n, slot;
+            trial_q.pop(lane, n, slot);
+            const bool busy = (uint32_t)lane < n;
+            const uint32_t first = P[EF_FIRST][slot], cnt = P[EF_CNT][slot];
+            FastMod fm;
+            fm.d = busy && cnt ? cnt : 1u;
+            fm.z = P[EF_Z][slot];
+            const uint32_t nb0 = P[EF_NB0][slot], nb1 = P[EF_NB1][slot], nb2 = P[EF_NB2][slot], nb3 = P[EF_NB3][slot];
+            const uint32_t tm0 = P[EF_TM0][slot], tm1 = P[EF_TM1][slot], tm2 = P[EF_TM2][slot], tm3 = P[EF_TM3][slot];
+            const uint32_t flags = P[EF_FLAGS][slot];
+            const bool fixed = (flags & kEfFixed) != 0u, filter = (flags & kElFilter) != 0u, haspad = (flags & kElHasPad) != 0u;
+            const uint32_t aux = P[EF_AUX][slot];
+            uint32_t rejected = P[EF_REJ][slot];
+            const uint32_t d0 = P[EF_D][slot];
+            const uint64_t gw = (uint64_t)walker_base + (uint64_t)P[EF_WALKER][slot];
+            // the window of draws: the slot's current block and the next two
+            W[0][lane] = P[EF_C0][slot];
+            W[1][lane] = P[EF_C1][slot];
+            W[2][lane] = P[EF_C2][slot];
+            W[3][lane] = P[EF_C3][slot];
+            if (busy) {
+                uint32_t nbk[4];
+                walker_block(gw, (d0 >> 2) + 1u, seed, nbk);
+                W[4][lane] = nbk[0];
+                W[5][lane] = nbk[1];
+                W[6][lane] = nbk[2];
+                W[7][lane] = nbk[3];
+                walker_block(gw, (d0 >> 2) + 2u, seed, nbk);
+                W[8][lane] = nbk[0];
+                W[9][lane] = nbk[1];
+                W[10][lane] = nbk[2];
+                W[11][lane] = nbk[3];
+            }
+            uint32_t pos = d0 & 3u;           // next draw inside the window
+            const uint32_t need = fixed ? 1u : 2u;
+            uint32_t verdict = 0u, at = 0u, ru_keep = 0u;
+            bool running = busy;
+#pragma unroll 1
+            for (int rep = 0; rep < 4; ++rep) {
+                running = running && pos + need <= 8u + (d0 & 3u) && pos + need <= (uint32_t)kElWin;
+                if (__ballot(running) == 0) break;
+                if (running) {
+                    if (kCount) ++n_trials;
+                    uint32_t v;
+                    if (fixed) {
+                        const uint32_t ru = W[pos][lane] >> 1;
+                        pos += 1u;
+                        v = ru < aux ? 1u : 0u;
+                    } else {
+                        const uint32_t rc = W[pos][lane] >> 1, ru = W[pos + 1u][lane] >> 1;
+                        pos += 2u;
+                        const uint32_t idx = fm.mod(rc);
+                        const uint32_t k = (idx >> 5) & 3u, sh = idx & 31u;
+                        const bool nbb = ((k == 0u ? nb0 : (k == 1u ? nb1 : (k == 2u ? nb2 : nb3))) >> sh) & 1u;
+                        const bool tmb = ((k == 0u ? tm0 : (k == 1u ? tm1 : (k == 2u ? tm2 : tm3))) >> sh) & 1u;
+                        const uint32_t v_band = nbb ? (filter ? 2u : v_set) : v_clear;
+                        const uint32_t v_cls = ru < bp.lo ? 1u : (ru >= bp.hi ? 0u : v_band);
+                        // the offset may hold t: exact mask -> the reference's first test, then its class; filter -> look
+                        const uint32_t v_t = filter ? 2u : ((ru < bp.t0) ? 1u : v_cls);
+                        v = haspad ? 2u : (tmb ? v_t : v_cls);
+                        at = first + idx;
+                        ru_keep = ru;
+                    }
+                    rejected = v == 0u ? rejected + 1u : rejected;
+                    if (rejected >= kTrialCap) {
+                        st |= (uint32_t)kStTrialCap;
+                        v = 1u;
+                    }
+                    verdict = v;
+                    running = v == 0u;
+                }
+            }
+            bool to_issue = false, to_trial = false;
+            if (busy) {
+                // the block the walker's next draw lives in becomes the slot's current block
+                const uint32_t used = pos - (d0 & 3u);
+                const uint32_t d1 = d0 + used;
+                const uint32_t shift = (d1 >> 2) - (d0 >> 2);  // 0, 1 or 2 blocks on
+                P[EF_C0][slot] = W[4 * shift + 0][lane];
+                P[EF_C1][slot] = W[4 * shift + 1][lane];
+                P[EF_C2][slot] = W[4 * shift + 2][lane];
+                P[EF_C3][slot] = W[4 * shift + 3][lane];
+                P[EF_D][slot] = d1;
+                P[EF_REJ][slot] = rejected;
+                if (verdict == 0u) {
+                    to_trial = true;
+                } else if (fixed) {  // the fixed candidate is taken: through its entry, or bare (padding / jump)
+                    const bool bare = P[EF_AT][slot] == kNoEdge;
+                    set_kind(slot, flags, bare ? EK_NOENTRY : EK_ENTRY);
+                    if (kCount && !bare) ++n_fetch;
+                    to_issue = true;
+                } else {
+                    P[EF_AT][slot] = at;
+                    P[EF_AUX][slot] = ru_keep;
+                    set_kind(slot, flags, verdict == 1u ? EK_ENTRY : EK_TEST);
+                    if (kCount) ++n_fetch;
+                    to_issue = true;
+                }
+            }
+            issue_q.push(to_issue, slot);
+            trial_q.push(to_trial, slot);
+            pool_fence();
+        }
+    }
+
+    if (st) atomicOr((unsigned long long *)&status[0], (unsigned long long)st);
+    if (kCount) {
+        const uint64_t a = wave_sum(n_trials), b = wave_sum(n_fetch), c = wave_sum(n_tests), d = wave_sum(n_probes);
+        if (lane == 0) {
+            atomicAdd((unsigned long long *)&status[4], (unsigned long long)a);
+            atomicAdd((unsigned long long *)&status[5], (unsigned long long)b);
+            atomicAdd((unsigned long long *)&status[6], (unsigned long long)c);
+            atomicAdd((unsigned long long *)&status[7], (unsigned long long)d);
+        }
+    }
 }
 
 }  // namespace
