@@ -251,6 +251,31 @@ int trw_walk_edge_list_hip(const int64_t *edges, int64_t n_edges,
                            int64_t *out, void *workspace, size_t workspace_bytes, void *hip_stream);
 
 /*
+ * The prepared edge list (cf. trw_prepare_csr_hip): uint32 shadow of tails and index; TRW_ELPREP_TABLE adds the edge
+ * table {head, tail, positions of the tail in the head's range modulo 32, "not only the head's last edge"};
+ * TRW_ELPREP_ENTRIES (implies TABLE) adds one 64-byte entry per edge with the next node's range and two 128-bit
+ * masks ("the tail at this offset is a neighbour of the node I came from" / "... IS the node I came from") --
+ * the biased walk then decides its trials in registers (elist_pool_kernel).  The blob depends on `padding_idx`.
+ * trw_walk_edge_list_hip above prepares inside its workspace on every call; a caller that walks an edge list more
+ * than once keeps the blob.  trw_walk_edge_list_prepared_hip needs a 256-byte workspace (the status block).
+ */
+#define TRW_ELPREP_TABLE   1
+#define TRW_ELPREP_ENTRIES 2
+int32_t trw_prepare_edge_list_plan(int64_t n_edges, int64_t n_nodes, int64_t n_walkers, int32_t walk_length,
+                                   double p, double q, int64_t padding_idx, int32_t rng_mode);
+size_t trw_prepare_edge_list_bytes(int64_t n_edges, int64_t n_nodes, int64_t padding_idx, int32_t what);
+int trw_prepare_edge_list_hip(const int64_t *edges, int64_t n_edges, const int64_t *node_edge_index, int64_t n_nodes,
+                              int64_t padding_idx, int32_t what, void *prepared, size_t prepared_bytes,
+                              void *hip_stream);
+int trw_walk_edge_list_prepared_hip(const void *prepared, size_t prepared_bytes, int32_t what,
+                                    const int64_t *edges, int64_t n_edges,
+                                    const int64_t *node_edge_index, int64_t n_nodes,
+                                    const int64_t *targets, int64_t n_walkers, int64_t walker_base,
+                                    double p, double q, int32_t walk_length, int32_t seed,
+                                    int64_t padding_idx, int32_t restart, int32_t rng_mode,
+                                    int64_t *out, void *workspace, size_t workspace_bytes, void *hip_stream);
+
+/*
  * Window builders.  Replace the reference's to_windows_gpu / to_windows_cbow_gpu
  * (csrc/cuda/windows_cuda.h:5-17, called from csrc/rw_init.cpp:83-84 and :96-97) and produce what
  * to_windows_cpu / to_windows_cbow_cpu (csrc/cpu/windows_cpu.cpp:5-77, :80-158) produce.

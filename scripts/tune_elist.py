@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Times the biased edge-list walk of one libtrw_hip.so build (GPU box, tuning aid; cf. tune_biased.py)."""
+import argparse
+import ctypes
+import importlib.util
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ap = argparse.ArgumentParser()
+ap.add_argument("--lib", default=os.path.join(ROOT, "torch_random_walk_amd", "libtrw_hip.so"))
+ap.add_argument("--nodes", type=int, default=1_000_000)
+ap.add_argument("--edges", type=int, default=10_000_000)
+ap.add_argument("--runs", type=int, default=4)
+ap.add_argument("--L", type=int, default=80)
+ap.add_argument("--env", nargs="*", default=[])
+ap.add_argument("--tag", default="")
+args = ap.parse_args()
+for kv in args.env:
+    k, v = kv.split("=", 1)
+    os.environ[k] = v
+import torch  # noqa: E402
+
+
+def load(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "torch_random_walk_amd", name + ".py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+graphs, utils = load("graphs"), load("utils")
+L = ctypes.CDLL(args.lib)
+vp, i64, i32, dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_double
+L.trw_last_error.restype = ctypes.c_char_p
+L.trw_walk_edge_list_workspace_bytes.argtypes = [i64, i64, i64, i32, i64, i32]
+L.trw_walk_edge_list_workspace_bytes.restype = ctypes.c_size_t
+L.trw_walk_edge_list_hip.argtypes = [vp, i64, vp, i64, vp, i64, i64, dbl, dbl, i32, i32, i64, i32, i32, vp, vp, ctypes.c_size_t, vp]
+L.trw_profile_enable.argtypes = [ctypes.c_int]
+L.trw_profile_last.argtypes = [ctypes.POINTER(dbl)] * 3
+L.trw_walk_status.argtypes = [vp, vp, ctypes.POINTER(i64)]
+dev = torch.device("cuda", 0)
+n = args.nodes
+rp, ci = graphs.rmat(n, args.edges, seed=1, device=dev)
+heads = torch.repeat_interleave(torch.arange(n, device=dev), rp[1:] - rp[:-1])
+keep = ci != (heads + 1) % n
+index, edges = utils.build_node_edge_index(torch.stack([heads[keep], ci[keep]], 1), torch.arange(n, device=dev))
+E_ = edges.shape[0]
+tg = torch.arange(n, device=dev)
+stream = torch.cuda.current_stream().cuda_stream
+nb = L.trw_walk_edge_list_workspace_bytes(E_, n, n, args.L, n, 2)
+ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+out = torch.empty((n, args.L + 1), dtype=torch.int64, device=dev)
+L.trw_profile_enable(1)
+pre, wk = [], []
+chk = None
+for r in range(args.runs):
+    rc = L.trw_walk_edge_list_hip(edges.data_ptr(), E_, index.data_ptr(), n, tg.data_ptr(), n, 0, 0.25, 4.0, args.L, 10, n, 1, 2,
+                                  out.data_ptr(), ws.data_ptr(), nb, stream)
+    assert rc == 0, L.trw_last_error()
+    a, b, c = dbl(), dbl(), dbl()
+    assert L.trw_profile_last(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) == 0
+    pre.append(a.value)
+    wk.append(b.value)
+    s = int(out.sum())
+    assert chk is None or chk == s
+    chk = s
+st = (i64 * 4)()
+L.trw_walk_status(ws.data_ptr(), stream, st)
+print("%-40s prepare %.2f  walk %s  best %.2f  family %d status %d checksum %x" % (
+    args.tag or os.path.basename(args.lib), min(pre), " ".join("%.2f" % t for t in wk), min(wk), st[3], st[0], chk & 0xffffffff), flush=True)

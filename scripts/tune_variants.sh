@@ -10,6 +10,6 @@ for FLAGS in "$@"; do
   LIB=gpurun_out/variants/libtrw_v$i.so
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-function $FLAGS -o $LIB \
       torch_random_walk_amd/csrc/trw_hip.hip torch_random_walk_amd/csrc/trw_cpu.cpp 2> gpurun_out/variants/build_v$i.log || { echo "build failed: $FLAGS"; tail -5 gpurun_out/variants/build_v$i.log; continue; }
-  timeout -k 10 300 python3 scripts/tune_biased.py --lib $LIB --tag "[$FLAGS]" ${TUNE_ARGS:-} 2>&1 | grep -v amdgpu.ids
+  timeout -k 10 300 python3 ${TUNE_SCRIPT:-scripts/tune_biased.py} --lib $LIB --tag "[$FLAGS]" ${TUNE_ARGS:-} 2>&1 | grep -v amdgpu.ids
   rm -f $LIB
 done

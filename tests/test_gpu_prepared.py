@@ -239,3 +239,35 @@ def test_prepared_c_abi_direct(rw):
             assert (out.cpu().numpy() == O.walk(rp, ci, tg, p, q, Lw, 10, rng_mode=omode)).all(), (what, p, q, mode)
             if what in (2, 6, 7, 14) and mode == 2 and p != 1.0:
                 assert st[3] in (4, 5)                             # the mask / walker-pool kernel
+
+
+def test_prepared_edge_list_is_cached_per_padding_id_and_invalidated_by_writes(rw):
+    from torch_rw import utils
+    rng = np.random.default_rng(3)
+    n = 500
+    src, dst = rng.integers(0, n, 4000), rng.integers(0, n, 4000)
+    src = src[src % 7 != 3]
+    dst = dst[:src.size]
+    index, edges = utils.build_node_edge_index(torch.as_tensor(np.stack([src, dst], 1)), torch.arange(n))
+    tg = rng.integers(0, n, 3000)
+    d_e, d_i, d_t = edges.to(DEV), index.to(DEV), torch.as_tensor(tg).to(DEV)
+
+    def both(pad):
+        got = rw.walk_edge_list_ex(d_e, d_i, d_t, 0.25, 4.0, 25, 5, pad, rng_mode=rw.RNG_WALKER).cpu().numpy()
+        ref = O.walk_edge_list(d_e.cpu().numpy(), d_i.cpu().numpy(), tg, 0.25, 4.0, 25, 5, pad, rng_mode=O.RNG_WALKER)
+        assert (got == ref).all()
+
+    both(n)
+    info = rw.cache_info()
+    assert len(info) == 1 and info[0][:2] == (n, edges.shape[0]) and info[0][2] == 3      # table + entries
+    blob = info[0][3]
+    both(n)
+    assert rw.cache_info()[0][3] == blob and len(rw.cache_info()) == 1
+    both(3)                                                       # another padding id: another prepared edge list
+    assert len(rw.cache_info()) == 2
+    # in-place write to the tails: the version counter invalidates, the walk follows the new edges
+    perm = torch.randperm(d_e.shape[0], device=DEV)
+    d_e[:, 1] = d_e[perm, 1]
+    both(n)
+    u = rw.walk_edge_list_ex(d_e, d_i, d_t, 1.0, 1.0, 25, 5, n, rng_mode=rw.RNG_WALKER).cpu().numpy()
+    assert (u == O.walk_edge_list(d_e.cpu().numpy(), d_i.cpu().numpy(), tg, 1.0, 1.0, 25, 5, n, rng_mode=O.RNG_WALKER)).all()

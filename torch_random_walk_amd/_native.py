@@ -66,6 +66,15 @@ def cabi():
         L.trw_status_post.restype = ctypes.c_int
         L.trw_status_collect.argtypes = [ctypes.c_int, ctypes.POINTER(i64)]
         L.trw_status_collect.restype = ctypes.c_int
+        L.trw_prepare_edge_list_plan.argtypes = [i64, i64, i64, i32, dbl, dbl, i64, i32]
+        L.trw_prepare_edge_list_plan.restype = ctypes.c_int32
+        L.trw_prepare_edge_list_bytes.argtypes = [i64, i64, i64, i32]
+        L.trw_prepare_edge_list_bytes.restype = ctypes.c_size_t
+        L.trw_prepare_edge_list_hip.argtypes = [vp, i64, vp, i64, i64, i32, vp, ctypes.c_size_t, vp]
+        L.trw_prepare_edge_list_hip.restype = ctypes.c_int
+        L.trw_walk_edge_list_prepared_hip.argtypes = [vp, ctypes.c_size_t, i32, vp, i64, vp, i64, vp, i64, i64, dbl, dbl,
+                                                      i32, i32, i64, i32, i32, vp, vp, ctypes.c_size_t, vp]
+        L.trw_walk_edge_list_prepared_hip.restype = ctypes.c_int
         L.trw_walk_status.argtypes = [vp, vp, ctypes.POINTER(i64)]
         L.trw_walk_status.restype = ctypes.c_int
         L.trw_accept_threshold.argtypes = [dbl]

@@ -143,6 +143,8 @@ struct PreparedGraph {
     int64_t rp_numel = 0, ci_numel = 0;
     uint32_t rp_version = 0, ci_version = 0;
     c10::Device device{c10::kCPU};
+    int kind = 0;                 // 0: CSR (row_ptr, col_idx); 1: edge list (edge_list_indexed, node_edge_index)
+    int64_t pad = 0;              // edge list: the padding id the shadow was built for
     int32_t what = 0;
     torch::Tensor blob;
     void *ready = nullptr;        // event recorded after the prepare kernels
@@ -173,10 +175,10 @@ bool cache_enabled()
 
 bool cacheable(const torch::Tensor &t) { return !t.is_inference() && t.has_storage(); }
 
-bool entry_matches(const PreparedGraph &e, const torch::Tensor &rp, const torch::Tensor &ci)
+bool entry_matches(const PreparedGraph &e, const torch::Tensor &rp, const torch::Tensor &ci, int kind, int64_t pad)
 {
     const auto a = e.rp_storage.lock(), b = e.ci_storage.lock();
-    return a && b && a.get() == rp.storage().unsafeGetStorageImpl() && b.get() == ci.storage().unsafeGetStorageImpl() &&
+    return e.kind == kind && e.pad == pad && a && b && a.get() == rp.storage().unsafeGetStorageImpl() && b.get() == ci.storage().unsafeGetStorageImpl() &&
            e.rp_ptr == rp.data_ptr() && e.ci_ptr == ci.data_ptr() && e.rp_numel == rp.numel() &&
            e.ci_numel == ci.numel() && e.rp_version == rp._version() && e.ci_version == ci._version() &&
            e.device == rp.device();
@@ -186,17 +188,21 @@ bool entry_matches(const PreparedGraph &e, const torch::Tensor &rp, const torch:
 // memory (each part is optional: the walk then takes the kernel that does without it).
 void build_blob(PreparedGraph &entry, const torch::Tensor &rp, const torch::Tensor &ci, int32_t what, void *stream)
 {
-    const int64_t n_nodes = rp.numel() - 1, nnz = ci.numel();
+    const bool elist = entry.kind == 1;  // rp = edge_list_indexed [E, 2], ci = node_edge_index [n, 2]
+    const int64_t n_nodes = elist ? ci.size(0) : rp.numel() - 1, nnz = elist ? rp.size(0) : ci.numel();
     // The old blob goes first: an upgrade rebuilds everything, and on a graph the size of BASELINE configs[3] old and
     // new blob (131 GB each) do not fit side by side.  (A call still walking over the old one holds its own reference.)
     entry.blob = torch::Tensor();
     entry.what = -100;
-    const int32_t ladder[4] = {what, (int32_t)(what & ~(TRW_PREP_MARKS | TRW_PREP_MARKS_FULL)),
-                               (int32_t)(what & TRW_PREP_UNIFORM), 0};
+    const int32_t csr_ladder[4] = {what, (int32_t)(what & ~(TRW_PREP_MARKS | TRW_PREP_MARKS_FULL)),
+                                   (int32_t)(what & TRW_PREP_UNIFORM), 0};
+    const int32_t el_ladder[4] = {what, (int32_t)(what & TRW_ELPREP_TABLE), 0, 0};
+    const int32_t *ladder = elist ? el_ladder : csr_ladder;
     for (int k = 0; k < 4; ++k) {
         const int32_t w = ladder[k];
         if (k > 0 && w == ladder[k - 1]) continue;
-        const size_t bytes = trw_prepare_csr_bytes(n_nodes, nnz, w);
+        const size_t bytes = elist ? trw_prepare_edge_list_bytes(nnz, n_nodes, entry.pad, w)
+                                   : trw_prepare_csr_bytes(n_nodes, nnz, w);
         torch::Tensor blob;
         try {
             blob = torch::empty({(int64_t)bytes}, rp.options().dtype(torch::kUInt8));
@@ -204,8 +210,10 @@ void build_blob(PreparedGraph &entry, const torch::Tensor &rp, const torch::Tens
             if (k == 3) throw;
             continue;  // (the allocator has already given its cached blocks back before throwing)
         }
-        const int rc = trw_prepare_csr_hip(rp.data_ptr<int64_t>(), n_nodes, ci.data_ptr<int64_t>(), nnz, w,
-                                           blob.data_ptr(), bytes, stream);
+        const int rc = elist ? trw_prepare_edge_list_hip(rp.data_ptr<int64_t>(), nnz, ci.data_ptr<int64_t>(), n_nodes,
+                                                         entry.pad, w, blob.data_ptr(), bytes, stream)
+                             : trw_prepare_csr_hip(rp.data_ptr<int64_t>(), n_nodes, ci.data_ptr<int64_t>(), nnz, w,
+                                                   blob.data_ptr(), bytes, stream);
         TORCH_CHECK(rc == TRW_OK, "torch_rw prepare failed (", rc, "): ", trw_last_error());
         trw_event_destroy(entry.ready);
         entry.ready = trw_event_record(stream);
@@ -228,7 +236,7 @@ struct PreparedUse {
 // The prepared graph for this call (built or upgraded as needed); !valid when the call should prepare for
 // itself (cache off, capture in progress, uncacheable tensors).
 PreparedUse prepared_for(const torch::Tensor &rp, const torch::Tensor &ci, int32_t needed, bool biased_walk, bool pin,
-                         const c10::hip::HIPStreamMasqueradingAsCUDA &torch_stream)
+                         const c10::hip::HIPStreamMasqueradingAsCUDA &torch_stream, int kind = 0, int64_t pad = 0)
 {
     void *const stream = (void *)torch_stream.stream();
     PreparedUse use;
@@ -236,7 +244,7 @@ PreparedUse prepared_for(const torch::Tensor &rp, const torch::Tensor &ci, int32
     std::lock_guard<std::mutex> lock(g_cache_mu);
     std::shared_ptr<PreparedGraph> hit;
     for (auto it = g_cache.begin(); it != g_cache.end();) {
-        if (entry_matches(**it, rp, ci)) {
+        if (entry_matches(**it, rp, ci, kind, pad)) {
             hit = *it;
             it = g_cache.erase(it);
         } else if ((*it)->rp_storage.expired() || (*it)->ci_storage.expired()) {
@@ -254,15 +262,21 @@ PreparedUse prepared_for(const torch::Tensor &rp, const torch::Tensor &ci, int32
         hit->rp_version = rp._version();
         hit->ci_version = ci._version();
         hit->device = rp.device();
+        hit->kind = kind;
+        hit->pad = pad;
         hit->what = -100;  // nothing built yet
     }
     int32_t want = needed < 0 ? 0 : needed;
     if (hit->what >= 0) want |= hit->what;
-    // the second node2vec walk over a graph is the sign that it is walked repeatedly: worth the full masks
-    if (biased_walk && (want & TRW_PREP_BIASED) && hit->biased_walks >= 1) want |= TRW_PREP_MARKS;
-    want &= ~hit->refused;
-    if (want & TRW_PREP_MARKS_FULL) want |= TRW_PREP_MARKS;
-    if (want & TRW_PREP_MARKS) want |= TRW_PREP_BIASED;
+    if (kind == 0) {
+        // the second node2vec walk over a graph is the sign that it is walked repeatedly: worth the full masks
+        if (biased_walk && (want & TRW_PREP_BIASED) && hit->biased_walks >= 1) want |= TRW_PREP_MARKS;
+        want &= ~hit->refused;
+        if (want & TRW_PREP_MARKS_FULL) want |= TRW_PREP_MARKS;
+        if (want & TRW_PREP_MARKS) want |= TRW_PREP_BIASED;
+    } else if (want & TRW_ELPREP_ENTRIES) {
+        want |= TRW_ELPREP_TABLE;
+    }
     want &= ~hit->refused;
     if (hit->what < 0 || (want & ~hit->what) != 0) build_blob(*hit, rp, ci, want, stream);
     if (biased_walk) ++hit->biased_walks;
@@ -479,17 +493,31 @@ torch::Tensor walk_edge_list_ex(const torch::Tensor &edge_list_indexed, const to
     const auto tg = target_nodes.contiguous();
     const int64_t n_edges = ed.size(0), n_nodes = ix.size(0), n_walkers = tg.numel();
     auto walks = torch::empty({n_walkers, walk_length + 1}, tg.options());
-    const size_t ws_bytes = trw_walk_edge_list_workspace_bytes(n_edges, n_nodes, n_walkers, (int32_t)walk_length,
-                                                               padding_idx, (int32_t)rng_mode);
-    auto workspace = torch::empty({(int64_t)ws_bytes}, tg.options().dtype(torch::kUInt8));
+    void *const hs = (void *)stream.stream();
+    const int32_t needed = trw_prepare_edge_list_plan(n_edges, n_nodes, n_walkers, (int32_t)walk_length, p, q, padding_idx,
+                                                      (int32_t)rng_mode);
+    PreparedUse prepared;
+    if (n_walkers > 0 && needed >= 0 && ed.is_same(edge_list_indexed) && ix.is_same(node_edges_idx))
+        prepared = prepared_for(ed, ix, needed, false, false, stream, 1, padding_idx);
+    torch::Tensor workspace;
     int rc;
-    {
+    if (prepared.valid) {
+        workspace = torch::empty({256}, tg.options().dtype(torch::kUInt8));
+        pybind11::gil_scoped_release nogil;
+        rc = trw_walk_edge_list_prepared_hip(prepared.blob.data_ptr(), (size_t)prepared.blob.numel(), prepared.what,
+                                             ed.data_ptr<int64_t>(), n_edges, ix.data_ptr<int64_t>(), n_nodes,
+                                             tg.data_ptr<int64_t>(), n_walkers, walker_base, p, q, (int32_t)walk_length,
+                                             (int32_t)seed, padding_idx, restart ? 1 : 0, (int32_t)rng_mode,
+                                             walks.data_ptr<int64_t>(), workspace.data_ptr(), 256, hs);
+    } else {
+        const size_t ws_bytes = trw_walk_edge_list_workspace_bytes(n_edges, n_nodes, n_walkers, (int32_t)walk_length,
+                                                                   padding_idx, (int32_t)rng_mode);
+        workspace = torch::empty({(int64_t)ws_bytes}, tg.options().dtype(torch::kUInt8));
         pybind11::gil_scoped_release nogil;
         rc = trw_walk_edge_list_hip(ed.data_ptr<int64_t>(), n_edges, ix.data_ptr<int64_t>(), n_nodes,
                                     tg.data_ptr<int64_t>(), n_walkers, walker_base, p, q, (int32_t)walk_length,
                                     (int32_t)seed, padding_idx, restart ? 1 : 0, (int32_t)rng_mode,
-                                    walks.data_ptr<int64_t>(), workspace.data_ptr(), ws_bytes,
-                                    (void *)stream.stream());
+                                    walks.data_ptr<int64_t>(), workspace.data_ptr(), ws_bytes, hs);
     }
     TORCH_CHECK(rc == TRW_OK, "torch_rw walk_edge_list failed (", rc, "): ", trw_last_error());
     finish_status(workspace, (void *)stream.stream(), check_mode, "walk_edge_list");
@@ -701,7 +729,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
         std::lock_guard<std::mutex> lock(g_cache_mu);
         std::vector<std::tuple<int64_t, int64_t, int64_t, int64_t, int64_t>> out;
         for (const auto &e : g_cache)
-            out.emplace_back(e->rp_numel - 1, e->ci_numel, (int64_t)e->what, (int64_t)e->blob.numel(), e->biased_walks);
+            out.emplace_back(e->kind == 1 ? e->ci_numel / 2 : e->rp_numel - 1, e->kind == 1 ? e->rp_numel / 2 : e->ci_numel,
+                             (int64_t)e->what, (int64_t)e->blob.numel(), e->biased_walks);
         return out;
     });
     m.attr("PREP_UNIFORM") = (int64_t)TRW_PREP_UNIFORM;

@@ -344,7 +344,8 @@ int resolve_triples_mode(int32_t rng_mode, int64_t n_walkers, int64_t walker_bas
 }  // namespace
 
 namespace {
-struct EdgeListPlan {
+// The prepared edge list (cf. PrepLayout): shadow, edge table, 64-byte entries -- a function of (sizes, padding id, what).
+struct EdgeListLayout {
     bool narrow = false;
     bool hash = false;
     uint32_t hash_mask = 0;
@@ -352,48 +353,59 @@ struct EdgeListPlan {
     size_t off_tail32 = 0, off_ix32 = 0, off_table = 0, off_ent = 0, total = 0;
 };
 
-EdgeListPlan make_elist_plan(int64_t n_edges, int64_t n_nodes, int64_t n_walkers, int32_t L, int64_t padding_idx,
-                             int32_t rng_mode, bool uniform)
+bool elist_fits_narrow(int64_t n_edges, int64_t n_nodes, int64_t padding_idx)
 {
-    EdgeListPlan pl;
+    return n_nodes < ((int64_t)1 << 31) && n_edges < ((int64_t)1 << 32) - 64 && padding_idx >= 0 &&
+           padding_idx < ((int64_t)1 << 31) && env_long("TRW_FORCE_WIDE", 0, 1, 0) == 0;
+}
+
+EdgeListLayout make_elist_layout(int64_t n_edges, int64_t n_nodes, int64_t padding_idx, int32_t what)
+{
+    EdgeListLayout pl;
     size_t off = kStatusBytes;
-    const bool fits = n_nodes < ((int64_t)1 << 31) && n_edges < ((int64_t)1 << 32) - 64 && padding_idx >= 0 &&
-                      padding_idx < ((int64_t)1 << 31) && env_long("TRW_FORCE_WIDE", 0, 1, 0) == 0;
-    // (L < 2^22: elist_walk_kernel addresses a wave's 64 rows with a 32-bit byte offset)
-    // The serial replay of a biased walk wants the shadow too: the edge table is built from it.
-    pl.narrow = fits && (rng_mode != TRW_RNG_GLIBC || !uniform) && n_walkers > 0 && L >= 1 && L < (1 << 22);
+    pl.narrow = what >= 0 && elist_fits_narrow(n_edges, n_nodes, padding_idx);
     if (pl.narrow) {
         pl.off_tail32 = off;
         off += align_up((size_t)n_edges * 4 + 64, 256);
         pl.off_ix32 = off;
         off += align_up((size_t)n_nodes * 8 + 64, 256);
-        if (!uniform) {
-            // Build the edge table unless the batch is tiny next to the graph: without it is_neighbor is the
-            // reference's linear scan of an unsorted edge range (hubs: on R-MAT 1M/10M, 80 steps, 16 walkers
-            // took 168 ms that way, 256 walkers 500 ms, 1024 walkers 635 ms; 5.6 ms with the table, which costs
-            // ~0.15 ns per edge), so the bar is far lower than the CSR walk's, whose fallback is a bisection.
-            uint64_t cap = 1024;
-            while (cap < 3 * (uint64_t)n_edges) cap <<= 1;
-            const long forced = env_long("TRW_HASH", 0, 1, -1);
-            const bool worth = (__int128)n_walkers * L * 65536 >= (__int128)n_edges;
-            if (cap <= ((uint64_t)1 << 31) && (forced == 1 || (forced == -1 && worth))) {
-                pl.hash = true;
-                pl.hash_mask = (uint32_t)(cap - 1);
-                pl.off_table = off;
-                off += (size_t)cap * 16;
-                // the entries cost a pass with about 10 table probes per edge: from nnz/4 steps on (TRW_ELPOOL=0/1 forces)
-                const long pforced = env_long("TRW_ELPOOL", 0, 1, -1);
-                const bool pworth = (__int128)n_walkers * L * 4 >= (__int128)n_edges && n_walkers < ((int64_t)1 << 32);
-                if (rng_mode != TRW_RNG_GLIBC && (pforced == 1 || (pforced == -1 && pworth))) {
-                    pl.ent = true;
-                    pl.off_ent = off;
-                    off += align_up((size_t)n_edges * 64 + 64, 256);
-                }
+        uint64_t cap = 1024;
+        while (cap < 3 * (uint64_t)n_edges) cap <<= 1;
+        if ((what & (TRW_ELPREP_TABLE | TRW_ELPREP_ENTRIES)) && cap <= ((uint64_t)1 << 31)) {
+            pl.hash = true;
+            pl.hash_mask = (uint32_t)(cap - 1);
+            pl.off_table = off;
+            off += (size_t)cap * 16;
+            if (what & TRW_ELPREP_ENTRIES) {
+                pl.ent = true;
+                pl.off_ent = off;
+                off += align_up((size_t)n_edges * 64 + 64, 256);
             }
         }
     }
     pl.total = off;
     return pl;
+}
+
+// What one call of this shape is worth preparing (`mode`: resolved, or the caller's for the upper bound).
+int32_t elist_plan_what(int64_t n_edges, int64_t n_nodes, int64_t n_walkers, int32_t L, int64_t padding_idx,
+                        int32_t mode, bool uniform)
+{
+    // (L < 2^22: elist_walk_kernel addresses a wave's 64 rows with a 32-bit byte offset)
+    if (n_walkers <= 0 || L < 1 || L >= (1 << 22) || !elist_fits_narrow(n_edges, n_nodes, padding_idx)) return TRW_PREP_NOTHING;
+    if (uniform) return mode == TRW_RNG_GLIBC ? TRW_PREP_NOTHING : 0;
+    // Build the edge table unless the batch is tiny next to the graph: without it is_neighbor is the reference's
+    // linear scan of an unsorted edge range (hubs: on R-MAT 1M/10M, 80 steps, 16 walkers took 168 ms that way, 256
+    // walkers 500 ms; 5.6 ms with the table, which costs ~0.15 ns per edge).  The serial replay wants it too.
+    const long forced = env_long("TRW_HASH", 0, 1, -1);
+    const bool worth = (__int128)n_walkers * L * 65536 >= (__int128)n_edges;
+    if (!(forced == 1 || (forced == -1 && worth))) return 0;
+    // the entries cost a pass with about 20 table probes per edge (13 ms on R-MAT 1M/10M): from n_edges/4 steps on
+    const long pforced = env_long("TRW_ELPOOL", 0, 1, -1);
+    const bool pworth = (__int128)n_walkers * L * 4 >= (__int128)n_edges;
+    if (mode != TRW_RNG_GLIBC && n_walkers < ((int64_t)1 << 32) && (pforced == 1 || (pforced == -1 && pworth)))
+        return TRW_ELPREP_TABLE | TRW_ELPREP_ENTRIES;
+    return TRW_ELPREP_TABLE;
 }
 
 int resolve_elist_mode(int32_t rng_mode, bool uniform, int64_t n_walkers, int64_t walker_base, int32_t L)
@@ -847,18 +859,68 @@ int trw_walk_triples_hip(const int64_t *triples, int64_t n_triples, const int64_
 
 // ---- edge-list walk, reference csrc/cpu/rw_cpu_edge_list.cpp -------------------------------------
 
-size_t trw_walk_edge_list_workspace_bytes(int64_t n_edges, int64_t n_nodes, int64_t n_walkers, int32_t walk_length,
-                                          int64_t padding_idx, int32_t rng_mode)
+int32_t trw_prepare_edge_list_plan(int64_t n_edges, int64_t n_nodes, int64_t n_walkers, int32_t walk_length, double p,
+                                   double q, int64_t padding_idx, int32_t rng_mode)
 {
-    if (n_edges < 0 || n_nodes < 0) return kStatusBytes;
-    // sized for the biased walk (the larger of the two shapes): the query does not know p and q
-    return make_elist_plan(n_edges, n_nodes, n_walkers, walk_length, padding_idx, rng_mode, false).total;
+    if (n_edges < 0 || n_nodes < 0) return TRW_PREP_NOTHING;
+    const bool uniform = (p == 1.0 && q == 1.0);
+    const int mode = resolve_elist_mode(rng_mode, uniform, n_walkers, 0, walk_length);
+    return elist_plan_what(n_edges, n_nodes, n_walkers, walk_length, padding_idx, mode < 0 ? TRW_RNG_AUTO : mode, uniform);
 }
 
-int trw_walk_edge_list_hip(const int64_t *edges, int64_t n_edges, const int64_t *node_edge_index, int64_t n_nodes,
-                           const int64_t *targets, int64_t n_walkers, int64_t walker_base, double p, double q,
-                           int32_t walk_length, int32_t seed, int64_t padding_idx, int32_t restart, int32_t rng_mode,
-                           int64_t *out, void *workspace, size_t workspace_bytes, void *hip_stream)
+size_t trw_prepare_edge_list_bytes(int64_t n_edges, int64_t n_nodes, int64_t padding_idx, int32_t what)
+{
+    if (n_edges < 0 || n_nodes < 0) return kStatusBytes;
+    return make_elist_layout(n_edges, n_nodes, padding_idx, what).total;
+}
+
+int trw_prepare_edge_list_hip(const int64_t *edges, int64_t n_edges, const int64_t *node_edge_index, int64_t n_nodes,
+                              int64_t padding_idx, int32_t what, void *prepared, size_t prepared_bytes, void *hip_stream)
+{
+    t_last_error.clear();
+    if (n_edges < 0 || n_nodes < 0) return fail(TRW_E_ARG, "negative size argument");
+    if (n_edges > 0 && !edges) return fail(TRW_E_ARG, "edge_list_indexed is null");
+    if (n_nodes > 0 && !node_edge_index) return fail(TRW_E_ARG, "node_edge_index is null");
+    if (!prepared || ((uintptr_t)prepared & 15u) != 0) return fail(TRW_E_WORKSPACE, "prepared buffer missing or not 16-byte aligned");
+    const EdgeListLayout pl = make_elist_layout(n_edges, n_nodes, padding_idx, what);
+    if (prepared_bytes < pl.total) return fail(TRW_E_WORKSPACE, "prepared buffer too small for this edge list");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    char *ws = (char *)prepared;
+    int64_t *header = (int64_t *)ws;
+    if (g_prof.on && (g_prof.prep[0] || hipEventCreate(&g_prof.prep[0]) == hipSuccess))
+        (void)hipEventRecord(g_prof.prep[0], stream);
+    device_fill(header, 0u, kStatusBytes, stream);
+    if (pl.narrow) {
+        elist_shadow_kernel<<<stream_grid(n_edges > n_nodes ? n_edges : n_nodes), kBlock, 0, stream>>>(
+            edges, n_edges, node_edge_index, n_nodes, padding_idx, (uint32_t *)(ws + pl.off_tail32),
+            (u32x2_a8 *)(ws + pl.off_ix32), header);
+        if (pl.hash) {
+            uint32_t *el_table = (uint32_t *)(ws + pl.off_table);
+            device_fill(el_table, 0xFFFFFFFFu, ((size_t)pl.hash_mask + 1) * 16, stream);
+            elist_table_build_kernel<<<stream_grid(n_edges), kBlock, 0, stream>>>(
+                edges, n_edges, n_nodes, (const uint32_t *)(ws + pl.off_tail32),
+                (const u32x2_a8 *)(ws + pl.off_ix32), el_table, pl.hash_mask);
+            if (pl.ent)
+                elist_ext_kernel<<<stream_grid(n_edges), kBlock, 0, stream>>>(
+                    edges, n_edges, n_nodes, (uint32_t)padding_idx, (const uint32_t *)(ws + pl.off_tail32),
+                    (const u32x2_a8 *)(ws + pl.off_ix32), el_table, pl.hash_mask, (u32x4_a16 *)(ws + pl.off_ent));
+        }
+    }
+    if (g_prof.on && g_prof.prep[0] && (g_prof.prep[1] || hipEventCreate(&g_prof.prep[1]) == hipSuccess)) {
+        (void)hipEventRecord(g_prof.prep[1], stream);
+        g_prof.prep_valid = true;
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "kernel launch");
+    return TRW_OK;
+}
+
+static int walk_edge_list_prepared(const void *prepared, size_t prepared_bytes, int32_t what, const int64_t *edges,
+                                   int64_t n_edges, const int64_t *node_edge_index, int64_t n_nodes,
+                                   const int64_t *targets, int64_t n_walkers, int64_t walker_base, double p, double q,
+                                   int32_t walk_length, int32_t seed, int64_t padding_idx, int32_t restart,
+                                   int32_t rng_mode, int64_t *out, void *workspace, size_t workspace_bytes,
+                                   void *hip_stream, bool mark_prepare)
 {
     t_last_error.clear();
     if (n_edges < 0 || n_nodes < 0 || n_walkers < 0 || walker_base < 0)
@@ -877,16 +939,18 @@ int trw_walk_edge_list_hip(const int64_t *edges, int64_t n_edges, const int64_t 
     if (mode < 0) return fail(TRW_E_RNG_MODE, "unknown rng_mode");
     if (mode == TRW_RNG_GLIBC && walker_base != 0)
         return fail(TRW_E_RNG_MODE, "TRW_RNG_GLIBC edge-list walks replay one serial stream: walker_base must be 0");
+    const EdgeListLayout pl = make_elist_layout(n_edges, n_nodes, padding_idx, what);
+    if (!prepared || prepared_bytes < pl.total || ((uintptr_t)prepared & 15u) != 0)
+        return fail(TRW_E_WORKSPACE, "prepared edge list missing, misaligned or smaller than its layout");
+    if (walk_length >= (1 << 22) && pl.narrow) return fail(TRW_E_ARG, "walk_length too large for the uint32 kernels");
 
     hipStream_t stream = (hipStream_t)hip_stream;
     int64_t *status = (int64_t *)workspace;
     hipError_t e = hipSuccess;
-    device_fill(status, 0u, kStatusBytes, stream);
+    if (mark_prepare) prof_mark(0, stream);
+    status_seed_kernel<<<1, 64, 0, stream>>>((const int64_t *)prepared, status);
     if (n_walkers == 0) return TRW_OK;
-
-    const EdgeListPlan pl = make_elist_plan(n_edges, n_nodes, n_walkers, walk_length, padding_idx, mode, uniform);
-    if (workspace_bytes < pl.total) return fail(TRW_E_WORKSPACE, "workspace too small for this call shape");
-    char *ws = (char *)workspace;
+    const char *ws = (const char *)prepared;
     const unsigned walker_grid = (unsigned)((n_walkers + kBlock - 1) / kBlock);
 
     BiasedParams bp = {0, 0, 0, 0, 0};
@@ -902,25 +966,8 @@ int trw_walk_edge_list_hip(const int64_t *edges, int64_t n_edges, const int64_t 
     EdgeListView<false> wide = {edges, node_edge_index, nullptr, nullptr, n_edges, n_nodes};
     EdgeListView<true> narrow = {nullptr, nullptr, (const uint32_t *)(ws + pl.off_tail32),
                                  (const u32x2_a8 *)(ws + pl.off_ix32), n_edges, n_nodes};
+    const uint32_t *el_table = pl.hash ? (const uint32_t *)(ws + pl.off_table) : nullptr;
 
-    prof_mark(0, stream);
-    uint32_t *el_table = nullptr;
-    if (pl.narrow) {
-        elist_shadow_kernel<<<stream_grid(n_edges > n_nodes ? n_edges : n_nodes), kBlock, 0, stream>>>(
-            edges, n_edges, node_edge_index, n_nodes, padding_idx, (uint32_t *)(ws + pl.off_tail32),
-            (u32x2_a8 *)(ws + pl.off_ix32), status);
-        if (pl.hash) {
-            el_table = (uint32_t *)(ws + pl.off_table);
-            device_fill(el_table, 0xFFFFFFFFu, ((size_t)pl.hash_mask + 1) * 16, stream);
-            elist_table_build_kernel<<<stream_grid(n_edges), kBlock, 0, stream>>>(
-                edges, n_edges, n_nodes, (const uint32_t *)(ws + pl.off_tail32),
-                (const u32x2_a8 *)(ws + pl.off_ix32), el_table, pl.hash_mask);
-            if (pl.ent && mode == TRW_RNG_WALKER)
-                elist_ext_kernel<<<stream_grid(n_edges), kBlock, 0, stream>>>(
-                    edges, n_edges, n_nodes, (uint32_t)padding_idx, (const uint32_t *)(ws + pl.off_tail32),
-                    (const u32x2_a8 *)(ws + pl.off_ix32), el_table, pl.hash_mask, (u32x4_a16 *)(ws + pl.off_ent));
-        }
-    }
     prof_mark(1, stream);
     if (mode == TRW_RNG_GLIBC) {
         SeedWindow sw;
@@ -932,8 +979,8 @@ int trw_walk_edge_list_hip(const int64_t *edges, int64_t n_edges, const int64_t 
             elist_walk_kernel<false, true><<<walker_grid, kBlock, 0, stream>>>(
                 narrow, targets, n_walkers, walker_base, walk_length, padding_idx, restart, (uint32_t)seed, bp,
                 el_table, pl.hash_mask, out, status);
-        else if (pl.ent) {
-            // walker pool over the prepared entries: 2 workgroups per CU (a wave's pool: 96 walkers x 26 words + windows)
+        else if (pl.ent && n_walkers < ((int64_t)1 << 32) && env_long("TRW_ELPOOL", 0, 1, 1) == 1) {
+            // walker pool over the prepared entries: 2 workgroups per CU (a wave's pool: 128 walkers x 26 words + windows)
             int64_t pblocks = (n_walkers + (int64_t)kPoolWaves * kElSlots - 1) / ((int64_t)kPoolWaves * kElSlots);
             const int64_t president = (int64_t)device_cu_count() * env_long("TRW_ELPOOL_BLOCKS", 1, 4, 2);
             if (pblocks > president) pblocks = president;
@@ -962,10 +1009,65 @@ int trw_walk_edge_list_hip(const int64_t *edges, int64_t n_edges, const int64_t 
                 0u, out, status);
     }
     prof_mark(2, stream);
-    prof_mark(3, stream);  // elist_walk_kernel writes the rows itself: nothing to finish
+    prof_mark(3, stream);  // the walk kernels write the rows themselves: nothing to finish
     e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "kernel launch");
     return TRW_OK;
+}
+
+int trw_walk_edge_list_prepared_hip(const void *prepared, size_t prepared_bytes, int32_t what, const int64_t *edges,
+                                    int64_t n_edges, const int64_t *node_edge_index, int64_t n_nodes,
+                                    const int64_t *targets, int64_t n_walkers, int64_t walker_base, double p, double q,
+                                    int32_t walk_length, int32_t seed, int64_t padding_idx, int32_t restart,
+                                    int32_t rng_mode, int64_t *out, void *workspace, size_t workspace_bytes,
+                                    void *hip_stream)
+{
+    return walk_edge_list_prepared(prepared, prepared_bytes, what, edges, n_edges, node_edge_index, n_nodes, targets,
+                                   n_walkers, walker_base, p, q, walk_length, seed, padding_idx, restart, rng_mode, out,
+                                   workspace, workspace_bytes, hip_stream, true);
+}
+
+// One-shot form: prepares what this call shape is worth inside the workspace, then walks.
+size_t trw_walk_edge_list_workspace_bytes(int64_t n_edges, int64_t n_nodes, int64_t n_walkers, int32_t walk_length,
+                                          int64_t padding_idx, int32_t rng_mode)
+{
+    if (n_edges < 0 || n_nodes < 0) return kStatusBytes;
+    // sized for the biased walk (the larger of the two shapes): the query does not know p and q
+    const int32_t what = elist_plan_what(n_edges, n_nodes, n_walkers, walk_length, padding_idx, rng_mode, false);
+    return (size_t)kStatusBytes + make_elist_layout(n_edges, n_nodes, padding_idx, what).total;
+}
+
+int trw_walk_edge_list_hip(const int64_t *edges, int64_t n_edges, const int64_t *node_edge_index, int64_t n_nodes,
+                           const int64_t *targets, int64_t n_walkers, int64_t walker_base, double p, double q,
+                           int32_t walk_length, int32_t seed, int64_t padding_idx, int32_t restart, int32_t rng_mode,
+                           int64_t *out, void *workspace, size_t workspace_bytes, void *hip_stream)
+{
+    t_last_error.clear();
+    if (n_edges < 0 || n_nodes < 0 || n_walkers < 0 || walker_base < 0)
+        return fail(TRW_E_ARG, "negative size argument");
+    if (walk_length < 1) return fail(TRW_E_ARG, "walk_length must be >= 1");
+    if (!workspace || workspace_bytes < (size_t)kStatusBytes)
+        return fail(TRW_E_WORKSPACE, "workspace missing or smaller than the status block");
+    if (((uintptr_t)workspace & 15u) != 0) return fail(TRW_E_WORKSPACE, "workspace must be 16-byte aligned");
+    const bool uniform = (p == 1.0 && q == 1.0);
+    const int mode = resolve_elist_mode(rng_mode, uniform, n_walkers, walker_base, walk_length);
+    if (mode < 0) return fail(TRW_E_RNG_MODE, "unknown rng_mode");
+    if (n_walkers == 0) {
+        device_fill(workspace, 0u, kStatusBytes, (hipStream_t)hip_stream);
+        return TRW_OK;
+    }
+    const int32_t what = elist_plan_what(n_edges, n_nodes, n_walkers, walk_length, padding_idx, mode, uniform);
+    const size_t prep_bytes = make_elist_layout(n_edges, n_nodes, padding_idx, what).total;
+    if (workspace_bytes < (size_t)kStatusBytes + prep_bytes)
+        return fail(TRW_E_WORKSPACE, "workspace too small for this call shape");
+    void *prepared = (char *)workspace + kStatusBytes;
+    prof_mark(0, (hipStream_t)hip_stream);
+    if (int rc = trw_prepare_edge_list_hip(edges, n_edges, node_edge_index, n_nodes, padding_idx, what, prepared,
+                                           prep_bytes, hip_stream))
+        return rc;
+    return walk_edge_list_prepared(prepared, prep_bytes, what, edges, n_edges, node_edge_index, n_nodes, targets,
+                                   n_walkers, walker_base, p, q, walk_length, seed, padding_idx, restart, mode, out,
+                                   workspace, kStatusBytes, hip_stream, false);
 }
 
 // ---- window builders, reference csrc/cpu/windows_cpu.cpp ------------------------------------------

@@ -474,7 +474,7 @@ elist_ext_kernel(const int64_t *__restrict__ edges, int64_t n_edges, int64_t n_n
 }
 
 #ifndef TRW_ELPOOL_SLOTS
-#define TRW_ELPOOL_SLOTS 96
+#define TRW_ELPOOL_SLOTS 128
 #endif
 constexpr int kElSlots = TRW_ELPOOL_SLOTS;  // walkers resident per wave
 constexpr int kElWin = 12;                  // draws a burst can see: the slot's current Philox block + the next two
