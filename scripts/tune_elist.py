@@ -14,6 +14,7 @@ ap.add_argument("--runs", type=int, default=4)
 ap.add_argument("--L", type=int, default=80)
 ap.add_argument("--env", nargs="*", default=[])
 ap.add_argument("--tag", default="")
+ap.add_argument("--count", action="store_true")
 args = ap.parse_args()
 for kv in args.env:
     k, v = kv.split("=", 1)
@@ -54,6 +55,8 @@ L.trw_profile_enable(1)
 pre, wk = [], []
 chk = None
 for r in range(args.runs):
+    if args.count and r == args.runs - 1:
+        L.trw_profile_enable(3)
     rc = L.trw_walk_edge_list_hip(edges.data_ptr(), E_, index.data_ptr(), n, tg.data_ptr(), n, 0, 0.25, 4.0, args.L, 10, n, 1, 2,
                                   out.data_ptr(), ws.data_ptr(), nb, stream)
     assert rc == 0, L.trw_last_error()
@@ -66,5 +69,12 @@ for r in range(args.runs):
     chk = s
 st = (i64 * 4)()
 L.trw_walk_status(ws.data_ptr(), stream, st)
+if args.count:
+    raw = ws[:256].view(torch.int64).cpu().tolist()
+    steps = n * args.L
+    names = ["RANGE", "ENTRY", "TEST", "MEMBER", "FIXNB", "PEEK", "NOENTRY"]
+    print("   per step: trials %.2f fetch %.3f tests %.3f probes %.3f | gathers consumed by kind: %s | wave iterations %.3e" % (
+        raw[4] / steps, raw[5] / steps, raw[6] / steps, raw[7] / steps,
+        " ".join("%s %.3f" % (nm, raw[12 + k] / steps) for k, nm in enumerate(names)), raw[19]))
 print("%-40s prepare %.2f  walk %s  best %.2f  family %d status %d checksum %x" % (
     args.tag or os.path.basename(args.lib), min(pre), " ".join("%.2f" % t for t in wk), min(wk), st[3], st[0], chk & 0xffffffff), flush=True)

@@ -350,7 +350,7 @@ struct EdgeListLayout {
     bool hash = false;
     uint32_t hash_mask = 0;
     bool ent = false;  // 64-byte per-edge entries: the walker-pool kernel
-    size_t off_tail32 = 0, off_ix32 = 0, off_table = 0, off_ent = 0, total = 0;
+    size_t off_tail32 = 0, off_ix32 = 0, off_table = 0, off_ent = 0, off_nd = 0, total = 0;
 };
 
 bool elist_fits_narrow(int64_t n_edges, int64_t n_nodes, int64_t padding_idx)
@@ -380,6 +380,8 @@ EdgeListLayout make_elist_layout(int64_t n_edges, int64_t n_nodes, int64_t paddi
                 pl.ent = true;
                 pl.off_ent = off;
                 off += align_up((size_t)n_edges * 64 + 64, 256);
+                pl.off_nd = off;
+                off += align_up((size_t)n_nodes * 16 + 64, 256);
             }
         }
     }
@@ -900,10 +902,14 @@ int trw_prepare_edge_list_hip(const int64_t *edges, int64_t n_edges, const int64
             elist_table_build_kernel<<<stream_grid(n_edges), kBlock, 0, stream>>>(
                 edges, n_edges, n_nodes, (const uint32_t *)(ws + pl.off_tail32),
                 (const u32x2_a8 *)(ws + pl.off_ix32), el_table, pl.hash_mask);
-            if (pl.ent)
+            if (pl.ent) {
                 elist_ext_kernel<<<stream_grid(n_edges), kBlock, 0, stream>>>(
                     edges, n_edges, n_nodes, (uint32_t)padding_idx, (const uint32_t *)(ws + pl.off_tail32),
                     (const u32x2_a8 *)(ws + pl.off_ix32), el_table, pl.hash_mask, (u32x4_a16 *)(ws + pl.off_ent));
+                elist_node_kernel<<<stream_grid(n_nodes), kBlock, 0, stream>>>(
+                    n_nodes, (uint32_t)padding_idx, (const uint32_t *)(ws + pl.off_tail32),
+                    (const u32x2_a8 *)(ws + pl.off_ix32), el_table, pl.hash_mask, (u32x4_a16 *)(ws + pl.off_nd));
+            }
         }
     }
     if (g_prof.on && g_prof.prep[0] && (g_prof.prep[1] || hipEventCreate(&g_prof.prep[1]) == hipSuccess)) {
@@ -986,12 +992,12 @@ static int walk_edge_list_prepared(const void *prepared, size_t prepared_bytes, 
             if (pblocks > president) pblocks = president;
             if (g_prof.count)
                 elist_pool_kernel<true><<<(unsigned)pblocks, kBlock, 0, stream>>>(
-                    (const u32x2_a8 *)(ws + pl.off_ix32), (const u32x4_a16 *)(ws + pl.off_ent), el_table, pl.hash_mask,
+                    (const u32x4_a16 *)(ws + pl.off_nd), (const u32x4_a16 *)(ws + pl.off_ent), el_table, pl.hash_mask,
                     targets, n_nodes, n_walkers, walker_base, walk_length, (uint32_t)padding_idx, restart, (uint32_t)seed,
                     bp, out, status);
             else
                 elist_pool_kernel<false><<<(unsigned)pblocks, kBlock, 0, stream>>>(
-                    (const u32x2_a8 *)(ws + pl.off_ix32), (const u32x4_a16 *)(ws + pl.off_ent), el_table, pl.hash_mask,
+                    (const u32x4_a16 *)(ws + pl.off_nd), (const u32x4_a16 *)(ws + pl.off_ent), el_table, pl.hash_mask,
                     targets, n_nodes, n_walkers, walker_base, walk_length, (uint32_t)padding_idx, restart, (uint32_t)seed,
                     bp, out, status);
         } else

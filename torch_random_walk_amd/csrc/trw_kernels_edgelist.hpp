@@ -410,7 +410,39 @@ elist_glibc_seq_kernel(EdgeListView<false> g, const int64_t *__restrict__ target
 // four times, built from the table's position masks by walking u's edges (kElFilter: clear = certainly not,
 // set = load the candidate and see); a range that holds the padding id as a tail is all "see" (kElHasPad).
 constexpr uint32_t kElFilter = 1u, kElHasPad = 2u;
-constexpr uint32_t kElFilterWalk = 256u;  // longest u range walked for a filter mask; all-ones beyond
+#ifndef TRW_EL_FILTER_WALK
+#define TRW_EL_FILTER_WALK 256
+#endif
+constexpr uint32_t kElFilterWalk = TRW_EL_FILTER_WALK;  // longest u range walked for a filter mask; all-ones beyond
+
+// Per node, 16 bytes: {first, last, flags, only tail}: what a walker needs when it reaches a node WITHOUT an entry
+// (from the padding id, by restart): its edge range, whether that range holds the padding id as a tail
+// (kElHasPad), and the tail of its single edge when it has exactly one.
+__global__ void __launch_bounds__(kBlock)
+elist_node_kernel(int64_t n_nodes, uint32_t pad, const uint32_t *__restrict__ tail32,
+                  const u32x2_a8 *__restrict__ ix32, const uint32_t *__restrict__ table, uint32_t mask,
+                  u32x4_a16 *__restrict__ nd)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n_nodes; v += stride) {
+        const u32x2_a8 ix = ix32[v];
+        uint32_t flags = 0, only = 0;
+        if (ix.x != kNoEdge) {
+            const uint32_t cnt = ix.y - ix.x + 1u;
+            if (cnt == 1u) only = tail32[ix.x];
+            if (cnt <= 128u) {
+                for (uint32_t j = 0; j < cnt; ++j)
+                    if (tail32[ix.x + j] == pad) flags |= kElHasPad;
+            } else {
+                uint32_t pm;
+                bool in_range;
+                if (elist_table_find(table, mask, (uint32_t)v, pad, pm, in_range)) flags |= kElHasPad;
+            }
+        }
+        u32x4_a16 o = {ix.x, ix.y, flags, only};
+        nd[v] = o;
+    }
+}
 
 __global__ void __launch_bounds__(kBlock)
 elist_ext_kernel(const int64_t *__restrict__ edges, int64_t n_edges, int64_t n_nodes, uint32_t pad,
@@ -491,10 +523,11 @@ enum : int {
     EF_COUNT
 };
 constexpr uint32_t kEfFixed = 4u;
+constexpr uint32_t kEfTNoNb = 8u;  // flag bit 3: t has no edge that is_neighbor would look at (nothing is its neighbour)
 
 template <bool kCount>
 __global__ void __launch_bounds__(kBlock)
-elist_pool_kernel(const u32x2_a8 *__restrict__ ix32, const u32x4_a16 *__restrict__ ent,
+elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict__ ent,
                   const uint32_t *__restrict__ table, uint32_t mask, const int64_t *__restrict__ targets,
                   int64_t n_nodes, int64_t n_walkers, int64_t walker_base, int32_t L, uint32_t pad, int32_t restart,
                   uint32_t seed, BiasedParams bp, int64_t *__restrict__ out, int64_t *__restrict__ status)
@@ -542,21 +575,27 @@ elist_pool_kernel(const u32x2_a8 *__restrict__ ix32, const u32x4_a16 *__restrict
         if (prev == pad) {  // the candidate is the jump node, no draw for it (rw_cpu_edge_list.cpp:14-16)
             P[EF_X][slot] = jump;
             P[EF_AT][slot] = kNoEdge;
+            const uint32_t tn = P[EF_FLAGS][slot] & kEfTNoNb;
             if (jump == pad) {
                 P[EF_AUX][slot] = bp.t0;
-                set_kind(slot, kEfFixed, 0u);
+                set_kind(slot, kEfFixed | tn, 0u);
+                return 0;
+            }
+            if (tn) {  // t is a dead end (the usual way onto the padding id): the jump node is no neighbour of it
+                P[EF_AUX][slot] = fixed_threshold(jump, P[EF_T][slot], false);
+                set_kind(slot, kEfFixed | tn, 0u);
                 return 0;
             }
             set_kind(slot, kEfFixed, EK_FIXNB);  // is the jump node a neighbour of t?
             return 1;
         }
-        set_kind(slot, 0u, EK_RANGE);  // a real node: its edge range first
+        set_kind(slot, P[EF_FLAGS][slot] & kEfTNoNb, EK_RANGE);  // a real node: its edge range first
         return 1;
     };
     // ... with its range and masks in the slot (FIRST, CNT, masks, flag bits 0..1): fixed or multi-candidate step
     auto classify = [&](uint32_t slot, uint32_t only_tail, bool have_only) -> int {
         const uint32_t cnt = P[EF_CNT][slot], t = P[EF_T][slot], jump = P[EF_JUMP][slot];
-        const uint32_t fbits = P[EF_FLAGS][slot] & 3u;
+        const uint32_t fbits = P[EF_FLAGS][slot] & (3u | kEfTNoNb);
         if (cnt == 0u) {  // dead end: the candidate is the padding id
             P[EF_X][slot] = (pad == t) ? pad : jump;
             P[EF_AT][slot] = kNoEdge;
@@ -579,7 +618,12 @@ elist_pool_kernel(const u32x2_a8 *__restrict__ ix32, const u32x4_a16 *__restrict
             }
             P[EF_X][slot] = only_tail;
             P[EF_AT][slot] = P[EF_FIRST][slot];
-            if (fbits & kElFilter) {  // (cannot happen for an entry-described range of one edge, kept for the bare path)
+            if (fbits & kElFilter) {  // masks say nothing about this single edge (bare arrival): ask the table
+                if (fbits & kEfTNoNb) {
+                    P[EF_AUX][slot] = fixed_threshold(only_tail, t, false);
+                    set_kind(slot, fbits | kEfFixed, 0u);
+                    return 0;
+                }
                 set_kind(slot, fbits | kEfFixed, EK_FIXNB);
                 return 1;
             }
@@ -601,7 +645,11 @@ elist_pool_kernel(const u32x2_a8 *__restrict__ ix32, const u32x4_a16 *__restrict
         row_of(slot)[s] = (int64_t)node;
         ++s;
         P[EF_S][slot] = (uint32_t)s;
-        P[EF_T][slot] = P[EF_PREV][slot];
+        const uint32_t left = P[EF_PREV][slot];
+        // the node being left becomes t: does is_neighbor(., t) have anything to look at?  (edges [first, last))
+        const bool tnonb = left == pad ? pad >= (uint32_t)n_nodes : P[EF_CNT][slot] <= 1u;
+        P[EF_FLAGS][slot] = tnonb ? kEfTNoNb : 0u;
+        P[EF_T][slot] = left;
         P[EF_PREV][slot] = node;
         P[EF_REJ][slot] = 0u;
         if (s > L) {
@@ -617,14 +665,19 @@ elist_pool_kernel(const u32x2_a8 *__restrict__ ix32, const u32x4_a16 *__restrict
         row_of(slot)[s] = (int64_t)x;
         ++s;
         P[EF_S][slot] = (uint32_t)s;
-        P[EF_T][slot] = P[EF_PREV][slot];
+        const uint32_t left = P[EF_PREV][slot];
+        const bool tnonb = left == pad ? pad >= (uint32_t)n_nodes : P[EF_CNT][slot] <= 1u;
+        P[EF_T][slot] = left;
         P[EF_PREV][slot] = x;
         P[EF_REJ][slot] = 0u;
         if (s > L) {
             to_free = true;
             return -1;
         }
-        if (x == pad) return arrive_bare(slot);
+        if (x == pad) {
+            P[EF_FLAGS][slot] = tnonb ? kEfTNoNb : 0u;
+            return arrive_bare(slot);
+        }
         P[EF_FIRST][slot] = e0.y;
         P[EF_CNT][slot] = e0.z;
         P[EF_NB0][slot] = e1.x;
@@ -635,7 +688,7 @@ elist_pool_kernel(const u32x2_a8 *__restrict__ ix32, const u32x4_a16 *__restrict
         P[EF_TM1][slot] = e2.y;
         P[EF_TM2][slot] = e2.z;
         P[EF_TM3][slot] = e2.w;
-        P[EF_FLAGS][slot] = e0.w & 3u;
+        P[EF_FLAGS][slot] = (e0.w & 3u) | (tnonb ? kEfTNoNb : 0u);
         return classify(slot, e3.x, true);
     };
 
@@ -643,13 +696,21 @@ elist_pool_kernel(const u32x2_a8 *__restrict__ ix32, const u32x4_a16 *__restrict
         // ================= adopt =================
         {
             bool to_trial = false, to_issue = false, to_free = false;
+            if (kCount) {  // how many gathers of each kind were consumed (status[12 + kind]) and in how many passes ([19])
+                for (uint32_t k = 0; k < 7u; ++k) {
+                    const unsigned long long b = __ballot(hold && hkind == k);
+                    if (b && lane == 0) atomicAdd((unsigned long long *)&status[12 + k], (unsigned long long)__popcll(b));
+                }
+                if (lane == 0) atomicAdd((unsigned long long *)&status[19], 1ull);
+            }
             if (hold) {
                 const uint32_t slot = hs;
                 int where = -1;  // 0 trial queue, 1 issue queue, -1 neither (freed)
                 const uint32_t flags = P[EF_FLAGS][slot];
-                if (hkind == EK_RANGE) {  // e0.x, e0.y = (first, last) of PREV
+                if (hkind == EK_RANGE) {  // e0 = {first, last, flags, only tail} of PREV
                     const uint32_t first = e0.x, cnt = first == kNoEdge ? 0u : e0.y - e0.x + 1u;
                     if (P[EF_S][slot] == 1u) {  // the first step samples a neighbour of the start node outright (:188)
+                        P[EF_CNT][slot] = cnt;  // (the start node becomes t: step_* looks at this)
                         if (cnt == 0u) {
                             where = step_bare(slot, pad, to_free);
                         } else {
@@ -663,13 +724,19 @@ elist_pool_kernel(const u32x2_a8 *__restrict__ ix32, const u32x4_a16 *__restrict
                             if (kCount) ++n_fetch;
                             where = 1;
                         }
-                    } else {  // a node reached without an entry: no masks -- every candidate is looked at
+                    } else {
+                        // A node reached without an entry: it was jumped to from the padding id, so t IS the padding id.
+                        // When the padding id is no node of the graph nothing is its neighbour and only a tail equal
+                        // to it "is t": a range without such tails has all-zero masks, exactly.  Otherwise every
+                        // candidate is looked at.
+                        const bool plain = P[EF_T][slot] == pad && pad >= (uint32_t)n_nodes && !(e0.z & kElHasPad);
+                        const uint32_t fill = plain ? 0u : 0xFFFFFFFFu;
                         P[EF_FIRST][slot] = first;
                         P[EF_CNT][slot] = cnt;
-                        P[EF_NB0][slot] = P[EF_NB1][slot] = P[EF_NB2][slot] = P[EF_NB3][slot] = 0xFFFFFFFFu;
-                        P[EF_TM0][slot] = P[EF_TM1][slot] = P[EF_TM2][slot] = P[EF_TM3][slot] = 0xFFFFFFFFu;
-                        P[EF_FLAGS][slot] = kElFilter | kElHasPad;
-                        where = classify(slot, 0u, false);
+                        P[EF_NB0][slot] = P[EF_NB1][slot] = P[EF_NB2][slot] = P[EF_NB3][slot] = fill;
+                        P[EF_TM0][slot] = P[EF_TM1][slot] = P[EF_TM2][slot] = P[EF_TM3][slot] = fill;
+                        P[EF_FLAGS][slot] = (plain ? 0u : (kElFilter | kElHasPad)) | (flags & kEfTNoNb);
+                        where = classify(slot, e0.w, true);
                     }
                 } else if (hkind == EK_ENTRY) {
                     where = step_entry(slot, to_free);
@@ -700,7 +767,7 @@ elist_pool_kernel(const u32x2_a8 *__restrict__ ix32, const u32x4_a16 *__restrict
                     else if (x == pad) verdict = ru < bp.t0 ? 2 : 0;
                     else if (ru < bp.lo) verdict = 1;
                     else if (ru >= bp.hi) verdict = 0;
-                    else if (!nb_bit) verdict = band_takes_near ? 0 : 1;
+                    else if (!nb_bit || (flags & kEfTNoNb)) verdict = band_takes_near ? 0 : 1;
                     else verdict = 3;
                     if (verdict == 1) {
                         where = step_entry(slot, to_free);
@@ -835,9 +902,7 @@ elist_pool_kernel(const u32x2_a8 *__restrict__ ix32, const u32x4_a16 *__restrict
                         e3 = *reinterpret_cast<const u32x4_a4 *>(addr + 12);
                     }
                 } else if (kind == EK_RANGE) {
-                    const u32x2_a8 ix = ix32[P[EF_PREV][slot]];
-                    e0.x = ix.x;
-                    e0.y = ix.y;
+                    e0 = *reinterpret_cast<const u32x4_a4 *>(nd + P[EF_PREV][slot]);
                 } else if (kind == EK_MEMBER || kind == EK_FIXNB) {
                     const uint32_t s0 = edge_hash(P[EF_T][slot], P[EF_X][slot]);
                     e0 = *reinterpret_cast<const u32x4_a4 *>(table + 4 * (size_t)((s0 + (flags >> 8)) & mask));
@@ -861,6 +926,7 @@ elist_pool_kernel(const u32x2_a8 *__restrict__ ix32, const u32x4_a16 *__restrict
             const uint32_t tm0 = P[EF_TM0][slot], tm1 = P[EF_TM1][slot], tm2 = P[EF_TM2][slot], tm3 = P[EF_TM3][slot];
             const uint32_t flags = P[EF_FLAGS][slot];
             const bool fixed = (flags & kEfFixed) != 0u, filter = (flags & kElFilter) != 0u, haspad = (flags & kElHasPad) != 0u;
+            const bool tnonb = (flags & kEfTNoNb) != 0u;  // nothing is a neighbour of t: every nb bit reads as clear
             const uint32_t aux = P[EF_AUX][slot];
             uint32_t rejected = P[EF_REJ][slot];
             const uint32_t d0 = P[EF_D][slot];
@@ -903,7 +969,7 @@ elist_pool_kernel(const u32x2_a8 *__restrict__ ix32, const u32x4_a16 *__restrict
                         pos += 2u;
                         const uint32_t idx = fm.mod(rc);
                         const uint32_t k = (idx >> 5) & 3u, sh = idx & 31u;
-                        const bool nbb = ((k == 0u ? nb0 : (k == 1u ? nb1 : (k == 2u ? nb2 : nb3))) >> sh) & 1u;
+                        const bool nbb = !tnonb && (((k == 0u ? nb0 : (k == 1u ? nb1 : (k == 2u ? nb2 : nb3))) >> sh) & 1u);
                         const bool tmb = ((k == 0u ? tm0 : (k == 1u ? tm1 : (k == 2u ? tm2 : tm3))) >> sh) & 1u;
                         const uint32_t v_band = nbb ? (filter ? 2u : v_set) : v_clear;
                         const uint32_t v_cls = ru < bp.lo ? 1u : (ru >= bp.hi ? 0u : v_band);
@@ -922,7 +988,7 @@ elist_pool_kernel(const u32x2_a8 *__restrict__ ix32, const u32x4_a16 *__restrict
                     running = v == 0u;
                 }
             }
-            bool to_issue = false, to_trial = false;
+            bool to_issue = false, to_trial = false, to_free = false;
             if (busy) {
                 // the block the walker's next draw lives in becomes the slot's current block
                 const uint32_t used = pos - (d0 & 3u);
@@ -936,10 +1002,13 @@ elist_pool_kernel(const u32x2_a8 *__restrict__ ix32, const u32x4_a16 *__restrict
                 P[EF_REJ][slot] = rejected;
                 if (verdict == 0u) {
                     to_trial = true;
-                } else if (fixed) {  // the fixed candidate is taken: through its entry, or bare (padding / jump)
-                    const bool bare = P[EF_AT][slot] == kNoEdge;
-                    set_kind(slot, flags, bare ? EK_NOENTRY : EK_ENTRY);
-                    if (kCount && !bare) ++n_fetch;
+                } else if (fixed && P[EF_AT][slot] == kNoEdge) {  // taken without an entry (padding / jump): no gather, step now
+                    const int where = step_bare(slot, P[EF_X][slot], to_free);
+                    to_trial = where == 0;
+                    to_issue = where == 1;
+                } else if (fixed) {  // the fixed candidate is taken through its entry
+                    set_kind(slot, flags, EK_ENTRY);
+                    if (kCount) ++n_fetch;
                     to_issue = true;
                 } else {
                     P[EF_AT][slot] = at;
@@ -951,6 +1020,7 @@ elist_pool_kernel(const u32x2_a8 *__restrict__ ix32, const u32x4_a16 *__restrict
             }
             issue_q.push(to_issue, slot);
             trial_q.push(to_trial, slot);
+            free_q.push(to_free, slot);
             pool_fence();
         }
     }
