@@ -325,6 +325,26 @@ int trw_to_windows_triples_cbow_hip(const int64_t *walks, int64_t num_walks, int
                                     int64_t *neg_triples, int64_t *pos_windows, void *workspace,
                                     size_t workspace_bytes, void *hip_stream);
 
+/*
+ * Host legs of the rows next to the CSR walk: what the reference's dispatcher does with CPU tensors for its other
+ * entry points (csrc/rw_init.cpp:27-131 -> walk_edge_list_cpu, triples::walk_triples_cpu, to_windows*_cpu).  HOST
+ * pointers, synchronous, one thread, the reference's one glibc rand() stream (that is csrc/cpu on one thread);
+ * arguments and result layouts as the *_hip forms above (no walker_base / rng_mode / workspace / stream).
+ * `cbow` selects to_windows_cbow / to_windows_triples_cbow; `centre`/`rest`/`neg` are (target_nodes, pos_windows,
+ * neg_windows) or, with cbow, (pos_nodes, windows, neg_nodes).  Data faults: TRW_E_DATA.
+ */
+int trw_walk_edge_list_cpu(const int64_t *edges, int64_t n_edges, const int64_t *node_edge_index, int64_t n_nodes,
+                           const int64_t *targets, int64_t n_walkers, double p, double q, int32_t walk_length,
+                           int32_t seed, int64_t padding_idx, int32_t restart, int64_t *out);
+int trw_walk_triples_cpu(const int64_t *triples, int64_t n_triples, const int64_t *rt_index, int64_t n_entities,
+                         const int64_t *targets, int64_t n_walkers, int32_t walk_length, int64_t padding_idx,
+                         int32_t seed, int64_t *out);
+int trw_to_windows_cpu(const int64_t *walks, int64_t num_walks, int64_t walk_cols, int32_t window_size,
+                       int64_t num_nodes, int32_t seed, int32_t cbow, int64_t *centre, int64_t *rest, int64_t *neg);
+int trw_to_windows_triples_cpu(const int64_t *walks, int64_t num_walks, int64_t walk_cols, int32_t window_size,
+                               int64_t padding_idx, const int64_t *triples, int64_t num_triples, int32_t seed,
+                               int32_t cbow, int64_t *target_triples, int64_t *pos_windows, int64_t *neg);
+
 /* Synchronises `hip_stream` and copies the status block of the last walk that
  * used `workspace` to the host: status[0] = OR of TRW_ST_* bits,
  * status[1] = 1 if some CSR row was found unsorted (biased walks only; the

@@ -100,9 +100,39 @@ def test_surface_names():
         ["edge_list_indexed", "node_edge_index", "target_nodes", "p", "q", "walk_length", "seed", "padding_idx",
          "restart"]                                                  # torch_rw/rw.py:6
     assert callable(torch_rw_native.walk_edge_list) and callable(utils.to_edge_list_indexed)
-    z = torch.zeros((1, 2), dtype=torch.int64)
-    with pytest.raises(RuntimeError, match="CUDA tensor"):
-        rw.walk_edge_list(z, z, torch.zeros(1, dtype=torch.int64), 1.0, 1.0, 3, 1, 9)
+
+
+def test_host_leg_all_reference_goldens_through_the_reference_call(egold):
+    """The reference's six CPU goldens (tests/test_rw_edge_list.py) through its own call on CPU tensors: the
+    dispatcher's host leg (rw_init.cpp:41-44 -> walk_edge_list_cpu), product code in csrc/trw_cpu.cpp."""
+    from torch_rw import rw
+    for c in egold["cases"]:
+        edges, index, targets, pad = _reference_inputs(egold, c["directed"])
+        kw = dict(edge_list_indexed=edges, node_edge_index=index, target_nodes=targets, p=c["p"], q=c["q"],
+                  walk_length=6, seed=c["seed"], padding_idx=pad)
+        if not c["restart"]:
+            kw["restart"] = False
+        walks = rw.walk_edge_list(**kw)
+        assert walks.device.type == "cpu" and walks.dtype == torch.int64 and tuple(walks.shape) == (5, 7)
+        assert walks.tolist() == c["walks"], c["source"]
+
+
+@pytest.mark.parametrize("p,q", [(1.0, 1.0), (0.25, 4.0), (0.7, 0.2), (4.0, 0.25)])
+@pytest.mark.parametrize("restart", [True, False])
+def test_host_leg_equals_oracle(p, q, restart):
+    from torch_rw import rw
+    edges, index = _random_edge_list(300, 2500, 11)
+    pad = 300
+    tg = np.random.default_rng(1).integers(0, 300, 700)
+    tg[::23] = pad
+    for L in (1, 2, 25):
+        ref = O.walk_edge_list(edges.numpy(), index.numpy(), tg, p, q, L, 5, pad, restart=restart, rng_mode=O.RNG_GLIBC_SEQ)
+        got = rw.walk_edge_list(edges, index, torch.as_tensor(tg), p, q, L, 5, pad, restart)
+        assert (got.numpy() == ref).all()
+    with pytest.raises(RuntimeError, match="outside"):
+        rw.walk_edge_list(edges, index, torch.tensor([301]), 1.0, 1.0, 4, 1, pad)
+    with pytest.raises(RuntimeError, match="expected scalar type Long"):
+        rw.walk_edge_list(edges, index.to(torch.int32), torch.tensor([1]), 1.0, 1.0, 4, 1, pad)
 
 
 # ---- GPU tier ------------------------------------------------------------------------------

@@ -96,9 +96,26 @@ def test_surface_names():
     assert list(inspect.signature(rw.walk_triples).parameters) == \
         ["triples_indexed", "relation_tail_index", "target_nodes", "walk_length", "padding_idx", "seed", "restart"]
     assert callable(torch_rw_native.walk_triples) and callable(utils.build_relation_tail_index)
-    with pytest.raises(RuntimeError, match="CUDA tensor"):
-        rw.walk_triples(torch.zeros((1, 3), dtype=torch.int64), torch.zeros((1, 2), dtype=torch.int64),
-                        torch.zeros(1, dtype=torch.int64), 3, 9, 1)
+
+
+def test_host_leg_reference_golden_and_oracle(tgold):
+    """The reference's CPU golden (tests/test_rw_triples.py:70-79) through its own call on CPU tensors: the host leg
+    (rw_init.cpp:66-74 -> triples::walk_triples_cpu), product code in csrc/trw_cpu.cpp; then against the oracle."""
+    from torch_rw import rw, utils
+    tt = torch.Tensor(tgold["triples"]["list"])
+    ents = torch.Tensor(sorted(set(tt[:, 0].tolist() + tt[:, 2].tolist()))).to(int)
+    index, ts = utils.build_relation_tail_index(tt, ents)
+    c = tgold["walk_cpu"]
+    w = rw.walk_triples(triples_indexed=ts, relation_tail_index=index, target_nodes=torch.tensor(c["target_nodes"]),
+                        walk_length=c["walk_length"], seed=c["seed"], padding_idx=c["padding_idx"], restart=False)
+    assert w.device.type == "cpu" and w.dtype == torch.int64 and w.tolist() == c["walks"]
+    ts2, index2, ents2, pad = _kg(200, 900, 5, 5)
+    tg = np.random.default_rng(0).integers(0, 200, 500)
+    tg[::17] = pad
+    ref = O.walk_triples(ts2.numpy(), index2.numpy(), tg, 12, pad, 7, rng_mode=O.RNG_GLIBC_SEQ)
+    assert (rw.walk_triples(ts2, index2, torch.as_tensor(tg), 12, pad, 7).numpy() == ref).all()
+    with pytest.raises(RuntimeError, match="outside"):
+        rw.walk_triples(ts2, index2, torch.tensor([10**6]), 4, pad, 1)
 
 
 # ---- GPU tier ------------------------------------------------------------------------------

@@ -71,8 +71,47 @@ def test_surface_names():
     assert list(inspect.signature(rw.to_windows).parameters) == ["walks", "window_size", "num_nodes", "seed"]
     assert list(inspect.signature(rw.to_windows_cbow).parameters) == ["walks", "window_size", "num_nodes", "seed"]
     assert callable(torch_rw_native.to_windows) and callable(torch_rw_native.to_windows_cbow)
-    with pytest.raises(RuntimeError, match="CUDA tensor"):
-        rw.to_windows(torch.zeros((2, 6), dtype=torch.int64), 3, 5, 1)
+
+
+def test_host_legs_reference_goldens_and_oracle(wgold):
+    """All four window builders on CPU tensors (rw_init.cpp:77-131 -> to_windows*_cpu): the reference's CPU goldens
+    through its own calls, then element for element against the oracle on random shapes."""
+    from torch_rw import rw
+    g = wgold
+    walks = torch.tensor(g["walks"])
+    t, p, n = rw.to_windows(walks=walks, window_size=5, num_nodes=30, seed=20)
+    e = g["to_windows_cpu"]
+    assert t.device.type == "cpu" and t.size(0) == 18
+    assert t[:6].tolist() == e["target_nodes"] and p[:6].tolist() == e["pos_windows"] and n[:6].tolist() == e["neg_windows"]
+    pn, nn, w = rw.to_windows_cbow(walks=walks, window_size=5, num_nodes=30, seed=20)
+    e = g["to_windows_cbow_cpu"]
+    assert pn[:6].tolist() == e["pos_nodes"] and nn[:6].tolist() == e["neg_nodes"] and w[:6].tolist() == e["windows"]
+    c = g["triples_case"]
+    cw, ct = torch.tensor(c["walks"]), torch.tensor(c["triples"])
+    tt, pw, nw = rw.to_windows_triples(walks=cw, window_size=4, num_nodes=30, padding_idx=-1, triples=ct, seed=20)
+    e = c["to_windows_triples_cpu"]
+    assert tt[:2].tolist() == e["target_triples"] and pw[:2].tolist() == e["pos_windows"] and nw[:2].tolist() == e["neg_windows"]
+    pt, nt, w2 = rw.to_windows_triples_cbow(walks=cw, window_size=4, num_nodes=30, padding_idx=-1, triples=ct, seed=20)
+    e2 = c["to_windows_triples_cbow_cpu"]
+    assert pt[:2].tolist() == e2["pos_triples"] and nt[:2].tolist() == e2["neg_triples"] and w2[:2].tolist() == e["pos_windows"]
+    rng = np.random.default_rng(3)
+    for ws, num_nodes, seed in ((1, 7, 1), (2, 1, 3), (5, 30, 20), (8, 10**6, -1), (11, 2**33, 10)):
+        wk = rng.integers(0, min(num_nodes, 1000), (37, 23))
+        ref = O.to_windows(wk, ws, num_nodes, seed)
+        got = rw.to_windows(torch.as_tensor(wk), ws, num_nodes, seed)
+        assert all((a.numpy() == b).all() for a, b in zip(got, ref))
+        ref = O.to_windows_cbow(wk, ws, num_nodes, seed)
+        got = rw.to_windows_cbow(torch.as_tensor(wk), ws, num_nodes, seed)
+        assert all((a.numpy() == b).all() for a, b in zip(got, ref))
+    for ws, cols, ntr in ((1, 3, 1), (2, 7, 5), (4, 21, 10), (3, 161, 1000), (5, 20, 3)):
+        wk = rng.integers(0, 50, (9, cols))
+        tr = rng.integers(0, 50, (ntr, 3))
+        ref = O.to_windows_triples(wk, ws, 50, 49, tr, 7)
+        got = rw.to_windows_triples(torch.as_tensor(wk), ws, 50, 49, torch.as_tensor(tr), 7)
+        assert all((a.numpy() == b).all() for a, b in zip(got, ref))
+        ref = O.to_windows_triples_cbow(wk, ws, 50, 49, tr, 7)
+        got = rw.to_windows_triples_cbow(torch.as_tensor(wk), ws, 50, 49, torch.as_tensor(tr), 7)
+        assert all((a.numpy() == b).all() for a, b in zip(got, ref))
 
 
 # ---- GPU tier ------------------------------------------------------------------------------

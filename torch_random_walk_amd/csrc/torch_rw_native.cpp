@@ -7,8 +7,8 @@
 // memory (output + scratch through the caching allocator), the device guard and
 // the current stream.
 //
-// Device dispatch as in the reference (rw_init.cpp:20-24): tensors on the GPU go to the HIP kernels,
-// CPU tensors of the CSR walk to the library's host leg (trw_walk_csr_cpu).  Neither is a fallback for
+// Device dispatch as in the reference (rw_init.cpp:20-24 and the five other dispatchers): tensors on the GPU go to
+// the HIP kernels, CPU tensors to the library's host legs (trw_*_cpu: csrc/cpu on one thread).  Neither is a fallback for
 // the other: a GPU tensor never runs on the host.
 //
 // Data faults found on the device (degree-0 node, ids out of range, ...) are reported without a host
@@ -413,12 +413,12 @@ torch::Tensor walk_triples_ex(const torch::Tensor &triples_indexed, const torch:
                               bool restart, int64_t seed, int64_t walker_base, int64_t rng_mode, int64_t check)
 {
     (void)restart;  // accepted and never read by the reference either (rw_cpu_triples.cpp:48-55)
+    const bool on_gpu = triples_indexed.is_cuda();  // rw_init.cpp:57: the device of the first tensor picks the leg
     const int check_mode = resolve_check(check);
-    if (check_mode == kCheckDeferred) raise_pending();
-    check_index_tensor(target_nodes, "target_nodes");
+    if (on_gpu && check_mode == kCheckDeferred) raise_pending();
+    check_index_tensor(target_nodes, "target_nodes", on_gpu);
     for (const auto *t : {&triples_indexed, &relation_tail_index}) {
-        TORCH_CHECK(t->is_cuda(), "triples_indexed and relation_tail_index must be CUDA tensors (torch_rw_native here "
-                                  "is the MI355X HIP build; it has no CPU walker)");
+        TORCH_CHECK(t->is_cuda() == on_gpu, "triples_indexed, relation_tail_index and target_nodes must be on the same device");
         TORCH_CHECK(t->scalar_type() == torch::kInt64, "expected scalar type Long but found ",
                     c10::toString(t->scalar_type()));
         TORCH_CHECK(t->dim() == 2, "triples_indexed / relation_tail_index must be 2-dimensional");
@@ -430,6 +430,21 @@ torch::Tensor walk_triples_ex(const torch::Tensor &triples_indexed, const torch:
     TORCH_CHECK(walk_length >= 1, "walk_length must be >= 1, got ", walk_length);
     TORCH_CHECK(walk_length < (int64_t(1) << 30) && seed >= INT32_MIN && seed <= INT32_MAX,
                 "walk_length/seed must fit the reference's int arguments");
+    if (!on_gpu) {  // the host leg (rw_init.cpp:66-74 -> triples::walk_triples_cpu): csrc/cpu on one thread
+        const auto tr = triples_indexed.contiguous();
+        const auto ix = relation_tail_index.contiguous();
+        const auto tg = target_nodes.contiguous();
+        auto walks = torch::empty({tg.numel(), 2 * walk_length + 1}, tg.options());
+        int rc;
+        {
+            pybind11::gil_scoped_release nogil;
+            rc = trw_walk_triples_cpu(tr.data_ptr<int64_t>(), tr.size(0), ix.data_ptr<int64_t>(), ix.size(0),
+                                      tg.data_ptr<int64_t>(), tg.numel(), (int32_t)walk_length, padding_idx,
+                                      (int32_t)seed, walks.data_ptr<int64_t>());
+        }
+        TORCH_CHECK(rc == TRW_OK, "torch_rw walk_triples failed (", rc, "): ", trw_last_error());
+        return walks;
+    }
 
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(target_nodes.device());
     const auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(target_nodes.device().index());
@@ -470,12 +485,12 @@ torch::Tensor walk_edge_list_ex(const torch::Tensor &edge_list_indexed, const to
                                 int64_t seed, int64_t padding_idx, bool restart, int64_t walker_base,
                                 int64_t rng_mode, int64_t check)
 {
+    const bool on_gpu = edge_list_indexed.is_cuda();  // rw_init.cpp:39
     const int check_mode = resolve_check(check);
-    if (check_mode == kCheckDeferred) raise_pending();
-    check_index_tensor(target_nodes, "target_nodes");
+    if (on_gpu && check_mode == kCheckDeferred) raise_pending();
+    check_index_tensor(target_nodes, "target_nodes", on_gpu);
     for (const auto *t : {&edge_list_indexed, &node_edges_idx}) {
-        TORCH_CHECK(t->is_cuda(), "edge_list_indexed and node_edge_index must be CUDA tensors (torch_rw_native here "
-                                  "is the MI355X HIP build; it has no CPU walker)");
+        TORCH_CHECK(t->is_cuda() == on_gpu, "edge_list_indexed, node_edge_index and target_nodes must be on the same device");
         TORCH_CHECK(t->scalar_type() == torch::kInt64, "expected scalar type Long but found ",
                     c10::toString(t->scalar_type()));
         TORCH_CHECK(t->dim() == 2 && t->size(1) == 2, "edge_list_indexed / node_edge_index must be [*, 2]");
@@ -485,6 +500,21 @@ torch::Tensor walk_edge_list_ex(const torch::Tensor &edge_list_indexed, const to
     TORCH_CHECK(walk_length >= 1, "walk_length must be >= 1, got ", walk_length);
     TORCH_CHECK(walk_length < (int64_t(1) << 31) && seed >= INT32_MIN && seed <= INT32_MAX,
                 "walk_length/seed must fit the reference's int arguments");
+    if (!on_gpu) {  // the host leg (rw_init.cpp:41-44 -> walk_edge_list_cpu): csrc/cpu on one thread
+        const auto ed = edge_list_indexed.contiguous();
+        const auto ix = node_edges_idx.contiguous();
+        const auto tg = target_nodes.contiguous();
+        auto walks = torch::empty({tg.numel(), walk_length + 1}, tg.options());
+        int rc;
+        {
+            pybind11::gil_scoped_release nogil;
+            rc = trw_walk_edge_list_cpu(ed.data_ptr<int64_t>(), ed.size(0), ix.data_ptr<int64_t>(), ix.size(0),
+                                        tg.data_ptr<int64_t>(), tg.numel(), p, q, (int32_t)walk_length, (int32_t)seed,
+                                        padding_idx, restart ? 1 : 0, walks.data_ptr<int64_t>());
+        }
+        TORCH_CHECK(rc == TRW_OK, "torch_rw walk_edge_list failed (", rc, "): ", trw_last_error());
+        return walks;
+    }
 
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(target_nodes.device());
     const auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(target_nodes.device().index());
@@ -537,8 +567,6 @@ std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> windows_impl(const torch
                                                                      int64_t num_nodes, int64_t seed, bool cbow,
                                                                      int64_t base, int64_t rng_mode)
 {
-    TORCH_CHECK(walks.is_cuda(), "walks must be a CUDA tensor (torch_rw_native here is the MI355X HIP build; it has "
-                                 "no CPU path)");
     TORCH_CHECK(walks.scalar_type() == torch::kInt64, "expected scalar type Long but found ",
                 c10::toString(walks.scalar_type()));
     TORCH_CHECK(walks.dim() == 2, "walks must be 2-dimensional");
@@ -546,6 +574,22 @@ std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> windows_impl(const torch
     const int64_t num_walks = walks.size(0), cols = walks.size(1);
     TORCH_CHECK(window_size >= 1 && window_size <= cols, "window_size must be between 1 and the walk width");
     TORCH_CHECK(seed >= INT32_MIN && seed <= INT32_MAX, "seed must fit the reference's int argument");
+    if (!walks.is_cuda()) {  // the host leg (rw_init.cpp:85-87 / :98-100 -> to_windows{,_cbow}_cpu)
+        const int64_t Wc = (cols - window_size + 1) * num_walks;
+        auto centre = torch::empty({Wc}, walks.options());
+        auto rest = torch::empty({Wc, window_size - 1}, walks.options());
+        auto neg = cbow ? torch::empty({Wc}, walks.options()) : torch::empty({Wc, window_size - 1}, walks.options());
+        int rc;
+        {
+            pybind11::gil_scoped_release nogil;
+            rc = trw_to_windows_cpu(walks.data_ptr<int64_t>(), num_walks, cols, (int32_t)window_size, num_nodes,
+                                    (int32_t)seed, cbow ? 1 : 0, centre.data_ptr<int64_t>(), rest.data_ptr<int64_t>(),
+                                    neg.data_ptr<int64_t>());
+        }
+        TORCH_CHECK(rc == TRW_OK, "torch_rw to_windows failed (", rc, "): ", trw_last_error());
+        if (cbow) return std::make_tuple(centre, neg, rest);
+        return std::make_tuple(centre, rest, neg);
+    }
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(walks.device());
     const auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(walks.device().index());
     const int64_t W = (cols - window_size + 1) * num_walks;
@@ -592,8 +636,6 @@ std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> triples_windows_impl(con
                                                                              bool cbow, int64_t base, int64_t rng_mode)
 {
     for (const auto *t : {&walks, &triples}) {
-        TORCH_CHECK(t->is_cuda(), "walks and triples must be CUDA tensors (torch_rw_native here is the MI355X HIP "
-                                  "build; it has no CPU path)");
         TORCH_CHECK(t->scalar_type() == torch::kInt64, "expected scalar type Long but found ",
                     c10::toString(t->scalar_type()));
         TORCH_CHECK(t->dim() == 2, "walks and triples must be 2-dimensional");
@@ -603,6 +645,23 @@ std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> triples_windows_impl(con
     TORCH_CHECK(walks.device() == triples.device(), "walks and triples must be on the same device");
     TORCH_CHECK(window_size >= 1, "window_size must be >= 1");
     TORCH_CHECK(seed >= INT32_MIN && seed <= INT32_MAX, "seed must fit the reference's int argument");
+    if (!walks.is_cuda()) {  // the host leg (rw_init.cpp:113-115 / :128-130 -> to_windows_triples{,_cbow}_cpu)
+        const auto trc = triples.contiguous();
+        const int64_t nw = walks.size(0), cw = walks.size(1), Wc = ((cw - 1) / 2) * nw;
+        auto centre = torch::empty({Wc, 3}, walks.options());
+        auto pos = torch::empty({Wc, 2 * window_size, 3}, walks.options());
+        auto neg = cbow ? torch::empty({Wc, 3}, walks.options()) : torch::empty({Wc, 2 * window_size, 3}, walks.options());
+        int rc;
+        {
+            pybind11::gil_scoped_release nogil;
+            rc = trw_to_windows_triples_cpu(walks.data_ptr<int64_t>(), nw, cw, (int32_t)window_size, padding_idx,
+                                            trc.data_ptr<int64_t>(), trc.size(0), (int32_t)seed, cbow ? 1 : 0,
+                                            centre.data_ptr<int64_t>(), pos.data_ptr<int64_t>(), neg.data_ptr<int64_t>());
+        }
+        TORCH_CHECK(rc == TRW_OK, "torch_rw to_windows_triples failed (", rc, "): ", trw_last_error());
+        if (cbow) return std::make_tuple(centre, neg, pos);
+        return std::make_tuple(centre, pos, neg);
+    }
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(walks.device());
     const auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(walks.device().index());
     const auto tr = triples.contiguous();

@@ -319,3 +319,285 @@ extern "C" int trw_walk_csr_cpu(const int64_t *row_ptr, int64_t n_nodes, const i
     if (fault.any()) return fail(TRW_E_DATA, fault_text(fault.bits.load()));
     return TRW_OK;
 }
+
+// ---- host legs of the rows next to the CSR walk -------------------------------------------------------------
+// What the reference's dispatcher does with CPU tensors for its other six entry points (csrc/rw_init.cpp:27-131):
+// the csrc/cpu algorithms on ONE thread, i.e. on the one glibc rand() stream srand(seed) starts, consumed in the
+// reference's order.  Written from the semantics this library's own kernels implement (trw_kernels_*.hpp cite the
+// reference lines); nothing here is shared with the test oracle.
+namespace trw_cpu {
+namespace {
+
+// sample_int(lo, hi) of the reference (csrc/cpu/cpu_utils.cpp:3-10): inclusive range, NO draw for a single value
+inline int64_t sample_int(GlibcRand &rng, int64_t lo, int64_t hi)
+{
+    if (lo == hi) return lo;
+    return lo + (int64_t)rng() % (hi - lo + 1);
+}
+
+struct Ranges {  // an inclusive (first, last) index per node, (-1, -1) for a node without rows
+    const int64_t *index;
+    int64_t n_nodes, n_rows;
+    bool of(int64_t node, int64_t &first, int64_t &last, Fault &fault) const
+    {
+        first = last = -1;
+        if ((uint64_t)node >= (uint64_t)n_nodes) return false;
+        const int64_t a = index[2 * node], b = index[2 * node + 1];
+        if (a == -1 || b == -1) return false;
+        if (a < 0 || b < a || b >= n_rows) {
+            fault.raise(TRW_ST_BAD_CSR);
+            return false;
+        }
+        first = a;
+        last = b;
+        return true;
+    }
+};
+
+}  // namespace
+}  // namespace trw_cpu
+
+extern "C" int trw_walk_edge_list_cpu(const int64_t *edges, int64_t n_edges, const int64_t *node_edge_index,
+                                      int64_t n_nodes, const int64_t *targets, int64_t n_walkers, double p, double q,
+                                      int32_t walk_length, int32_t seed, int64_t padding_idx, int32_t restart,
+                                      int64_t *out)
+{
+    using namespace trw_cpu;
+    set_last_error("");
+    if (n_edges < 0 || n_nodes < 0 || n_walkers < 0) return fail(TRW_E_ARG, "negative size argument");
+    if (walk_length < 1) return fail(TRW_E_ARG, "walk_length must be >= 1");
+    if (!(p > 0.0) || !(q > 0.0) || !std::isfinite(p) || !std::isfinite(q))
+        return fail(TRW_E_ARG, "p and q must be positive and finite");
+    if ((n_edges > 0 && !edges) || (n_nodes > 0 && !node_edge_index)) return fail(TRW_E_ARG, "edge list / index is null");
+    if (n_walkers > 0 && (!targets || !out)) return fail(TRW_E_ARG, "targets/out is null");
+    const bool uniform = (p == 1.0 && q == 1.0);  // rw_cpu_edge_list.cpp:260
+    const Bias bias = make_bias(p, q);
+    const Ranges ranges = {node_edge_index, n_nodes, n_edges};
+    const int64_t pad = padding_idx, cols = (int64_t)walk_length + 1;
+    Fault fault;
+    GlibcRand rng(seed, 0);
+    auto tail_of = [&](int64_t e) {
+        const int64_t t = edges[2 * e + 1];
+        if (t != pad && (uint64_t)t >= (uint64_t)n_nodes) fault.raise(TRW_ST_NODE_RANGE);
+        return t;
+    };
+    for (int64_t i = 0; i < n_walkers && !fault.any(); ++i) {
+        int64_t *row = out + i * cols;
+        const int64_t start = targets[i];
+        row[0] = start;
+        if (start != pad && (uint64_t)start >= (uint64_t)n_nodes) {
+            fault.raise(TRW_ST_NODE_RANGE);
+            break;
+        }
+        const int64_t jump = restart ? start : pad;  // rw_cpu_edge_list.cpp:103-108
+        // sample_neighbor (:8-35): from the padding id to the jump node; a dead end steps onto the padding id
+        auto sample = [&](int64_t node, int64_t first, int64_t last) {
+            if (node == pad) return jump;
+            if (first < 0) return pad;
+            return tail_of(sample_int(rng, first, last));
+        };
+        int64_t here = start, first, last;
+        if (uniform) {
+            for (int32_t s = 1; s <= walk_length; ++s) {
+                ranges.of(here, first, last, fault);
+                here = sample(here, first, last);
+                row[s] = here;
+            }
+            continue;
+        }
+        int64_t back = start, back_first, back_last;
+        ranges.of(back, back_first, back_last, fault);
+        here = sample(back, back_first, back_last);  // :188
+        row[1] = here;
+        for (int32_t s = 2; s <= walk_length && !fault.any(); ++s) {
+            ranges.of(here, first, last, fault);
+            int64_t taken = here;
+            for (uint32_t tries = 0;; ++tries) {
+                const int64_t x = sample(here, first, last);
+                const double u = (double)rng() / (double)kRandMax;  // :198, always drawn
+                bool take = false;
+                taken = x;
+                if (x == back && u < bias.accept_back) {  // :204-209
+                    take = true;
+                } else if (x == pad) {  // :212-217
+                    take = u < bias.accept_back;
+                    taken = jump;
+                } else {  // :220-231 -- is_neighbor scans back's edges [first, last): never the last one (:51)
+                    bool near = false;
+                    if (u < bias.band_lo) {
+                        take = true;
+                    } else if (u < bias.band_hi) {
+                        for (int64_t e = back_first; back_first >= 0 && e < back_last; ++e)
+                            if (edges[2 * e + 1] == x) {
+                                near = true;
+                                break;
+                            }
+                        take = u < (near ? bias.accept_near : bias.accept_far);
+                    }
+                }
+                if (take) break;
+                if (tries + 1 >= kTrialLimit) {
+                    fault.raise(TRW_ST_TRIAL_CAP);
+                    break;
+                }
+            }
+            row[s] = taken;
+            back = here;
+            back_first = first;
+            back_last = last;
+            here = taken;
+        }
+    }
+    if (fault.any()) return fail(TRW_E_DATA, fault_text(fault.bits.load()));
+    return TRW_OK;
+}
+
+extern "C" int trw_walk_triples_cpu(const int64_t *triples, int64_t n_triples, const int64_t *rt_index,
+                                    int64_t n_entities, const int64_t *targets, int64_t n_walkers, int32_t walk_length,
+                                    int64_t padding_idx, int32_t seed, int64_t *out)
+{
+    using namespace trw_cpu;
+    set_last_error("");
+    if (n_triples < 0 || n_entities < 0 || n_walkers < 0) return fail(TRW_E_ARG, "negative size argument");
+    if (walk_length < 1) return fail(TRW_E_ARG, "walk_length must be >= 1");
+    if ((n_triples > 0 && !triples) || (n_entities > 0 && !rt_index)) return fail(TRW_E_ARG, "triples / index is null");
+    if (n_walkers > 0 && (!targets || !out)) return fail(TRW_E_ARG, "targets/out is null");
+    const Ranges ranges = {rt_index, n_entities, n_triples};
+    const int64_t pad = padding_idx, cols = 2 * (int64_t)walk_length + 1;
+    Fault fault;
+    GlibcRand rng(seed, 0);
+    for (int64_t i = 0; i < n_walkers && !fault.any(); ++i) {
+        int64_t *row = out + i * cols;
+        int64_t node = targets[i];
+        row[0] = node;
+        for (int32_t h = 0; h < walk_length; ++h) {  // rw_cpu_triples.cpp:11-46: (relation, tail) of a uniform out-triple
+            int64_t rel = pad, tail = pad, first, last;
+            if (node != pad) {
+                if ((uint64_t)node >= (uint64_t)n_entities) {
+                    fault.raise(TRW_ST_NODE_RANGE);
+                    break;
+                }
+                if (ranges.of(node, first, last, fault)) {
+                    const int64_t e = sample_int(rng, first, last);
+                    rel = triples[3 * e + 1];
+                    tail = triples[3 * e + 2];
+                }
+            }
+            row[2 * h + 1] = rel;
+            row[2 * h + 2] = tail;
+            node = tail;
+        }
+    }
+    if (fault.any()) return fail(TRW_E_DATA, fault_text(fault.bits.load()));
+    return TRW_OK;
+}
+
+namespace trw_cpu {
+namespace {
+int windows_args(const int64_t *walks, int64_t num_walks, int64_t cols, int32_t window_size)
+{
+    if (num_walks < 0) return fail(TRW_E_ARG, "negative size argument");
+    if (cols < 1 || window_size < 1) return fail(TRW_E_ARG, "window_size and the walk width must be >= 1");
+    if (num_walks > 0 && !walks) return fail(TRW_E_ARG, "walks is null");
+    return TRW_OK;
+}
+
+// centre and rest of every window of every walk (windows_cpu.cpp:38-60): mid = window_size / 2
+void gather_windows(const int64_t *walks, int64_t num_walks, int64_t cols, int32_t window_size, int64_t *centre,
+                    int64_t *rest)
+{
+    const int64_t per_walk = cols - window_size + 1, width = window_size - 1;
+    const int32_t mid = window_size / 2;
+    for (int64_t w = 0; w < num_walks * per_walk; ++w) {
+        const int64_t *win = walks + (w / per_walk) * cols + w % per_walk;
+        centre[w] = win[mid];
+        for (int32_t k = 0; k < width; ++k) rest[w * width + k] = win[k < mid ? k : k + 1];
+    }
+}
+
+// target triple and the 2*window_size rows around it (windows_cpu.cpp:190-276), with the reference's walk[rel] in
+// the head slot of left rows (:221) kept as it is
+void gather_triple_windows(const int64_t *walks, int64_t num_walks, int64_t cols, int32_t window_size, int64_t pad,
+                           int64_t *targets3, int64_t *rows)
+{
+    const int64_t per_walk = (cols - 1) / 2, slots = 2 * (int64_t)window_size;
+    for (int64_t w = 0; w < num_walks * per_walk; ++w) {
+        const int64_t *walk = walks + (w / per_walk) * cols;
+        const int64_t tri = 2 * (w % per_walk) + 1;
+        for (int c = 0; c < 3; ++c) targets3[w * 3 + c] = walk[tri - 1 + c];
+        int64_t *win = rows + w * slots * 3;
+        for (int64_t hop = 0; hop < window_size; ++hop) {
+            const int64_t rel = tri - (hop + 1) * 2;
+            win[hop * 3 + 0] = rel - 1 >= 0 ? walk[rel] : pad;
+            win[hop * 3 + 1] = rel >= 0 ? walk[rel] : pad;
+            win[hop * 3 + 2] = rel + 1 >= 0 ? walk[rel + 1] : pad;
+            const int64_t rr = tri + (hop + 1) * 2;
+            int64_t *o = win + (hop + window_size) * 3;
+            o[0] = rr - 1 < cols ? walk[rr - 1] : pad;
+            o[1] = rr < cols ? walk[rr] : pad;
+            o[2] = rr + 1 < cols ? walk[rr + 1] : pad;
+        }
+    }
+}
+}  // namespace
+}  // namespace trw_cpu
+
+extern "C" int trw_to_windows_cpu(const int64_t *walks, int64_t num_walks, int64_t walk_cols, int32_t window_size,
+                                  int64_t num_nodes, int32_t seed, int32_t cbow, int64_t *centre, int64_t *rest,
+                                  int64_t *neg)
+{
+    using namespace trw_cpu;
+    set_last_error("");
+    if (int rc = windows_args(walks, num_walks, walk_cols, window_size)) return rc;
+    if (window_size > walk_cols) return fail(TRW_E_ARG, "window_size must be between 1 and the walk width");
+    if (num_nodes < 1) return fail(TRW_E_ARG, "num_nodes must be >= 1 (the reference computes rand() % num_nodes)");
+    const int64_t total = num_walks * (walk_cols - window_size + 1), width = window_size - 1;
+    if (total == 0) return TRW_OK;
+    if (!centre || (cbow && !neg) || (width > 0 && (!rest || !neg))) return fail(TRW_E_ARG, "output pointer is null");
+    gather_windows(walks, num_walks, walk_cols, window_size, centre, rest);
+    GlibcRand rng(seed, 0);
+    if (!cbow) {  // window_size-1 negatives per window, each rand() % num_nodes (windows_cpu.cpp:62-68)
+        for (int64_t k = 0; k < total * width; ++k) neg[k] = (int64_t)rng() % num_nodes;
+    } else {  // one negative per window, redrawn while it equals the positive node, 101 redraws at most (:129-135)
+        for (int64_t w = 0; w < total; ++w) {
+            int64_t x = sample_int(rng, 0, num_nodes - 1);
+            for (int checks = 0; x == centre[w] && checks <= 100; ++checks) x = sample_int(rng, 0, num_nodes - 1);
+            neg[w] = x;
+        }
+    }
+    return TRW_OK;
+}
+
+extern "C" int trw_to_windows_triples_cpu(const int64_t *walks, int64_t num_walks, int64_t walk_cols,
+                                          int32_t window_size, int64_t padding_idx, const int64_t *triples,
+                                          int64_t num_triples, int32_t seed, int32_t cbow, int64_t *target_triples,
+                                          int64_t *pos_windows, int64_t *neg)
+{
+    using namespace trw_cpu;
+    set_last_error("");
+    if (int rc = windows_args(walks, num_walks, walk_cols, window_size)) return rc;
+    if (num_triples < 1 || !triples) return fail(TRW_E_ARG, "triples must hold at least one row");
+    const int64_t total = num_walks * ((walk_cols - 1) / 2), slots = 2 * (int64_t)window_size;
+    if (total == 0) return TRW_OK;
+    if (!target_triples || !pos_windows || !neg) return fail(TRW_E_ARG, "output pointer is null");
+    gather_triple_windows(walks, num_walks, walk_cols, window_size, padding_idx, target_triples, pos_windows);
+    GlibcRand rng(seed, 0);
+    auto copy_row = [&](int64_t *dst, int64_t r) {
+        dst[0] = triples[3 * r];
+        dst[1] = triples[3 * r + 1];
+        dst[2] = triples[3 * r + 2];
+    };
+    if (!cbow) {  // 2*window_size drawn rows of the pool per window (windows_cpu.cpp:279-290)
+        for (int64_t k = 0; k < total * slots; ++k) copy_row(neg + 3 * k, sample_int(rng, 0, num_triples - 1));
+    } else {  // one drawn row, redrawn while it equals the positive triple (:374-389)
+        for (int64_t w = 0; w < total; ++w) {
+            const int64_t *pt = target_triples + 3 * w;
+            int64_t r = sample_int(rng, 0, num_triples - 1);
+            for (int checks = 0; triples[3 * r] == pt[0] && triples[3 * r + 1] == pt[1] && triples[3 * r + 2] == pt[2] &&
+                                 checks <= 100; ++checks)
+                r = sample_int(rng, 0, num_triples - 1);
+            copy_row(neg + 3 * w, r);
+        }
+    }
+    return TRW_OK;
+}
