@@ -141,8 +141,8 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes,
  *                       the graph is read once per step.  Masks are worked out for entries one of whose rows
  *                       has at most 32 entries; the rest ask the table.
  *     TRW_PREP_MARKS    (implies BIASED) masks for every entry one of whose rows has at most 256 entries:
- *                       about 3.5x the prepare time, 30 % faster walks -- pays from about 3 walks of a graph
- *     TRW_PREP_MARKS_FULL (implies MARKS) ... at most 4096 entries: about 10x the prepare time, another 10 %
+ *                       about 3x the prepare time, 35 % faster walks -- pays from about 3 walks of a graph
+ *     TRW_PREP_MARKS_FULL (implies MARKS) ... at most 1024 entries: about 5x the prepare time, another 10 %
  *   or one of          TRW_PREP_ORDER_ONLY: no shadow, only the row-order probe the int64 biased kernels want;
  *                      TRW_PREP_NOTHING: header only (uniform walk on the per-walker stream)
  * trw_prepare_plan returns the `what` one call of the given shape is worth (what trw_walk_csr_hip builds).

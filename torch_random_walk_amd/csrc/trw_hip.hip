@@ -123,7 +123,7 @@ struct PrepLayout {
     bool ext16 = false;    // uniform: fat entries {v, start(v), deg(v)}, one gather per step
     bool biased = false;   // edge table + 32-byte fat entries
     bool marks = false;    // ... with the neighbourhood masks worked out for long rows too
-    bool marks_full = false;  // ... for rows up to 4096 entries (TRW_PREP_MARKS_FULL) instead of 256
+    bool marks_full = false;  // ... for rows up to 1024 entries (TRW_PREP_MARKS_FULL) instead of 256
     uint64_t hash_mask = 0;
     uint32_t heavy_room = 0;
     size_t off_row32 = 0, off_col32 = 0, off_ext16 = 0, off_table = 0, off_ext32 = 0, off_heavy = 0, total = 0;
@@ -503,11 +503,12 @@ int trw_prepare_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *
             // Rows up to inline_cap are marked by the thread that owns the entry; with TRW_PREP_MARKS longer ones (up
             // to heavy_cap) go through the wave-per-entry pass.  Measured on R-MAT 10M/110M (prepare ms -> walk ms of
             // the 8e8-step batch): inline 8: 22 -> 101; inline 32: 36 -> 86; inline 64: 72 -> 72; inline 32 + heavy
-            // 256: 128 -> 58; + heavy 1024: 252 -> 52.5; + heavy 4096: 390 -> 52 (one random table probe per entry
-            // of the shorter row: the pass runs at the memory system's gather ceiling).
+            // 256: 128 -> 58; + heavy 1024: 252 -> 52.5; + heavy 4096: 390 -> 52 with one random table probe per entry
+            // of the shorter row in both passes; the heavy pass bisects the (sorted, L2-resident) long rows instead
+            // since: inline 32 + heavy 256: 107 -> 58; + heavy 1024: 178 -> 52; + heavy 4096: 248 -> 53 (no better).
             const uint32_t inline_cap = (uint32_t)env_long("TRW_COMMON_MAX", 0, 4096, 32);
             const uint32_t heavy_cap =
-                pl.marks ? (uint32_t)env_long("TRW_HEAVY_MAX", 0, 1 << 20, pl.marks_full ? 4096 : 256) : 0u;
+                pl.marks ? (uint32_t)env_long("TRW_HEAVY_MAX", 0, 1 << 20, pl.marks_full ? 1024 : 256) : 0u;
             HeavyItem *heavy = pl.marks ? (HeavyItem *)(ws + pl.off_heavy) : nullptr;
             csr_ext32_kernel<<<stream_grid((nnz + 7) / 8), kBlock, 0, stream>>>(
                 row32, col32, n_nodes, nnz, table, pl.hash_mask, inline_cap, heavy_cap,

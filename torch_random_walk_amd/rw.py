@@ -61,8 +61,8 @@ def prepare(row_ptr, col_idx, biased=True, uniform=False, marks=True):
     ``walk`` does this by itself -- the first call over a graph prepares what one call is worth, the second
     node2vec call adds the full neighbourhood masks -- so ``prepare`` is only a way to pay up front:
     ``biased``: edge table + 32-byte fat entries (node2vec walks); ``marks``: with the neighbourhood masks of rows
-    up to 256 entries (about 3.5x the time, 30 % faster walks), ``marks="full"``: up to 4096 entries (about 10x the
-    time, another 10 %: for graphs walked dozens of times); ``uniform``: 16-byte fat entries for ``p == q == 1``.
+    up to 256 entries (about 3x the time, 35 % faster walks), ``marks="full"``: up to 1024 entries (about 5x the
+    time, another 10 %: for graphs walked a dozen times or more); ``uniform``: 16-byte fat entries for ``p == q == 1``.
     Valid while the two tensors are alive and not written to (an in-place write re-prepares on the next walk).
     Returns the ``PREP_*`` bits the cached graph holds.
     """
