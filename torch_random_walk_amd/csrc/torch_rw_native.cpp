@@ -368,13 +368,33 @@ torch::Tensor walk_ex(const torch::Tensor &row_ptr, const torch::Tensor &col_idx
                                        (int32_t)seed, (int32_t)rng_mode, walks.data_ptr<int64_t>(),
                                        workspace.data_ptr(), ws_bytes, hs);
     } else {
-        const size_t ws_bytes =
-            trw_walk_csr_workspace_bytes(n_nodes, nnz, n_walkers, (int32_t)walk_length, p, q, (int32_t)rng_mode);
-        workspace = torch::empty({(int64_t)ws_bytes}, rp.options().dtype(torch::kUInt8));
+        // self-contained call (cache off, capture in progress, temporaries): prepare into this call's own scratch.
+        // When the device is short of memory the prepared part is retried leaner -- the edge table and the fat entries
+        // are optional, the walk then takes the kernel that does without (the reference needs no scratch at all).
+        const size_t call_bytes =
+            trw_walk_csr_prepared_workspace_bytes(n_walkers, (int32_t)walk_length, p, q, (int32_t)rng_mode);
+        const int32_t ladder[3] = {needed, needed > 0 ? 0 : needed, needed >= 0 ? TRW_PREP_ORDER_ONLY : needed};
+        torch::Tensor blob;
+        int32_t what = needed;
+        for (int k = 0; k < 3; ++k) {
+            if (k > 0 && ladder[k] == ladder[k - 1]) continue;
+            what = ladder[k];
+            try {
+                blob = torch::empty({(int64_t)trw_prepare_csr_bytes(n_nodes, nnz, what)}, rp.options().dtype(torch::kUInt8));
+                break;
+            } catch (const c10::OutOfMemoryError &) {
+                if (k == 2) throw;
+            }
+        }
+        workspace = torch::empty({(int64_t)call_bytes}, rp.options().dtype(torch::kUInt8));
         pybind11::gil_scoped_release nogil;
-        rc = trw_walk_csr_hip(rp.data_ptr<int64_t>(), n_nodes, ci.data_ptr<int64_t>(), nnz, tg.data_ptr<int64_t>(),
-                              n_walkers, walker_base, p, q, (int32_t)walk_length, (int32_t)seed, (int32_t)rng_mode,
-                              walks.data_ptr<int64_t>(), workspace.data_ptr(), ws_bytes, hs);
+        rc = trw_prepare_csr_hip(rp.data_ptr<int64_t>(), n_nodes, ci.data_ptr<int64_t>(), nnz, what, blob.data_ptr(),
+                                 (size_t)blob.numel(), hs);
+        if (rc == TRW_OK)
+            rc = trw_walk_csr_prepared_hip(blob.data_ptr(), (size_t)blob.numel(), what, rp.data_ptr<int64_t>(), n_nodes,
+                                           ci.data_ptr<int64_t>(), nnz, tg.data_ptr<int64_t>(), n_walkers, walker_base, p,
+                                           q, (int32_t)walk_length, (int32_t)seed, (int32_t)rng_mode,
+                                           walks.data_ptr<int64_t>(), workspace.data_ptr(), call_bytes, hs);
     }
     TORCH_CHECK(rc == TRW_OK, "torch_rw walk failed (", rc, "): ", trw_last_error());
     finish_status(workspace, hs, check_mode, "walk");
