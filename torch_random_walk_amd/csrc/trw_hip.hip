@@ -587,7 +587,7 @@ static int walk_prepared(const void *prepared, size_t prepared_bytes, int32_t wh
     if (mode < 0) return fail(TRW_E_RNG_MODE, "unknown rng_mode");
     if (mode == TRW_RNG_GLIBC && !uniform && walker_base != 0)
         return fail(TRW_E_RNG_MODE, "TRW_RNG_GLIBC biased walks replay one serial stream: walker_base must be 0");
-    if (!uniform && what == TRW_PREP_NOTHING)
+    if (!uniform && what == TRW_PREP_NOTHING && n_walkers > 0)
         return fail(TRW_E_ARG, "a biased walk needs the row order: prepare with TRW_PREP_ORDER_ONLY at least");
     const unsigned __int128 last_pos = ((unsigned __int128)walker_base + (unsigned __int128)n_walkers) *
                                        (unsigned __int128)walk_length;
