@@ -1820,7 +1820,15 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
             uint32_t rejected = P[PF_REJ][slot];
             uint32_t w1 = P[PF_W1][slot], w2 = P[PF_W2][slot], w3 = P[PF_W3][slot], blk_at = P[PF_BLK][slot];
             const uint64_t gw = (uint64_t)walker_base + (uint64_t)P[PF_WALKER][slot];
-            uint32_t verdict = 0u, at = 0u;
+            // outcome of the lane's last trial: accepted / the candidate has to be looked at (filter bit) / neither
+            bool take = false, test = false;
+            uint32_t at = 0u;
+            // (looking at the runaway-rejection cap only when some lane is within a burst of it -- TRW_LAZY_CAP=1 --
+            // measured 1.5 % SLOWER than the plain per-trial compare: kept as the A/B switch it was)
+#ifndef TRW_LAZY_CAP
+#define TRW_LAZY_CAP 0
+#endif
+            const bool near_cap = TRW_LAZY_CAP ? __ballot(busy && rejected + 2u * kPoolPairs >= kTrialCap) != 0 : true;
 
             auto trial = [&](uint32_t rc, uint32_t ru) {
                 if (kCount) ++n_trials;
@@ -1828,15 +1836,21 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                 const uint32_t k = (idx >> 5) & 3u;
                 const uint32_t word = k == 0u ? m0 : (k == 1u ? m1 : (k == 2u ? m2 : m3));
                 const bool bit = (word >> (idx & 31u)) & 1u;
+                // verdict 0 reject / 1 accept / 2 look at the candidate, by selects: the same logic written as lane-mask
+                // algebra (compares + scalar and/or) measured 59 ms instead of 52 -- with three waves per SIMD the
+                // VALU -> SALU -> exec round trips cost more than the v_cndmask chain
                 const uint32_t v_band = bit ? (exact ? v_set_exact : 2u) : v_clear;
                 const uint32_t v_other = ru < bp.lo ? 1u : (ru >= bp.hi ? 0u : v_band);
                 uint32_t v = (idx - pos_lo < pos_cnt) ? (ru < bp.t0 ? 1u : 0u) : v_other;
                 rejected = v == 0u ? rejected + 1u : rejected;
-                if (rejected >= kTrialCap) {  // take whatever this trial drew
-                    st |= (uint32_t)kStTrialCap;
-                    v = 1u;
+                if (near_cap) {
+                    if (rejected >= kTrialCap) {  // take whatever this trial drew
+                        st |= (uint32_t)kStTrialCap;
+                        v = 1u;
+                    }
                 }
-                verdict = v;
+                take = v == 1u;
+                test = v == 2u;
                 at = t_start + idx;
             };
             bool running = busy;
@@ -1855,7 +1869,7 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                         ++blk_at;
                     }
                     odd = !was_odd;
-                    if (verdict == 0u) {  // second trial of the pair
+                    if (!(take || test)) {  // second trial of the pair
                         trial((was_odd ? w1 : w3) >> 1, (was_odd ? w2 : nb[0]) >> 1);
                         if (!was_odd) {
                             w1 = nb[1];
@@ -1865,7 +1879,7 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                         }
                         odd = was_odd;
                     }
-                    running = verdict == 0u;
+                    running = !(take || test);
                 }
             }
             // write back what moved
@@ -1877,10 +1891,10 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                 P[PF_BLK][slot] = blk_at;
                 P[PF_REJ][slot] = rejected;
                 uint32_t nf = (flags & kPfExact) | (odd ? kPfOdd : 0u);
-                if (verdict != 0u) {
+                if (take || test) {
                     if (kCount) ++n_fetch;
                     P[PF_AT][slot] = at;
-                    nf |= (verdict == 1u ? PK_ENTRY : PK_TEST) << 4;
+                    nf |= (take ? PK_ENTRY : PK_TEST) << 4;
                     to_issue = true;
                 } else {
                     to_trial = true;
