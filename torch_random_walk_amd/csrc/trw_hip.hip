@@ -691,7 +691,12 @@ static int walk_prepared(const void *prepared, size_t prepared_bytes, int32_t wh
         if (pool_kernel) {
             // 3 workgroups per CU: a wave's pool is 11 KB of LDS (kPoolSlots walkers x 22 words), 51 KB per workgroup
             int64_t pblocks = (n_walkers + (int64_t)kPoolWaves * kPoolSlots - 1) / ((int64_t)kPoolWaves * kPoolSlots);
-            const int64_t president = (int64_t)device_cu_count() * env_long("TRW_POOL_BLOCKS", 1, 4, 3);
+            // TRW_POOL_SPARE_BLOCKS: workgroups to leave out of the persistent grid.  With every CU holding three of them
+            // a kernel on another stream (an RCCL send/recv group) does not get on the chip until the walk is over
+            // (scripts/overlap_probe.py); a few CUs with only two leave it room.  bench.py sets it for N > 1.
+            int64_t president = (int64_t)device_cu_count() * env_long("TRW_POOL_BLOCKS", 1, 4, 3) -
+                                env_long("TRW_POOL_SPARE_BLOCKS", 0, 512, 0);
+            if (president < 1) president = 1;
             if (pblocks > president) pblocks = president;
             if (g_prof.count)
                 biased_pool_kernel<true><<<(unsigned)pblocks, kBlock, 0, stream>>>(
