@@ -163,3 +163,33 @@ def test_config4_papers100m_sharded_equals_unsharded():
     for r, g in zip(rows, got):
         ref = O.walk(rp_s, ci_s, np.array([r]), 1.0, 1.0, L, seed, rng_mode=O.RNG_GLIBC_INDEXED, walker_base=int(r))
         assert (ref[0] == g).all(), "row %d differs from the oracle" % r
+
+
+def test_config4_graph_node2vec_shard_keeps_the_table_path():
+    """The node2vec walk at BASELINE configs[3] scale: 1.71 G entries used to be beyond the edge
+    table's 2^31-slot cap, which silently sent such graphs to the bisection kernel.  Slot arithmetic is 64-bit now:
+    the prepared graph holds a 2^32-slot table (69 GB) + 32-byte entries (55 GB), one GPU's shard of the start nodes
+    (13.9 M walkers, global walker indices of shard 5) walks on the walker-pool kernel, and sampled rows equal the
+    oracle's per-walker stream."""
+    from torch_random_walk_amd import graphs
+    from torch_random_walk_amd.dist import shard_bounds
+    from torch_rw import rw
+    rw.clear_cache()
+    n, L, seed = 111_000_000, 80, 10
+    rp, ci = graphs.rmat(n, 1_600_000_000, seed=1, device=DEV)
+    lo, hi, _ = shard_bounds(n, 8, 5)
+    tg = torch.arange(lo, hi, device=DEV)
+    w = rw.walk_ex(rp, ci, tg, 0.25, 4.0, L, seed, walker_base=lo, rng_mode=rw.RNG_WALKER, check=True)
+    info = rw.cache_info()
+    assert len(info) == 1 and info[0][2] & rw.PREP_BIASED, info
+    assert info[0][3] > 16 * 2**32 + 32 * ci.numel()             # the table really has 2^32 slots
+    assert torch.equal(w[:, 0], tg) and int(w.min()) >= 0 and int(w.max()) < n
+    rows = np.unique(np.concatenate([[0, 1, hi - lo - 1], np.random.default_rng(0).integers(0, hi - lo, 21)]))
+    got = w[torch.as_tensor(rows, device=DEV)].cpu().numpy()
+    rp_s, ci_s = _sparse_host_csr(rp, ci, np.unique(got))
+    for r, g in zip(rows, got):
+        ref = O.walk(rp_s, ci_s, np.array([lo + r]), 0.25, 4.0, L, seed, rng_mode=O.RNG_WALKER, walker_base=int(lo + r))
+        assert (ref[0] == g).all(), "row %d differs from the oracle" % r
+    del w
+    rw.clear_cache()
+    torch.cuda.empty_cache()
