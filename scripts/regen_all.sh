@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX: rocprofv3 stats + PMC passes for every bench workload, condensed into
 # gpurun_out/collected/ (the raw traces are too big to travel back), then the bench lines themselves with CPU
 # baselines.  Afterwards, here: cp gpurun_out/collected/* profiles/
-TAG=${1:-r01}
+TAG=${1:-r02}
 WLS=${2:-"rmat10m_biased rmat10m_uniform er100k_uniform kg5m_triples elist_rmat1m_uniform elist_rmat1m_biased windows_1m"}
 mkdir -p gpurun_out/collected
 for w in $WLS; do
@@ -12,7 +12,7 @@ for w in $WLS; do
   echo "profiled $w"
 done
 cp gpurun_out/collected/pmc_traffic.json profiles/pmc_traffic.json   # bench.py reads traffic / misses from here
-for w in default rmat10m_uniform er100k_uniform papers100m_uniform kg5m_triples elist_rmat1m_uniform elist_rmat1m_biased windows_1m; do
+for w in default rmat10m_uniform er100k_uniform papers100m_uniform papers100m_biased kg5m_triples elist_rmat1m_uniform elist_rmat1m_biased windows_1m; do
   if [ $w = default ]; then ARG=""; else ARG="--workload $w"; fi
   timeout -k 10 300 python3 bench.py $ARG > gpurun_out/collected/${TAG}_bench_$w.json 2> gpurun_out/collected/bench_$w.err || echo "bench $w failed"
   echo "bench $w done"

@@ -92,6 +92,15 @@ if args.count:
     L.trw_walk_counters(ws.data_ptr(), stream, c)
     extra = " counters/step: trials %.2f fetch %.3f tests %.3f probes %.3f" % tuple(x / (B * args.L) for x in c)
     raw = ws[:256].view(torch.int64).cpu().tolist()
+    if st[3] == 5:  # the walker-pool kernel's wave counters (status[12..23])
+        it, ap, al, ip, il, bp_, bl, tp, c0, c1, c2, c3 = raw[12:24]
+        cyc = max(1, c0 + c1 + c2 + c3)
+        extra += ("\n    pool: wave iterations %.3e; adopt passes/iter %.2f (%.1f lanes), issue %.2f (%.1f), burst %.2f (%.1f lanes, "
+                  "%.2f pair passes, trial lane util %.1f%%); wall cycles adopt %.1f%% refill %.1f%% issue %.1f%% burst %.1f%% "
+                  "(%.0f cycles / iteration)" % (it, ap / it, al / max(1, ap), ip / it, il / max(1, ip), bp_ / it, bl / max(1, bp_),
+                                                 tp / max(1, bp_), 100.0 * c[0] / max(1, tp * 128), 100.0 * c0 / cyc, 100.0 * c1 / cyc,
+                                                 100.0 * c2 / cyc, 100.0 * c3 / cyc, cyc / it))
+        raw[12] = 0
     iters, reps, refills, ad = raw[12], raw[13], raw[14], raw[15]
     adopts, adopt_lanes = ad >> 40, ad & ((1 << 40) - 1)
     if iters:

@@ -139,6 +139,39 @@ def test_every_marking_path_walks_the_same_rows(rw, deg, inline_cap, monkeypatch
     assert rw.cache_info()[0][2] == full
 
 
+@pytest.mark.parametrize("env", [{}, {"TRW_POOL_KERNEL": "0"}, {"TRW_HASH_SLACK": "2", "TRW_COMMON_MAX": "0"}])
+def test_parallel_edges_beyond_the_packed_run_and_long_probe_chains(rw, env, monkeypatch):
+    """An entry packs "where t sits in prev's row" as multiplicity (4 bits) and first offset: pairs joined by more
+    than 15 parallel edges go through the table instead, and the walker pool then keeps the run where two of its
+    mask words were.  With a table at load 1/2 and no masks every in-band trial is a table lookup, some of them
+    with probe chains longer than the pool's 3-bit probe counter."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(5)
+    n = 300
+    src = [rng.integers(0, n, 4000)]
+    dst = [rng.integers(0, n, 4000)]
+    for a, b, m_ab, m_ba in ((0, 1, 40, 40), (2, 3, 16, 16), (4, 5, 15, 15), (6, 7, 17, 1), (8, 9, 1, 300), (10, 10, 20, 0)):
+        src += [np.full(m_ab, a), np.full(m_ba, b)]
+        dst += [np.full(m_ab, b), np.full(m_ba, a)]
+    src.append(np.arange(n))                 # no dead ends
+    dst.append((np.arange(n) + 1) % n)
+    src, dst = np.concatenate(src), np.concatenate(dst)
+    order = np.lexsort((dst, src))
+    src, dst = src[order], dst[order]
+    rp = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(rp, src + 1, 1)
+    rp = np.cumsum(rp)
+    ci = dst.astype(np.int64)
+    tg = np.concatenate([np.arange(12).repeat(300), rng.integers(0, n, 3000)])
+    d = _dev(rp, ci, tg)
+    for p, q in ((0.25, 4.0), (4.0, 0.25), (0.5, 1.0)):
+        ref = O.walk(rp, ci, tg, p, q, 30, 3, rng_mode=O.RNG_WALKER)
+        for _ in range(3):                   # cold, marks, served from the cache
+            assert (rw.walk_ex(*d, p, q, 30, 3, rng_mode=rw.RNG_WALKER).cpu().numpy() == ref).all()
+    rw.check_status()
+
+
 @pytest.mark.parametrize("env", [{"TRW_MASK_KERNEL": "0"}, {"TRW_MASK_KERNEL": "0", "TRW_NO_POS": "1"},
                                  {"TRW_RESIDENT_BLOCKS": "1"}, {"TRW_HASH_SLACK": "2", "TRW_RESIDENT_BLOCKS": "8"}])
 def test_mask_kernel_and_state_machine_kernel_agree(rw, env, monkeypatch):

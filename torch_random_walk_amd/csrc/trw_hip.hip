@@ -689,12 +689,12 @@ static int walk_prepared(const void *prepared, size_t prepared_bytes, int32_t wh
         // 32-bit walker numbers; TRW_POOL_KERNEL=0 runs the lane-per-walker mask kernel instead
         const bool pool_kernel = mask_kernel && n_walkers < ((int64_t)1 << 32) && env_long("TRW_POOL_KERNEL", 0, 1, 1) == 1;
         if (pool_kernel) {
-            // 3 workgroups per CU: a wave's pool is 11 KB of LDS (kPoolSlots walkers x 22 words), 51 KB per workgroup
+            // 4 workgroups per CU: a wave's pool is 9.9 KB of LDS (kPoolSlots walkers x 19 words), 39.5 KB per workgroup
             int64_t pblocks = (n_walkers + (int64_t)kPoolWaves * kPoolSlots - 1) / ((int64_t)kPoolWaves * kPoolSlots);
             // TRW_POOL_SPARE_BLOCKS: workgroups to leave out of the persistent grid.  With every CU holding three of them
             // a kernel on another stream (an RCCL send/recv group) does not get on the chip until the walk is over
             // (scripts/overlap_probe.py); a few CUs with only two leave it room.  bench.py sets it for N > 1.
-            int64_t president = (int64_t)device_cu_count() * env_long("TRW_POOL_BLOCKS", 1, 4, 3) -
+            int64_t president = (int64_t)device_cu_count() * env_long("TRW_POOL_BLOCKS", 1, 8, 4) -
                                 env_long("TRW_POOL_SPARE_BLOCKS", 0, 512, 0);
             if (president < 1) president = 1;
             if (pblocks > president) pblocks = president;

@@ -1529,10 +1529,13 @@ biased_mask_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
 #define TRW_POOL_PAIRS 2
 #endif
 constexpr int kPoolSlots = TRW_POOL_SLOTS;  // walkers resident per wave (<= 128; about 2 per lane keeps every phase fed)
-constexpr int kQueueCap = 128;              // ring capacity of the slot queues (a power of two >= kPoolSlots)
+constexpr int kQueueCap = TRW_POOL_SLOTS > 128 ? 256 : 128;  // ring capacity of the slot queues (a power of two >= kPoolSlots)
 constexpr int kPoolPairs = TRW_POOL_PAIRS;  // Philox blocks (pairs of trials) per visit of the burst
 constexpr int kPoolWaves = kBlock / 64;
 // A phase runs when its queue holds at least this many slots (or when nothing else can make progress)
+#ifndef TRW_POOL_FIRST_IN_BURST
+#define TRW_POOL_FIRST_IN_BURST 1
+#endif
 #ifndef TRW_POOL_ISSUE_MIN
 #define TRW_POOL_ISSUE_MIN 48
 #endif
@@ -1541,16 +1544,23 @@ constexpr int kPoolWaves = kBlock / 64;
 #endif
 constexpr uint32_t kPoolIssueMin = TRW_POOL_ISSUE_MIN, kPoolTrialMin = TRW_POOL_TRIAL_MIN;
 enum : uint32_t { PK_ROW = 0, PK_ENTRY = 1, PK_TEST = 2, PK_MEMBER = 3, PK_POS = 4 };  // what a slot's gather is for
+// 19 words per walker: with 128 walkers per wave that is 9.9 KB of LDS, 39.5 KB per workgroup, FOUR workgroups per CU
+// (160 KB) -- 22 words fitted three, and both the waves per SIMD and the walkers per wave pay (measured).
 enum : int {
-    PF_T = 0, PF_PREV, PF_START, PF_DEG, PF_Z, PF_POSLO, PF_POSCNT, PF_M0, PF_M1, PF_M2, PF_M3,
-    PF_FLAGS,   // bit 0: mask is exact, bit 1: next trial is an odd one, bits 4..6: PK_* of the queued / in-flight gather
-    PF_S, PF_REJ, PF_WALKER, PF_W1, PF_W2, PF_W3, PF_BLK,
+    PF_T = 0, PF_PREV, PF_START, PF_DEG, PF_Z,
+    PF_RPOS,    // where t sits in prev's row, packed as in the entry: multiplicity << 28 | first offset (0: nowhere)
+    PF_M0, PF_M1, PF_M2, PF_M3,  // (kPfWide: M2 / M3 = first offset / multiplicity instead, the mask reads as all ones)
+    PF_FLAGS,   // bits 0..3 kPf*, bits 4..6 PK_* of the queued / in-flight gather, bits 8..28 rejections at this step,
+                // bits 29..31 how far the probe chain of the current table lookup has gone
+    PF_S, PF_WALKER, PF_W1, PF_W2, PF_W3, PF_BLK,
     PF_X,       // the candidate node a table probe asks about
     PF_AT,      // fat entry index to gather
-    PF_PROBE,   // how far the probe chain of the current table lookup has gone
     PF_COUNT
 };
-constexpr uint32_t kPfExact = 1u, kPfOdd = 2u;
+// kPfFirst: the slot's next draw is the walk's first step; kPfWide: t's run in prev's row does not fit PF_RPOS
+constexpr uint32_t kPfExact = 1u, kPfOdd = 2u, kPfFirst = 4u, kPfWide = 8u;
+constexpr uint32_t kPfKind = 7u << 4, kPfRejShift = 8, kPfRejMask = 0x1FFFFFu << 8, kPfProbeShift = 29, kPfProbe = 7u << 29;
+static_assert(kTrialCap <= (kPfRejMask >> kPfRejShift), "the rejection count must fit its field");
 
 struct PoolQueue {  // a ring of slot numbers (bytes) in LDS; head/count are wave-uniform
     uint8_t *q;
@@ -1590,7 +1600,7 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                    int64_t *__restrict__ out, int64_t *__restrict__ status)
 {
     static_assert(kPoolSlots >= 64 && kPoolSlots <= kQueueCap && (kQueueCap & (kQueueCap - 1)) == 0 && kQueueCap <= 256,
-                  "pool size must be 64..128 slots (slot numbers travel as bytes)");
+                  "pool size must be 64..256 slots (slot numbers travel as bytes)");
     if (status[kStDescents] != status[kStBoundary]) return;  // unsorted rows: biased_hash_kernel's job
     __shared__ uint32_t pool_mem[kPoolWaves][PF_COUNT][kPoolSlots];
     __shared__ uint8_t queue_mem[kPoolWaves][3][kQueueCap];
@@ -1615,6 +1625,16 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
     uint32_t hs = 0, hkind = 0;
     u32x4_a4 e0 = {0u, 0u, 0u, 0u}, e1 = {0u, 0u, 0u, 0u};
     bool more_walkers = true;  // wave-uniform: the device counter has not run out yet
+    // counting variant only: passes / lanes / shader-clock cycles per phase of this wave (status[12..23])
+    uint64_t w_iters = 0, w_pass[3] = {0, 0, 0}, w_lanes[3] = {0, 0, 0}, w_cycles[4] = {0, 0, 0, 0}, w_trial_passes = 0;
+    uint64_t t_mark = kCount ? clock64() : 0;
+    auto lap = [&](int phase) {
+        if (kCount) {
+            const uint64_t now = clock64();
+            w_cycles[phase] += now - t_mark;
+            t_mark = now;
+        }
+    };
 
     // Columns go out one 8-byte store each: this kernel runs out of instruction issue, not of write requests, and
     // a plain store is an address and one instruction where combining four columns cost 25 and four words of state.
@@ -1624,6 +1644,14 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
         // ================= adopt: consume the gathers issued in the previous iteration =================
         {
             bool to_trial = false, to_issue = false, to_free = false;
+            if (kCount) {
+                const unsigned long long hb = __ballot(hold);
+                ++w_iters;
+                if (hb) {
+                    ++w_pass[0];
+                    w_lanes[0] += (uint64_t)__popcll(hb);
+                }
+            }
             if (hold) {
                 const uint32_t slot = hs;
                 if (hkind == PK_ROW) {  // e0 = row32[start node], row32[start node + 1]
@@ -1634,7 +1662,21 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                         int64_t *r = row_of(slot);
                         for (int32_t s = 1; s <= L; ++s) r[s] = (int64_t)prev;
                         to_free = true;
-                    } else {  // first step: plain uniform neighbour, draw 0 (rw_cpu.cpp:159)
+                    } else {  // first step: plain uniform neighbour, draw 0 (rw_cpu.cpp:159).  Its Philox block is
+                        // NOT worked out here: a wave adopts a start row in almost every other iteration, one lane
+                        // at a time, and ten rounds for one lane cost what they cost for 64.  The slot goes to the
+                        // burst as an "odd trial on block -1": the burst's next block is block 0, word 0 is the draw.
+#if TRW_POOL_FIRST_IN_BURST
+                        FastMod fm;
+                        fm.init(deg);
+                        P[PF_START][slot] = start;
+                        P[PF_DEG][slot] = deg;
+                        P[PF_Z][slot] = fm.z;
+                        P[PF_RPOS][slot] = 0u;
+                        P[PF_BLK][slot] = 0xFFFFFFFFu;
+                        P[PF_FLAGS][slot] = kPfOdd | kPfFirst;
+                        to_trial = true;
+#else  // (the A/B baseline: the block worked out where the row arrives)
                         uint32_t blk[4];
                         walker_block((uint64_t)walker_base + (uint64_t)P[PF_WALKER][slot], 0u, seed, blk);
                         P[PF_W1][slot] = blk[1];
@@ -1645,6 +1687,7 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                         P[PF_FLAGS][slot] = PK_ENTRY << 4;
                         if (kCount) ++n_fetch;
                         to_issue = true;
+#endif
                     }
                 } else if (hkind == PK_ENTRY) {  // e0, e1 = the accepted entry: step onto it
                     const uint32_t x = e0.x;
@@ -1673,16 +1716,13 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                         P[PF_M2][slot] = e1.z;
                         P[PF_M3][slot] = e1.w;
                         P[PF_S][slot] = (uint32_t)s;
-                        P[PF_REJ][slot] = 0u;
-                        const uint32_t keep = P[PF_FLAGS][slot] & kPfOdd;
+                        P[PF_RPOS][slot] = e0.w;
+                        const uint32_t keep = P[PF_FLAGS][slot] & kPfOdd;  // (rejections and probe count start at 0)
                         const uint32_t ex = (e0.z & kMaskIsFilter) ? 0u : kPfExact;
                         if (e0.w == kRposLookup) {  // too many parallel edges / too far into the row for the packed form
                             P[PF_FLAGS][slot] = keep | ex | (PK_POS << 4);
-                            P[PF_PROBE][slot] = 0u;
                             to_issue = true;
                         } else {
-                            P[PF_POSLO][slot] = e0.w & 0x0FFFFFFFu;
-                            P[PF_POSCNT][slot] = e0.w >> 28;
                             P[PF_FLAGS][slot] = keep | ex;
                             to_trial = true;
                         }
@@ -1690,38 +1730,62 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                 } else if (hkind == PK_TEST) {  // e0.x = a candidate whose mask bit is only a filter: ask the table
                     if (kCount) ++n_tests;
                     P[PF_X][slot] = e0.x;
-                    P[PF_PROBE][slot] = 0u;
-                    P[PF_FLAGS][slot] = (P[PF_FLAGS][slot] & 15u) | (PK_MEMBER << 4);
+                    P[PF_FLAGS][slot] = (P[PF_FLAGS][slot] & ~(kPfKind | kPfProbe)) | (PK_MEMBER << 4);
                     to_issue = true;
                 } else {  // PK_MEMBER / PK_POS: e0 = {u, v, lo, cnt-1} of one table slot
                     if (kCount) ++n_probes;
                     const uint32_t t = P[PF_T][slot], prev = P[PF_PREV][slot];
-                    const bool empty = e0.x == 0xFFFFFFFFu;
-                    const bool match = hkind == PK_MEMBER ? (e0.x == t && e0.y == P[PF_X][slot]) : (e0.x == prev && e0.y == t);
+                    const uint32_t ku = hkind == PK_MEMBER ? t : prev, kv = hkind == PK_MEMBER ? P[PF_X][slot] : t;
+                    uint32_t flags = P[PF_FLAGS][slot];
+                    bool empty = e0.x == 0xFFFFFFFFu;
+                    bool match = e0.x == ku && e0.y == kv;
+                    if (!empty && !match && (flags & kPfProbe) == kPfProbe) {
+                        // the chain is longer than the probe field counts: this lane walks the rest of it here
+                        uint64_t sl = (edge_slot(ku, kv, mask) + 8u) & mask;
+                        while (true) {
+                            const u32x4_a16 g = *reinterpret_cast<const u32x4_a16 *>(table + 4 * sl);
+                            if (kCount) ++n_probes;
+                            empty = g.x == 0xFFFFFFFFu;
+                            match = g.x == ku && g.y == kv;
+                            if (empty || match) {
+                                e0.z = g.z;
+                                e0.w = g.w;
+                                break;
+                            }
+                            sl = (sl + 1u) & mask;
+                        }
+                    }
                     if (!empty && !match) {
-                        P[PF_PROBE][slot] += 1u;
+                        P[PF_FLAGS][slot] = flags + (1u << kPfProbeShift);
                         to_issue = true;
                     } else if (hkind == PK_POS) {  // where t sits in prev's row
-                        P[PF_POSLO][slot] = match ? e0.z : 0u;
-                        P[PF_POSCNT][slot] = match ? e0.w + 1u : 0u;
-                        P[PF_FLAGS][slot] &= 15u;
+                        const uint32_t lo = match ? e0.z : 0u, cnt = match ? e0.w + 1u : 0u;
+                        flags &= ~(kPfKind | kPfProbe);
+                        if (cnt <= 15u && lo < (1u << 28)) {
+                            P[PF_RPOS][slot] = cnt ? (cnt << 28 | lo) : 0u;
+                        } else {  // the run goes where two mask words were; the mask then says "look" for every offset
+                            P[PF_M2][slot] = lo;
+                            P[PF_M3][slot] = cnt;
+                            flags = (flags & ~kPfExact) | kPfWide;
+                        }
+                        P[PF_FLAGS][slot] = flags;
                         to_trial = true;
                     } else {  // the trial drew inside the band: a neighbour is accepted iff t1 is the upper threshold
                         bool accept = match == band_takes_near;
+                        flags &= ~(kPfKind | kPfProbe);
                         if (!accept) {
-                            const uint32_t rej = P[PF_REJ][slot] + 1u;
-                            P[PF_REJ][slot] = rej;
-                            if (rej >= kTrialCap) {
+                            flags += 1u << kPfRejShift;
+                            if (((flags & kPfRejMask) >> kPfRejShift) >= kTrialCap) {
                                 st |= (uint32_t)kStTrialCap;
                                 accept = true;
                             }
                         }
                         if (accept) {  // gather the entry again, this time to step onto it
-                            P[PF_FLAGS][slot] = (P[PF_FLAGS][slot] & 15u) | (PK_ENTRY << 4);
+                            P[PF_FLAGS][slot] = flags | (PK_ENTRY << 4);
                             if (kCount) ++n_fetch;
                             to_issue = true;
                         } else {
-                            P[PF_FLAGS][slot] &= 15u;
+                            P[PF_FLAGS][slot] = flags;
                             to_trial = true;
                         }
                     }
@@ -1733,6 +1797,7 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
             hold = false;
             pool_fence();
         }
+        lap(0);
 
         // ================= refill: new walkers into free slots =================
         if (more_walkers && (free_q.count >= 32u || trial_q.count + issue_q.count < 64u) && free_q.count > 0u) {
@@ -1767,7 +1832,6 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                     P[PF_PREV][slot] = (uint32_t)tg;  // step 1 leaves the start node
                     P[PF_T][slot] = (uint32_t)tg;
                     P[PF_S][slot] = 1u;
-                    P[PF_REJ][slot] = 0u;
                     P[PF_FLAGS][slot] = PK_ROW << 4;
                     to_issue = true;
                 }
@@ -1776,14 +1840,20 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
             free_q.push(back, slot);
             pool_fence();
         }
+        lap(1);
         if (!more_walkers && free_q.count == (uint32_t)kPoolSlots) break;  // every walker of this wave is done
 
         // ================= issue: gathers for the slots that want one =================
         if (issue_q.count >= kPoolIssueMin || (issue_q.count > 0u && trial_q.count < kPoolTrialMin)) {
             uint32_t n, slot;
             issue_q.pop(lane, n, slot);
+            if (kCount) {
+                ++w_pass[1];
+                w_lanes[1] += n;
+            }
             if ((uint32_t)lane < n) {
-                const uint32_t kind = P[PF_FLAGS][slot] >> 4;
+                const uint32_t flags = P[PF_FLAGS][slot];
+                const uint32_t kind = (flags & kPfKind) >> 4;
                 const uint32_t *addr;
                 if (kind == PK_ENTRY || kind == PK_TEST) {
                     addr = reinterpret_cast<const uint32_t *>(ext + 2 * (size_t)P[PF_AT][slot]);
@@ -1792,7 +1862,7 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                 } else {
                     const uint32_t t = P[PF_T][slot], prev = P[PF_PREV][slot];
                     const uint64_t s0 = kind == PK_MEMBER ? edge_slot(t, P[PF_X][slot], mask) : edge_slot(prev, t, mask);
-                    addr = table + 4 * ((s0 + P[PF_PROBE][slot]) & mask);
+                    addr = table + 4 * ((s0 + (flags >> kPfProbeShift)) & mask);
                 }
                 e0 = *reinterpret_cast<const u32x4_a4 *>(addr);
                 if (kind == PK_ENTRY) e1 = *reinterpret_cast<const u32x4_a4 *>(addr + 4);
@@ -1802,22 +1872,28 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
             }
         }
 
+        lap(2);
         // ================= burst: trials for a wave of slots that are between gathers =================
         if (trial_q.count >= kPoolTrialMin || (trial_q.count > 0u && issue_q.count < kPoolIssueMin)) {
             uint32_t n, slot;
             trial_q.pop(lane, n, slot);
+            if (kCount) {
+                ++w_pass[2];
+                w_lanes[2] += n;
+            }
             bool busy = (uint32_t)lane < n;
             // the slot's trial state, into registers
             const uint32_t t_start = P[PF_START][slot], deg = P[PF_DEG][slot];
             FastMod fm;
             fm.d = busy ? deg : 1u;
             fm.z = P[PF_Z][slot];
-            const uint32_t pos_lo = P[PF_POSLO][slot], pos_cnt = P[PF_POSCNT][slot];
-            const uint32_t m0 = P[PF_M0][slot], m1 = P[PF_M1][slot], m2 = P[PF_M2][slot], m3 = P[PF_M3][slot];
-            const uint32_t flags = P[PF_FLAGS][slot];
-            const bool exact = (flags & kPfExact) != 0u;
+            const uint32_t flags = P[PF_FLAGS][slot], rpos = P[PF_RPOS][slot];
+            const bool exact = (flags & kPfExact) != 0u, first = (flags & kPfFirst) != 0u, wide = (flags & kPfWide) != 0u;
+            uint32_t m0 = P[PF_M0][slot], m1 = P[PF_M1][slot], m2 = P[PF_M2][slot], m3 = P[PF_M3][slot];
+            const uint32_t pos_lo = wide ? m2 : (rpos & 0x0FFFFFFFu), pos_cnt = wide ? m3 : (rpos >> 28);
+            if (wide) m0 = m1 = m2 = m3 = 0xFFFFFFFFu;
             bool odd = (flags & kPfOdd) != 0u;
-            uint32_t rejected = P[PF_REJ][slot];
+            uint32_t rejected = (flags & kPfRejMask) >> kPfRejShift;
             uint32_t w1 = P[PF_W1][slot], w2 = P[PF_W2][slot], w3 = P[PF_W3][slot], blk_at = P[PF_BLK][slot];
             const uint64_t gw = (uint64_t)walker_base + (uint64_t)P[PF_WALKER][slot];
             // outcome of the lane's last trial: accepted / the candidate has to be looked at (filter bit) / neither
@@ -1830,8 +1906,8 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
 #endif
             const bool near_cap = TRW_LAZY_CAP ? __ballot(busy && rejected + 2u * kPoolPairs >= kTrialCap) != 0 : true;
 
-            auto trial = [&](uint32_t rc, uint32_t ru) {
-                if (kCount) ++n_trials;
+            auto trial = [&](uint32_t rc, uint32_t ru, bool forced) {
+                if (kCount && !forced) ++n_trials;
                 const uint32_t idx = fm.mod(rc);
                 const uint32_t k = (idx >> 5) & 3u;
                 const uint32_t word = k == 0u ? m0 : (k == 1u ? m1 : (k == 2u ? m2 : m3));
@@ -1842,6 +1918,7 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                 const uint32_t v_band = bit ? (exact ? v_set_exact : 2u) : v_clear;
                 const uint32_t v_other = ru < bp.lo ? 1u : (ru >= bp.hi ? 0u : v_band);
                 uint32_t v = (idx - pos_lo < pos_cnt) ? (ru < bp.t0 ? 1u : 0u) : v_other;
+                v = forced ? 1u : v;  // the first step takes whatever it drew (no acceptance draw is consumed)
                 rejected = v == 0u ? rejected + 1u : rejected;
                 if (near_cap) {
                     if (rejected >= kTrialCap) {  // take whatever this trial drew
@@ -1857,11 +1934,12 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
 #pragma unroll 1
             for (int rep = 0; rep < kPoolPairs; ++rep) {
                 if (__ballot(running) == 0) break;
+                if (kCount) ++w_trial_passes;
                 if (running) {
                     uint32_t nb[4];
                     walker_block(gw, blk_at + 1u, seed, nb);
                     const bool was_odd = odd;
-                    trial((was_odd ? w3 : w1) >> 1, (was_odd ? nb[0] : w2) >> 1);
+                    trial((was_odd ? (first ? nb[0] : w3) : w1) >> 1, (was_odd ? nb[0] : w2) >> 1, first);
                     if (was_odd) {  // moved on to the next block (now an even trial on it)
                         w1 = nb[1];
                         w2 = nb[2];
@@ -1870,7 +1948,7 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                     }
                     odd = !was_odd;
                     if (!(take || test)) {  // second trial of the pair
-                        trial((was_odd ? w1 : w3) >> 1, (was_odd ? w2 : nb[0]) >> 1);
+                        trial((was_odd ? w1 : w3) >> 1, (was_odd ? w2 : nb[0]) >> 1, false);
                         if (!was_odd) {
                             w1 = nb[1];
                             w2 = nb[2];
@@ -1889,8 +1967,7 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                 P[PF_W2][slot] = w2;
                 P[PF_W3][slot] = w3;
                 P[PF_BLK][slot] = blk_at;
-                P[PF_REJ][slot] = rejected;
-                uint32_t nf = (flags & kPfExact) | (odd ? kPfOdd : 0u);
+                uint32_t nf = (flags & (kPfExact | kPfWide)) | (odd ? kPfOdd : 0u) | (rejected << kPfRejShift);
                 if (take || test) {
                     if (kCount) ++n_fetch;
                     P[PF_AT][slot] = at;
@@ -1905,12 +1982,16 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
             trial_q.push(to_trial, slot);
             pool_fence();
         }
+        lap(3);
     }
 
     if (st) atomicOr((unsigned long long *)&status[0], (unsigned long long)st);
     if (kCount) {
         const uint64_t a = wave_sum(n_trials), b = wave_sum(n_fetch), c = wave_sum(n_tests), d = wave_sum(n_probes);
         if (lane == 0) {
+            const uint64_t w[12] = {w_iters, w_pass[0], w_lanes[0], w_pass[1], w_lanes[1], w_pass[2], w_lanes[2],
+                                    w_trial_passes, w_cycles[0], w_cycles[1], w_cycles[2], w_cycles[3]};
+            for (int k = 0; k < 12; ++k) atomicAdd((unsigned long long *)&status[12 + k], (unsigned long long)w[k]);
             atomicAdd((unsigned long long *)&status[4], (unsigned long long)a);
             atomicAdd((unsigned long long *)&status[5], (unsigned long long)b);
             atomicAdd((unsigned long long *)&status[6], (unsigned long long)c);
