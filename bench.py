@@ -376,7 +376,7 @@ def main():
         kernel_name = "elist_walk_kernel"
     elif elist:
         # biased: the counting variant of the kernel through the C ABI (same walks), then bytes the algorithm as run
-        # must move: per walker 8 B target + 8 B index pair; 8 B per stored column; 64 B per entry gathered (every
+        # must move: per walker 8 B target + 8 B index pair; 8 B per stored column; 48 B read per entry gathered (every
         # accepted offset + the candidates the masks could not decide); 16 B per table slot read
         lib.trw_walk_edge_list_workspace_bytes.restype = ctypes.c_size_t
         lib.trw_walk_edge_list_workspace_bytes.argtypes = [ctypes.c_int64] * 3 + [ctypes.c_int32, ctypes.c_int64, ctypes.c_int32]
@@ -398,7 +398,7 @@ def main():
         if int(stw[3]) == 5:
             kernel_name = "elist_pool_kernel"
             counters = dict(trials=trials, entry_gathers=fetches, candidates_tested=tests, table_slots=probes)
-            alg_bytes = B * 16 + 8 * B * (L + 1) + 64 * fetches + 16 * probes
+            alg_bytes = B * 16 + 8 * B * (L + 1) + 48 * fetches + 16 * probes
         else:   # the lane-per-walker kernel loads every candidate (4 B) and an 8-byte index pair per step
             kernel_name = "elist_walk_kernel"
             alg_bytes = B * (16 + 40 * L)

@@ -992,9 +992,9 @@ static int walk_edge_list_prepared(const void *prepared, size_t prepared_bytes, 
                 narrow, targets, n_walkers, walker_base, walk_length, padding_idx, restart, (uint32_t)seed, bp,
                 el_table, pl.hash_mask, out, status);
         else if (pl.ent && n_walkers < ((int64_t)1 << 32) && env_long("TRW_ELPOOL", 0, 1, 1) == 1) {
-            // walker pool over the prepared entries: 2 workgroups per CU (a wave's pool: 128 walkers x 26 words + windows)
+            // walker pool over the prepared entries: 3 workgroups per CU (a wave's pool: 124 walkers x 22 words + windows)
             int64_t pblocks = (n_walkers + (int64_t)kPoolWaves * kElSlots - 1) / ((int64_t)kPoolWaves * kElSlots);
-            const int64_t president = (int64_t)device_cu_count() * env_long("TRW_ELPOOL_BLOCKS", 1, 4, 2);
+            const int64_t president = (int64_t)device_cu_count() * env_long("TRW_ELPOOL_BLOCKS", 1, 8, 3);
             if (pblocks > president) pblocks = president;
             if (g_prof.count)
                 elist_pool_kernel<true><<<(unsigned)pblocks, kBlock, 0, stream>>>(

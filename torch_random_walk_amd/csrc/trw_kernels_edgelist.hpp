@@ -403,13 +403,17 @@ elist_glibc_seq_kernel(EdgeListView<false> g, const int64_t *__restrict__ target
 //     word 0..3    v, first(v), cnt(v) (edges of v; 0: none), flags
 //     word 4..7    nb mask: bit (j & 127) = "the tail at offset j of v's range is in u's edges [first, last)"
 //                  -- the reference's is_neighbor(x, t), rw_cpu_edge_list.cpp:37-62, last edge excluded
-//     word 8..11   t mask:  bit (j & 127) = "the tail at offset j of v's range is u" -- tails keep their input
-//                  order, so the offsets that hold t are a set, not a run
-//     word 12      the only tail of v when cnt(v) == 1 (that step has a fixed candidate and draws nothing for it)
-// Exact for cnt(v) <= 128 (the range is scanned); for longer ranges both masks are 32-bit filters replicated
+//     word 8       where t = u sits in v's range -- tails keep their input order, so that is a set of offsets:
+//                      cnt(v) <= 32            bit j = "offset j holds u", exact
+//                      kElTmOffset             the ONE offset that holds u (0xFFFFFFFF: none), exact
+//                      kElTmLook               bit (j & 31) = "some offset == j (mod 32) may hold u": load it and see
+//     word 9       the only tail of v when cnt(v) == 1 (that step has a fixed candidate and draws nothing for it)
+// The nb mask is exact for cnt(v) <= 128 (the range is scanned); for longer ranges it is a 32-bit filter replicated
 // four times, built from the table's position masks by walking u's edges (kElFilter: clear = certainly not,
 // set = load the candidate and see); a range that holds the padding id as a tail is all "see" (kElHasPad).
-constexpr uint32_t kElFilter = 1u, kElHasPad = 2u;
+// (One word for t instead of a second 128-bit mask: the walker pool keeps a copy per walker in LDS, and three
+// words less per walker are a third workgroup per CU.)
+constexpr uint32_t kElFilter = 1u, kElHasPad = 2u, kElTmOffset = 4u, kElTmLook = 8u;
 #ifndef TRW_EL_FILTER_WALK
 #define TRW_EL_FILTER_WALK 256
 #endif
@@ -453,10 +457,9 @@ elist_ext_kernel(const int64_t *__restrict__ edges, int64_t n_edges, int64_t n_n
     for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n_edges; e += stride) {
         const int64_t head = edges[2 * e];
         const uint32_t v = tail32[e];
-        uint32_t first = kNoEdge, cnt = 0, flags = 0, only = 0;
-        Mask128 nb, tm;
+        uint32_t first = kNoEdge, cnt = 0, flags = 0, only = 0, tm = 0;
+        Mask128 nb;
         nb.clear();
-        tm.clear();
         if (v != pad && v < (uint32_t)n_nodes && (uint64_t)head < (uint64_t)n_nodes) {
             const uint32_t u = (uint32_t)head;
             const u32x2_a8 ix = ix32[v];
@@ -468,11 +471,24 @@ elist_ext_kernel(const int64_t *__restrict__ edges, int64_t n_edges, int64_t n_n
             uint32_t pm;
             bool in_range;
             if (cnt >= 1u && cnt <= 128u) {
+                uint32_t occ = 0, at = 0xFFFFFFFFu, m32 = 0;
                 for (uint32_t j = 0; j < cnt; ++j) {
                     const uint32_t x = tail32[first + j];
                     if (x == pad) flags |= kElHasPad;
-                    if (x == u) tm.set(j);
+                    if (x == u) {
+                        if (occ++ == 0) at = j;
+                        m32 |= 1u << (j & 31u);
+                    }
                     if (elist_table_contains(table, mask, u, x)) nb.set(j);
+                }
+                if (cnt <= 32u) {
+                    tm = m32;
+                } else if (occ <= 1u) {
+                    tm = at;
+                    flags |= kElTmOffset;
+                } else {
+                    tm = m32;
+                    flags |= kElTmLook;
                 }
             } else if (cnt > 128u) {
                 flags |= kElFilter;
@@ -485,19 +501,18 @@ elist_ext_kernel(const int64_t *__restrict__ edges, int64_t n_edges, int64_t n_n
                     for (uint32_t k = ux.x; k < ux.y; ++k)  // u's edges [first, last): the last one never counts
                         if (elist_table_find(table, mask, v, tail32[k], pm, in_range)) n32 |= pm;
                 }
-                for (int k = 0; k < 4; ++k) {
-                    tm.w[k] = t32;
-                    nb.w[k] = n32;
-                }
+                tm = t32;
+                flags |= kElTmLook;
+                for (int k = 0; k < 4; ++k) nb.w[k] = n32;
             }
-            if (flags & kElHasPad) {
-                flags |= kElFilter;
+            if (flags & kElHasPad) {  // any candidate may be the padding id: every trial looks
+                flags = (flags & ~kElTmOffset) | kElFilter | kElTmLook;
                 nb.fill();
-                tm.fill();
+                tm = 0xFFFFFFFFu;
             }
         }
-        u32x4_a16 a = {v, first, cnt, flags}, b = {nb.w[0], nb.w[1], nb.w[2], nb.w[3]},
-                  c = {tm.w[0], tm.w[1], tm.w[2], tm.w[3]}, d = {only, 0u, 0u, 0u};
+        u32x4_a16 a = {v, first, cnt, flags}, b = {nb.w[0], nb.w[1], nb.w[2], nb.w[3]}, c = {tm, only, 0u, 0u},
+                  d = {0u, 0u, 0u, 0u};
         ent[4 * (size_t)e] = a;
         ent[4 * (size_t)e + 1] = b;
         ent[4 * (size_t)e + 2] = c;
@@ -506,24 +521,34 @@ elist_ext_kernel(const int64_t *__restrict__ edges, int64_t n_edges, int64_t n_n
 }
 
 #ifndef TRW_ELPOOL_SLOTS
-#define TRW_ELPOOL_SLOTS 128
+#define TRW_ELPOOL_SLOTS 124
 #endif
 constexpr int kElSlots = TRW_ELPOOL_SLOTS;  // walkers resident per wave
 constexpr int kElWin = 12;                  // draws a burst can see: the slot's current Philox block + the next two
 enum : uint32_t { EK_RANGE = 0, EK_ENTRY, EK_TEST, EK_MEMBER, EK_FIXNB, EK_PEEK, EK_NOENTRY };
+// 22 words per walker + 2 KB of draw window per wave: 13.3 KB per wave, 53.4 KB per workgroup, THREE workgroups per CU
+// (26 words and a 3 KB window fitted two: 10.6 -> ms on the R-MAT 1M/10M list)
 enum : int {
-    EF_T = 0, EF_PREV, EF_FIRST, EF_CNT, EF_Z, EF_NB0, EF_NB1, EF_NB2, EF_NB3, EF_TM0, EF_TM1, EF_TM2, EF_TM3,
-    EF_FLAGS,  // bit 0 kElFilter, bit 1 kElHasPad, bit 2 this step has a FIXED candidate, bits 4..7 EK_*, bits 8.. probe count
-    EF_S, EF_REJ, EF_WALKER, EF_C0, EF_C1, EF_C2, EF_C3,
-    EF_D,      // draws the walker has consumed (the Philox block in C0..C3 is block D / 4)
+    EF_T = 0, EF_PREV, EF_FIRST, EF_CNT, EF_Z, EF_NB0, EF_NB1, EF_NB2, EF_NB3,
+    EF_TM,     // where t sits in PREV's range: word 8 of the entry, read as flag bits 2..3 say
+    EF_FLAGS,  // bits 0..4 kEf*, bits 5..7 EK_* of the queued / in-flight gather, bits 8..28 rejections at this step,
+               // bits 29..31 how far the probe chain of the current table lookup has gone
+    EF_S, EF_WALKER, EF_C0, EF_C1, EF_C2, EF_C3,
+    EF_D,      // draws the walker has consumed; C0..C3 is the Philox block of the LAST one, block (D - 1) / 4
     EF_X,      // fixed step: the node an accepted trial selects; table probes: the node asked about
     EF_AT,     // entry to gather (kNoEdge: the selected node is reached without an entry -- padding, restart)
     EF_AUX,    // fixed step: accept iff draw < AUX; candidate under test: its acceptance draw
     EF_JUMP,   // where a walk goes from the padding id: its start node (restart) or the padding id
     EF_COUNT
 };
-constexpr uint32_t kEfFixed = 4u;
-constexpr uint32_t kEfTNoNb = 8u;  // flag bit 3: t has no edge that is_neighbor would look at (nothing is its neighbour)
+// slot flags: kEfFilter / kEfTmOffset / kEfTmLook are the entry's kElFilter / kElTmOffset / kElTmLook;
+// kEfFixed: this step has a FIXED candidate; kEfTNoNb: t has no edge that is_neighbor would look at
+constexpr uint32_t kEfFilter = kElFilter, kEfFixed = 2u, kEfTmOffset = kElTmOffset, kEfTmLook = kElTmLook, kEfTNoNb = 16u;
+constexpr uint32_t kEfLow = 31u, kEfKindShift = 5, kEfKind = 7u << 5, kEfRejShift = 8, kEfRej = 0x1FFFFFu << 8,
+                   kEfProbeShift = 29, kEfProbe = 7u << 29;
+static_assert(kTrialCap <= (kEfRej >> kEfRejShift), "the rejection count must fit its field");
+// what of an entry's flag word a slot keeps
+constexpr uint32_t kEfFromEntry = kElFilter | kElTmOffset | kElTmLook;
 
 template <bool kCount>
 __global__ void __launch_bounds__(kBlock)
@@ -534,7 +559,11 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
 {
     static_assert(kElSlots >= 64 && kElSlots <= kQueueCap, "pool size must be 64..128 slots");
     __shared__ uint32_t pool_mem[kPoolWaves][EF_COUNT][kElSlots];
-    __shared__ uint32_t win_mem[kPoolWaves][kElWin][64];
+#ifndef TRW_EL_WIN12
+#define TRW_EL_WIN12 0
+#endif
+    constexpr int kWinOff = TRW_EL_WIN12 ? 0 : 4;  // window positions below this are read from the slot's C0..C3
+    __shared__ uint32_t win_mem[kPoolWaves][kElWin - kWinOff][64];
     __shared__ uint8_t queue_mem[kPoolWaves][3][kQueueCap];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         status[2] = TRW_RNG_WALKER;
@@ -556,11 +585,20 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
     uint32_t n_trials = 0, n_fetch = 0, n_tests = 0, n_probes = 0;
     bool hold = false;
     uint32_t hs = 0, hkind = 0;
-    u32x4_a4 e0 = {0u, 0u, 0u, 0u}, e1 = {0u, 0u, 0u, 0u}, e2 = {0u, 0u, 0u, 0u}, e3 = {0u, 0u, 0u, 0u};
+    u32x4_a4 e0 = {0u, 0u, 0u, 0u}, e1 = {0u, 0u, 0u, 0u}, e2 = {0u, 0u, 0u, 0u};
     bool more_walkers = true;
 
     auto row_of = [&](uint32_t slot) { return out + (int64_t)P[EF_WALKER][slot] * cols; };
-    auto set_kind = [&](uint32_t slot, uint32_t keep_bits, uint32_t kind) { P[EF_FLAGS][slot] = (keep_bits & 15u) | (kind << 4); };
+    // new low flag bits and gather kind for a slot; the rejection count stays, the probe count restarts
+    auto set_kind = [&](uint32_t slot, uint32_t low, uint32_t kind) {
+        P[EF_FLAGS][slot] = (P[EF_FLAGS][slot] & kEfRej) | (low & kEfLow) | (kind << kEfKindShift);
+    };
+    // one more rejection at this step; true when that was the last one allowed
+    auto reject = [&](uint32_t slot) {
+        const uint32_t f = P[EF_FLAGS][slot] + (1u << kEfRejShift);
+        P[EF_FLAGS][slot] = f;
+        return ((f & kEfRej) >> kEfRejShift) >= kTrialCap;
+    };
     // accept threshold of a FIXED candidate x for a walker whose t is `t` (rw_cpu_edge_list.cpp:204-231 with x constant):
     //   x is the padding id -> t0;  else max(x == t ? t0 : 0, is_neighbor ? t1 : t2)
     auto fixed_threshold = [&](uint32_t x, uint32_t t, bool nb) {
@@ -572,10 +610,10 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
     // restart): decide what its next step looks like.  Returns 0 -> trial queue, 1 -> issue queue.
     auto arrive_bare = [&](uint32_t slot) -> int {
         const uint32_t prev = P[EF_PREV][slot], jump = P[EF_JUMP][slot];
+        const uint32_t tn = P[EF_FLAGS][slot] & kEfTNoNb;
         if (prev == pad) {  // the candidate is the jump node, no draw for it (rw_cpu_edge_list.cpp:14-16)
             P[EF_X][slot] = jump;
             P[EF_AT][slot] = kNoEdge;
-            const uint32_t tn = P[EF_FLAGS][slot] & kEfTNoNb;
             if (jump == pad) {
                 P[EF_AUX][slot] = bp.t0;
                 set_kind(slot, kEfFixed | tn, 0u);
@@ -589,13 +627,13 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
             set_kind(slot, kEfFixed, EK_FIXNB);  // is the jump node a neighbour of t?
             return 1;
         }
-        set_kind(slot, P[EF_FLAGS][slot] & kEfTNoNb, EK_RANGE);  // a real node: its edge range first
+        set_kind(slot, tn, EK_RANGE);  // a real node: its edge range first
         return 1;
     };
-    // ... with its range and masks in the slot (FIRST, CNT, masks, flag bits 0..1): fixed or multi-candidate step
+    // ... with its range and masks in the slot (FIRST, CNT, masks, their flag bits): fixed or multi-candidate step
     auto classify = [&](uint32_t slot, uint32_t only_tail, bool have_only) -> int {
         const uint32_t cnt = P[EF_CNT][slot], t = P[EF_T][slot], jump = P[EF_JUMP][slot];
-        const uint32_t fbits = P[EF_FLAGS][slot] & (3u | kEfTNoNb);
+        const uint32_t fbits = P[EF_FLAGS][slot] & (kEfFilter | kEfTmOffset | kEfTmLook | kEfTNoNb);
         if (cnt == 0u) {  // dead end: the candidate is the padding id
             P[EF_X][slot] = (pad == t) ? pad : jump;
             P[EF_AT][slot] = kNoEdge;
@@ -618,7 +656,7 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
             }
             P[EF_X][slot] = only_tail;
             P[EF_AT][slot] = P[EF_FIRST][slot];
-            if (fbits & kElFilter) {  // masks say nothing about this single edge (bare arrival): ask the table
+            if (fbits & kEfFilter) {  // masks say nothing about this single edge (bare arrival): ask the table
                 if (fbits & kEfTNoNb) {
                     P[EF_AUX][slot] = fixed_threshold(only_tail, t, false);
                     set_kind(slot, fbits | kEfFixed, 0u);
@@ -627,7 +665,8 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
                 set_kind(slot, fbits | kEfFixed, EK_FIXNB);
                 return 1;
             }
-            const bool is_t = P[EF_TM0][slot] & 1u, nb = P[EF_NB0][slot] & 1u;
+            // (a one-edge range is described exactly: TM is a plain bit mask for ranges up to 32)
+            const bool is_t = P[EF_TM][slot] & 1u, nb = P[EF_NB0][slot] & 1u;
             const uint32_t cls = nb ? bp.t1 : bp.t2;
             P[EF_AUX][slot] = (is_t && bp.t0 > cls) ? bp.t0 : cls;
             set_kind(slot, fbits | kEfFixed, 0u);
@@ -648,17 +687,16 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
         const uint32_t left = P[EF_PREV][slot];
         // the node being left becomes t: does is_neighbor(., t) have anything to look at?  (edges [first, last))
         const bool tnonb = left == pad ? pad >= (uint32_t)n_nodes : P[EF_CNT][slot] <= 1u;
-        P[EF_FLAGS][slot] = tnonb ? kEfTNoNb : 0u;
+        P[EF_FLAGS][slot] = tnonb ? kEfTNoNb : 0u;  // (no rejections yet at the new step)
         P[EF_T][slot] = left;
         P[EF_PREV][slot] = node;
-        P[EF_REJ][slot] = 0u;
         if (s > L) {
             to_free = true;
             return -1;
         }
         return arrive_bare(slot);
     };
-    // ... onto the entry in e0..e3
+    // ... onto the entry in e0..e2
     auto step_entry = [&](uint32_t slot, bool &to_free) -> int {
         const uint32_t x = e0.x;
         int32_t s = (int32_t)P[EF_S][slot];
@@ -669,7 +707,6 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
         const bool tnonb = left == pad ? pad >= (uint32_t)n_nodes : P[EF_CNT][slot] <= 1u;
         P[EF_T][slot] = left;
         P[EF_PREV][slot] = x;
-        P[EF_REJ][slot] = 0u;
         if (s > L) {
             to_free = true;
             return -1;
@@ -684,12 +721,9 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
         P[EF_NB1][slot] = e1.y;
         P[EF_NB2][slot] = e1.z;
         P[EF_NB3][slot] = e1.w;
-        P[EF_TM0][slot] = e2.x;
-        P[EF_TM1][slot] = e2.y;
-        P[EF_TM2][slot] = e2.z;
-        P[EF_TM3][slot] = e2.w;
-        P[EF_FLAGS][slot] = (e0.w & 3u) | (tnonb ? kEfTNoNb : 0u);
-        return classify(slot, e3.x, true);
+        P[EF_TM][slot] = e2.x;
+        P[EF_FLAGS][slot] = (e0.w & kEfFromEntry) | (tnonb ? kEfTNoNb : 0u);
+        return classify(slot, e2.y, true);
     };
 
     while (true) {
@@ -734,8 +768,8 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
                         P[EF_FIRST][slot] = first;
                         P[EF_CNT][slot] = cnt;
                         P[EF_NB0][slot] = P[EF_NB1][slot] = P[EF_NB2][slot] = P[EF_NB3][slot] = fill;
-                        P[EF_TM0][slot] = P[EF_TM1][slot] = P[EF_TM2][slot] = P[EF_TM3][slot] = fill;
-                        P[EF_FLAGS][slot] = (plain ? 0u : (kElFilter | kElHasPad)) | (flags & kEfTNoNb);
+                        P[EF_TM][slot] = fill;
+                        P[EF_FLAGS][slot] = (flags & (kEfRej | kEfTNoNb)) | (plain ? 0u : (kEfFilter | kEfTmLook));
                         where = classify(slot, e0.w, true);
                     }
                 } else if (hkind == EK_ENTRY) {
@@ -777,24 +811,35 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
                         P[EF_X][slot] = x;
                         set_kind(slot, flags, EK_MEMBER);
                         where = 1;
+                    } else if (reject(slot)) {
+                        st |= (uint32_t)kStTrialCap;
+                        where = step_entry(slot, to_free);
                     } else {
-                        const uint32_t rej = P[EF_REJ][slot] + 1u;
-                        P[EF_REJ][slot] = rej;
-                        if (rej >= kTrialCap) {
-                            st |= (uint32_t)kStTrialCap;
-                            where = step_entry(slot, to_free);
-                        } else {
-                            set_kind(slot, flags, 0u);
-                            where = 0;
-                        }
+                        set_kind(slot, flags, 0u);
+                        where = 0;
                     }
                 } else {  // EK_MEMBER / EK_FIXNB: e0 = one table slot {u, v, ~posmask, ~flags}
                     if (kCount) ++n_probes;
                     const uint32_t t = P[EF_T][slot], x = P[EF_X][slot];
-                    const bool empty = e0.x == 0xFFFFFFFFu;
-                    const bool match = e0.x == t && e0.y == x;
+                    bool empty = e0.x == 0xFFFFFFFFu;
+                    bool match = e0.x == t && e0.y == x;
+                    if (!empty && !match && (flags & kEfProbe) == kEfProbe) {
+                        // the chain is longer than the probe field counts: this lane walks the rest of it here
+                        uint32_t sl = (edge_hash(t, x) + 8u) & mask;
+                        while (true) {
+                            const u32x4_a16 g = *reinterpret_cast<const u32x4_a16 *>(table + 4 * (size_t)sl);
+                            if (kCount) ++n_probes;
+                            empty = g.x == 0xFFFFFFFFu;
+                            match = g.x == t && g.y == x;
+                            if (empty || match) {
+                                e0.w = g.w;
+                                break;
+                            }
+                            sl = (sl + 1u) & mask;
+                        }
+                    }
                     if (!empty && !match) {
-                        P[EF_FLAGS][slot] = flags + 256u;  // next slot of the probe chain
+                        P[EF_FLAGS][slot] = flags + (1u << kEfProbeShift);  // next slot of the probe chain
                         where = 1;
                     } else {
                         const bool nb = match && (e0.w & 1u) == 0u;
@@ -806,17 +851,13 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
                             set_kind(slot, flags, EK_ENTRY);
                             if (kCount) ++n_fetch;
                             where = 1;
+                        } else if (reject(slot)) {
+                            st |= (uint32_t)kStTrialCap;
+                            set_kind(slot, flags, EK_ENTRY);
+                            where = 1;
                         } else {
-                            const uint32_t rej = P[EF_REJ][slot] + 1u;
-                            P[EF_REJ][slot] = rej;
-                            if (rej >= kTrialCap) {
-                                st |= (uint32_t)kStTrialCap;
-                                set_kind(slot, flags, EK_ENTRY);
-                                where = 1;
-                            } else {
-                                set_kind(slot, flags, 0u);
-                                where = 0;
-                            }
+                            set_kind(slot, flags, 0u);
+                            where = 0;
                         }
                     }
                 }
@@ -863,9 +904,8 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
                     P[EF_PREV][slot] = (uint32_t)tg;
                     P[EF_T][slot] = (uint32_t)tg;
                     P[EF_S][slot] = 1u;
-                    P[EF_REJ][slot] = 0u;
                     P[EF_D][slot] = 0u;
-                    uint32_t blk[4];  // the slot always holds the Philox block its next draw lives in
+                    uint32_t blk[4];
                     walker_block((uint64_t)walker_base + (uint64_t)walker, 0u, seed, blk);
                     P[EF_C0][slot] = blk[0];
                     P[EF_C1][slot] = blk[1];
@@ -873,9 +913,9 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
                     P[EF_C3][slot] = blk[3];
                     if ((uint32_t)tg == pad) {  // step 1 from the padding id goes to the jump node (= the padding id)
                         P[EF_X][slot] = pad;
-                        set_kind(slot, 0u, EK_NOENTRY);
+                        P[EF_FLAGS][slot] = EK_NOENTRY << kEfKindShift;
                     } else {
-                        set_kind(slot, 0u, EK_RANGE);
+                        P[EF_FLAGS][slot] = EK_RANGE << kEfKindShift;
                     }
                     to_issue = true;
                 }
@@ -892,20 +932,19 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
             issue_q.pop(lane, n, slot);
             if ((uint32_t)lane < n) {
                 const uint32_t flags = P[EF_FLAGS][slot];
-                const uint32_t kind = (flags >> 4) & 15u;
+                const uint32_t kind = (flags & kEfKind) >> kEfKindShift;
                 if (kind == EK_ENTRY || kind == EK_TEST || kind == EK_PEEK) {
                     const uint32_t *addr = reinterpret_cast<const uint32_t *>(ent + 4 * (size_t)P[EF_AT][slot]);
                     e0 = *reinterpret_cast<const u32x4_a4 *>(addr);
                     if (kind != EK_PEEK) {
                         e1 = *reinterpret_cast<const u32x4_a4 *>(addr + 4);
                         e2 = *reinterpret_cast<const u32x4_a4 *>(addr + 8);
-                        e3 = *reinterpret_cast<const u32x4_a4 *>(addr + 12);
                     }
                 } else if (kind == EK_RANGE) {
                     e0 = *reinterpret_cast<const u32x4_a4 *>(nd + P[EF_PREV][slot]);
                 } else if (kind == EK_MEMBER || kind == EK_FIXNB) {
                     const uint32_t s0 = edge_hash(P[EF_T][slot], P[EF_X][slot]);
-                    e0 = *reinterpret_cast<const u32x4_a4 *>(table + 4 * (size_t)((s0 + (flags >> 8)) & mask));
+                    e0 = *reinterpret_cast<const u32x4_a4 *>(table + 4 * (size_t)((s0 + (flags >> kEfProbeShift)) & mask));
                 }  // EK_NOENTRY: nothing to load
                 hold = true;
                 hs = slot;
@@ -923,59 +962,69 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
             fm.d = busy && cnt ? cnt : 1u;
             fm.z = P[EF_Z][slot];
             const uint32_t nb0 = P[EF_NB0][slot], nb1 = P[EF_NB1][slot], nb2 = P[EF_NB2][slot], nb3 = P[EF_NB3][slot];
-            const uint32_t tm0 = P[EF_TM0][slot], tm1 = P[EF_TM1][slot], tm2 = P[EF_TM2][slot], tm3 = P[EF_TM3][slot];
+            const uint32_t tm = P[EF_TM][slot];
             const uint32_t flags = P[EF_FLAGS][slot];
-            const bool fixed = (flags & kEfFixed) != 0u, filter = (flags & kElFilter) != 0u, haspad = (flags & kElHasPad) != 0u;
+            const bool fixed = (flags & kEfFixed) != 0u, filter = (flags & kEfFilter) != 0u;
+            const bool tm_offset = (flags & kEfTmOffset) != 0u, tm_look = (flags & kEfTmLook) != 0u;
             const bool tnonb = (flags & kEfTNoNb) != 0u;  // nothing is a neighbour of t: every nb bit reads as clear
             const uint32_t aux = P[EF_AUX][slot];
-            uint32_t rejected = P[EF_REJ][slot];
+            uint32_t rejected = (flags & kEfRej) >> kEfRejShift;
             const uint32_t d0 = P[EF_D][slot];
             const uint64_t gw = (uint64_t)walker_base + (uint64_t)P[EF_WALKER][slot];
-            // the window of draws: the slot's current block and the next two
-            W[0][lane] = P[EF_C0][slot];
-            W[1][lane] = P[EF_C1][slot];
-            W[2][lane] = P[EF_C2][slot];
-            W[3][lane] = P[EF_C3][slot];
+            // the window of draws: positions 0..3 are the slot's block (C0..C3, the block of the last draw consumed),
+            // 4..11 the next two blocks, worked out here
+            const uint32_t cb = d0 ? (d0 - 1u) >> 2 : 0u;
+            if (TRW_EL_WIN12) {
+                W[0][lane] = P[EF_C0][slot];
+                W[1][lane] = P[EF_C1][slot];
+                W[2][lane] = P[EF_C2][slot];
+                W[3][lane] = P[EF_C3][slot];
+            }
             if (busy) {
                 uint32_t nbk[4];
-                walker_block(gw, (d0 >> 2) + 1u, seed, nbk);
-                W[4][lane] = nbk[0];
-                W[5][lane] = nbk[1];
-                W[6][lane] = nbk[2];
-                W[7][lane] = nbk[3];
-                walker_block(gw, (d0 >> 2) + 2u, seed, nbk);
-                W[8][lane] = nbk[0];
-                W[9][lane] = nbk[1];
-                W[10][lane] = nbk[2];
-                W[11][lane] = nbk[3];
+                walker_block(gw, cb + 1u, seed, nbk);
+                W[4 - kWinOff][lane] = nbk[0];
+                W[5 - kWinOff][lane] = nbk[1];
+                W[6 - kWinOff][lane] = nbk[2];
+                W[7 - kWinOff][lane] = nbk[3];
+                walker_block(gw, cb + 2u, seed, nbk);
+                W[8 - kWinOff][lane] = nbk[0];
+                W[9 - kWinOff][lane] = nbk[1];
+                W[10 - kWinOff][lane] = nbk[2];
+                W[11 - kWinOff][lane] = nbk[3];
             }
-            uint32_t pos = d0 & 3u;           // next draw inside the window
+            auto draw = [&](uint32_t w) {
+                if (TRW_EL_WIN12) return W[w][lane] >> 1;
+                return (w < 4u ? P[EF_C0 + (int)w][slot] : W[w - 4u][lane]) >> 1;
+            };
+            const uint32_t pos0 = d0 - 4u * cb;  // next draw inside the window (0..4)
+            uint32_t pos = pos0;
             const uint32_t need = fixed ? 1u : 2u;
             uint32_t verdict = 0u, at = 0u, ru_keep = 0u;
             bool running = busy;
 #pragma unroll 1
             for (int rep = 0; rep < 4; ++rep) {
-                running = running && pos + need <= 8u + (d0 & 3u) && pos + need <= (uint32_t)kElWin;
+                running = running && pos + need <= (uint32_t)kElWin;
                 if (__ballot(running) == 0) break;
                 if (running) {
                     if (kCount) ++n_trials;
                     uint32_t v;
                     if (fixed) {
-                        const uint32_t ru = W[pos][lane] >> 1;
+                        const uint32_t ru = draw(pos);
                         pos += 1u;
                         v = ru < aux ? 1u : 0u;
                     } else {
-                        const uint32_t rc = W[pos][lane] >> 1, ru = W[pos + 1u][lane] >> 1;
+                        const uint32_t rc = draw(pos), ru = draw(pos + 1u);
                         pos += 2u;
                         const uint32_t idx = fm.mod(rc);
                         const uint32_t k = (idx >> 5) & 3u, sh = idx & 31u;
                         const bool nbb = !tnonb && (((k == 0u ? nb0 : (k == 1u ? nb1 : (k == 2u ? nb2 : nb3))) >> sh) & 1u);
-                        const bool tmb = ((k == 0u ? tm0 : (k == 1u ? tm1 : (k == 2u ? tm2 : tm3))) >> sh) & 1u;
+                        const bool tmb = tm_offset ? idx == tm : ((tm >> sh) & 1u) != 0u;  // (a plain mask only describes ranges <= 32)
                         const uint32_t v_band = nbb ? (filter ? 2u : v_set) : v_clear;
                         const uint32_t v_cls = ru < bp.lo ? 1u : (ru >= bp.hi ? 0u : v_band);
-                        // the offset may hold t: exact mask -> the reference's first test, then its class; filter -> look
-                        const uint32_t v_t = filter ? 2u : ((ru < bp.t0) ? 1u : v_cls);
-                        v = haspad ? 2u : (tmb ? v_t : v_cls);
+                        // the offset may hold t: exact -> the reference's first test, then its class; otherwise look
+                        const uint32_t v_t = tm_look ? 2u : ((ru < bp.t0) ? 1u : v_cls);
+                        v = tmb ? v_t : v_cls;
                         at = first + idx;
                         ru_keep = ru;
                     }
@@ -990,16 +1039,18 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
             }
             bool to_issue = false, to_trial = false, to_free = false;
             if (busy) {
-                // the block the walker's next draw lives in becomes the slot's current block
-                const uint32_t used = pos - (d0 & 3u);
-                const uint32_t d1 = d0 + used;
-                const uint32_t shift = (d1 >> 2) - (d0 >> 2);  // 0, 1 or 2 blocks on
-                P[EF_C0][slot] = W[4 * shift + 0][lane];
-                P[EF_C1][slot] = W[4 * shift + 1][lane];
-                P[EF_C2][slot] = W[4 * shift + 2][lane];
-                P[EF_C3][slot] = W[4 * shift + 3][lane];
+                // the block of the last draw consumed becomes the slot's block
+                const uint32_t d1 = d0 + (pos - pos0);
+                const uint32_t shift = (d1 ? (d1 - 1u) >> 2 : 0u) - cb;  // 0, 1 or 2 blocks on
+                if (shift) {
+                    P[EF_C0][slot] = W[4 * shift - kWinOff][lane];
+                    P[EF_C1][slot] = W[4 * shift + 1 - kWinOff][lane];
+                    P[EF_C2][slot] = W[4 * shift + 2 - kWinOff][lane];
+                    P[EF_C3][slot] = W[4 * shift + 3 - kWinOff][lane];
+                }
                 P[EF_D][slot] = d1;
-                P[EF_REJ][slot] = rejected;
+                const uint32_t low = flags & kEfLow;
+                P[EF_FLAGS][slot] = low | (rejected << kEfRejShift);
                 if (verdict == 0u) {
                     to_trial = true;
                 } else if (fixed && P[EF_AT][slot] == kNoEdge) {  // taken without an entry (padding / jump): no gather, step now
@@ -1007,13 +1058,13 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
                     to_trial = where == 0;
                     to_issue = where == 1;
                 } else if (fixed) {  // the fixed candidate is taken through its entry
-                    set_kind(slot, flags, EK_ENTRY);
+                    set_kind(slot, low, EK_ENTRY);
                     if (kCount) ++n_fetch;
                     to_issue = true;
                 } else {
                     P[EF_AT][slot] = at;
                     P[EF_AUX][slot] = ru_keep;
-                    set_kind(slot, flags, verdict == 1u ? EK_ENTRY : EK_TEST);
+                    set_kind(slot, low, verdict == 1u ? EK_ENTRY : EK_TEST);
                     if (kCount) ++n_fetch;
                     to_issue = true;
                 }
