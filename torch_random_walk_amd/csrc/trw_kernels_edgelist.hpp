@@ -961,7 +961,6 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
             FastMod fm;
             fm.d = busy && cnt ? cnt : 1u;
             fm.z = P[EF_Z][slot];
-            const uint32_t nb0 = P[EF_NB0][slot], nb1 = P[EF_NB1][slot], nb2 = P[EF_NB2][slot], nb3 = P[EF_NB3][slot];
             const uint32_t tm = P[EF_TM][slot];
             const uint32_t flags = P[EF_FLAGS][slot];
             const bool fixed = (flags & kEfFixed) != 0u, filter = (flags & kEfFilter) != 0u;
@@ -1017,8 +1016,9 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
                         const uint32_t rc = draw(pos), ru = draw(pos + 1u);
                         pos += 2u;
                         const uint32_t idx = fm.mod(rc);
-                        const uint32_t k = (idx >> 5) & 3u, sh = idx & 31u;
-                        const bool nbb = !tnonb && (((k == 0u ? nb0 : (k == 1u ? nb1 : (k == 2u ? nb2 : nb3))) >> sh) & 1u);
+                        const uint32_t sh = idx & 31u;
+                        const uint32_t nbw = P[EF_NB0 + (int)((idx >> 5) & 3u)][slot];  // (by address: cf. biased_pool_kernel)
+                        const bool nbb = !tnonb && ((nbw >> sh) & 1u);
                         const bool tmb = tm_offset ? idx == tm : ((tm >> sh) & 1u) != 0u;  // (a plain mask only describes ranges <= 32)
                         const uint32_t v_band = nbb ? (filter ? 2u : v_set) : v_clear;
                         const uint32_t v_cls = ru < bp.lo ? 1u : (ru >= bp.hi ? 0u : v_band);

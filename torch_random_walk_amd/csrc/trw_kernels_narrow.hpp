@@ -1889,9 +1889,11 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
             fm.z = P[PF_Z][slot];
             const uint32_t flags = P[PF_FLAGS][slot], rpos = P[PF_RPOS][slot];
             const bool exact = (flags & kPfExact) != 0u, first = (flags & kPfFirst) != 0u, wide = (flags & kPfWide) != 0u;
-            uint32_t m0 = P[PF_M0][slot], m1 = P[PF_M1][slot], m2 = P[PF_M2][slot], m3 = P[PF_M3][slot];
-            const uint32_t pos_lo = wide ? m2 : (rpos & 0x0FFFFFFFu), pos_cnt = wide ? m3 : (rpos >> 28);
-            if (wide) m0 = m1 = m2 = m3 = 0xFFFFFFFFu;
+            uint32_t pos_lo = rpos & 0x0FFFFFFFu, pos_cnt = rpos >> 28;
+            if (wide) {
+                pos_lo = P[PF_M2][slot];
+                pos_cnt = P[PF_M3][slot];
+            }
             bool odd = (flags & kPfOdd) != 0u;
             uint32_t rejected = (flags & kPfRejMask) >> kPfRejShift;
             uint32_t w1 = P[PF_W1][slot], w2 = P[PF_W2][slot], w3 = P[PF_W3][slot], blk_at = P[PF_BLK][slot];
@@ -1909,9 +1911,10 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
             auto trial = [&](uint32_t rc, uint32_t ru, bool forced) {
                 if (kCount && !forced) ++n_trials;
                 const uint32_t idx = fm.mod(rc);
-                const uint32_t k = (idx >> 5) & 3u;
-                const uint32_t word = k == 0u ? m0 : (k == 1u ? m1 : (k == 2u ? m2 : m3));
-                const bool bit = (word >> (idx & 31u)) & 1u;
+                // the mask word comes straight from the slot (one LDS read by computed address: the four-way select
+                // between registers compiled to branches, ~15 instructions of a kernel that is bound by issue)
+                const uint32_t word = P[PF_M0 + (int)((idx >> 5) & 3u)][slot];
+                const bool bit = wide || ((word >> (idx & 31u)) & 1u);
                 // verdict 0 reject / 1 accept / 2 look at the candidate, by selects: the same logic written as lane-mask
                 // algebra (compares + scalar and/or) measured 59 ms instead of 52 -- with three waves per SIMD the
                 // VALU -> SALU -> exec round trips cost more than the v_cndmask chain
