@@ -1603,7 +1603,16 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                   "pool size must be 64..256 slots (slot numbers travel as bytes)");
     if (status[kStDescents] != status[kStBoundary]) return;  // unsorted rows: biased_hash_kernel's job
     __shared__ uint32_t pool_mem[kPoolWaves][PF_COUNT][kPoolSlots];
-    __shared__ uint8_t queue_mem[kPoolWaves][3][kQueueCap];
+#ifndef TRW_POOL_SPLIT_ISSUE
+#define TRW_POOL_SPLIT_ISSUE 0
+#endif
+    // TRW_POOL_SPLIT_ISSUE=1: two issue queues -- slots that want an ENTRY (or their start row) and slots that want a
+    // table slot / a candidate to test; an issue pass pops from ONE of them, so the adopt pass that follows runs one
+    // kind's code with all of its lanes instead of every kind's code with a share each.  Measured SLOWER (53.2 vs 46.4 ms):
+    // 128 walkers per wave are too few to keep three queues filled (adopt passes 54 -> 41 lanes, bursts 59 -> 49).
+    // Kept as the A/B switch it was.
+    constexpr bool kSplit = TRW_POOL_SPLIT_ISSUE != 0;
+    __shared__ uint8_t queue_mem[kPoolWaves][kSplit ? 4 : 3][kQueueCap];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         status[2] = TRW_RNG_WALKER;
         status[3] = 5;
@@ -1612,6 +1621,7 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t(*P)[kPoolSlots] = pool_mem[wv];
     PoolQueue trial_q = {queue_mem[wv][0], 0u, 0u}, issue_q = {queue_mem[wv][1], 0u, 0u}, free_q = {queue_mem[wv][2], 0u, 0u};
+    PoolQueue probe_q = {queue_mem[wv][kSplit ? 3 : 1], 0u, 0u};  // (unused when !kSplit)
     for (int i = lane; i < kPoolSlots; i += 64) free_q.q[i] = (uint8_t)i;
     free_q.count = kPoolSlots;
     pool_fence();
@@ -1792,7 +1802,13 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                 }
             }
             trial_q.push(to_trial, hs);
-            issue_q.push(to_issue, hs);
+            if (kSplit) {  // (every to_issue of this phase except the accepted-after-lookup entry is a probe)
+                const bool entry = to_issue && ((P[PF_FLAGS][hs] & kPfKind) >> 4) == PK_ENTRY;
+                issue_q.push(entry, hs);
+                probe_q.push(to_issue && !entry, hs);
+            } else {
+                issue_q.push(to_issue, hs);
+            }
             free_q.push(to_free, hs);
             hold = false;
             pool_fence();
@@ -1800,7 +1816,8 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
         lap(0);
 
         // ================= refill: new walkers into free slots =================
-        if (more_walkers && (free_q.count >= 32u || trial_q.count + issue_q.count < 64u) && free_q.count > 0u) {
+        if (more_walkers && (free_q.count >= 32u || trial_q.count + issue_q.count + (kSplit ? probe_q.count : 0u) < 64u) &&
+            free_q.count > 0u) {
             uint32_t n, slot;
             const uint32_t avail = free_q.count < 64u ? free_q.count : 64u;
             long long base = 0;
@@ -1844,9 +1861,11 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
         if (!more_walkers && free_q.count == (uint32_t)kPoolSlots) break;  // every walker of this wave is done
 
         // ================= issue: gathers for the slots that want one =================
-        if (issue_q.count >= kPoolIssueMin || (issue_q.count > 0u && trial_q.count < kPoolTrialMin)) {
+        auto issue_most = [&]() { return kSplit && probe_q.count > issue_q.count ? probe_q.count : issue_q.count; };
+        if (issue_most() >= kPoolIssueMin || (issue_most() > 0u && trial_q.count < kPoolTrialMin)) {
             uint32_t n, slot;
-            issue_q.pop(lane, n, slot);
+            if (kSplit && probe_q.count > issue_q.count) probe_q.pop(lane, n, slot);
+            else issue_q.pop(lane, n, slot);
             if (kCount) {
                 ++w_pass[1];
                 w_lanes[1] += n;
@@ -1874,7 +1893,7 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
 
         lap(2);
         // ================= burst: trials for a wave of slots that are between gathers =================
-        if (trial_q.count >= kPoolTrialMin || (trial_q.count > 0u && issue_q.count < kPoolIssueMin)) {
+        if (trial_q.count >= kPoolTrialMin || (trial_q.count > 0u && issue_most() < kPoolIssueMin)) {
             uint32_t n, slot;
             trial_q.pop(lane, n, slot);
             if (kCount) {
@@ -1981,7 +2000,12 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                 }
                 P[PF_FLAGS][slot] = nf;
             }
-            issue_q.push(to_issue, slot);
+            if (kSplit) {
+                issue_q.push(to_issue && take, slot);
+                probe_q.push(to_issue && !take, slot);
+            } else {
+                issue_q.push(to_issue, slot);
+            }
             trial_q.push(to_trial, slot);
             pool_fence();
         }
