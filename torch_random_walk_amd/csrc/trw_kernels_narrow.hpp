@@ -1533,6 +1533,10 @@ constexpr int kQueueCap = TRW_POOL_SLOTS > 128 ? 256 : 128;  // ring capacity of
 constexpr int kPoolPairs = TRW_POOL_PAIRS;  // Philox blocks (pairs of trials) per visit of the burst
 constexpr int kPoolWaves = kBlock / 64;
 // A phase runs when its queue holds at least this many slots (or when nothing else can make progress)
+#ifndef TRW_POOL_PAIR_STORES
+#define TRW_POOL_PAIR_STORES 0
+#endif
+typedef int64_t i64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
 #ifndef TRW_POOL_FIRST_IN_BURST
 #define TRW_POOL_FIRST_IN_BURST 1
 #endif
@@ -1704,14 +1708,27 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                     int32_t s = (int32_t)P[PF_S][slot];
                     const uint32_t prev = P[PF_PREV][slot];
                     int64_t *r = row_of(slot);
+                    // TRW_POOL_PAIR_STORES=1: columns leave in pairs -- the slot holds the last two nodes of the walk anyway
+                    // (prev becomes t), so every second step stores columns (s-1, s) as 16 bytes.  Without any stores the
+                    // kernel takes 43.9 ms instead of 46.6, but the pairs measured 46.4 against 46.0 for single stores
+                    // (rows of 81 columns are 8-byte aligned: the 16-byte store is split again); off, kept as the switch.
+#if TRW_POOL_PAIR_STORES
+                    if ((s & 1) == 0) {
+                        i64x2_a8 two = {(int64_t)prev, (int64_t)x};
+                        *reinterpret_cast<i64x2_a8 *>(r + s - 1) = two;
+                    } else if (s == L) {
+                        r[s] = (int64_t)x;
+                    }
+#else
                     r[s] = (int64_t)x;
+#endif
                     ++s;
                     const uint32_t deg = e0.z & ~kMaskIsFilter;
                     if (s > L) {
                         to_free = true;
                     } else if (deg == 0) {  // dead end: reported, the walker stays
                         st |= TRW_ST_DEGREE0;
-                        for (; s <= L; ++s) r[s] = (int64_t)x;
+                        for (--s; s <= L; ++s) r[s] = (int64_t)x;  // (from this column on: its pair may not have left yet)
                         to_free = true;
                     } else {
                         FastMod fm;
