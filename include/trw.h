@@ -404,6 +404,13 @@ int trw_profile_last(double *prepare_ms, double *walk_ms, double *finish_ms);
 int trw_profile_prepare_last(double *prepare_ms);
 int trw_walk_counters(const void *workspace, void *hip_stream, uint64_t counters[4]);
 
+/* Self-test of the device arithmetic the walk kernels are built on, over EVERY divisor a row length can be
+ * (1 .. 2^31-1): the exact reciprocal of the walker pools' one-correction `draw % degree` (the stand-in for the
+ * reference's `rand() % (row_end - row_start)`, csrc/cpu/rw_cpu.cpp:20), the two-correction form of the other
+ * kernels, both against the hardware's own %.  `scratch` = 16 bytes of device memory, 16-byte aligned.  Synchronises;
+ * *failures = number of divisors / draws that disagreed (0 on a healthy build). */
+int trw_selftest_hip(void *scratch, void *hip_stream, uint64_t *failures);
+
 #ifdef __cplusplus
 }
 #endif

@@ -433,6 +433,19 @@ def test_work_counters(rw, hash_path, monkeypatch):
     assert c[1] <= c[0] and c[2] <= cnt["membership_tests"]      # most trials never touch memory
 
 
+def test_library_selftest_of_the_draw_reduction():
+    """`draw % degree` on the device (rw_cpu.cpp:20's `rand() % n`): the walker pools reduce with an exact reciprocal
+    and ONE correction; the library checks that form and the two-correction one against the hardware's % for every
+    divisor below 2^31."""
+    from torch_random_walk_amd import _native
+    L = _native.cabi()
+    scratch = torch.zeros(2, dtype=torch.int64, device=DEV)
+    failures = ctypes.c_uint64(12345)
+    assert L.trw_selftest_hip(scratch.data_ptr(), torch.cuda.current_stream().cuda_stream, ctypes.byref(failures)) == 0, \
+        L.trw_last_error()
+    assert failures.value == 0
+
+
 # ---- BASELINE-sized runs: properties + sampled oracle rows --------------------------------
 
 def _check_big(rw, rp, ci, tg, p, q, L, seed, omode, sample=2000):

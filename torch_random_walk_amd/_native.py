@@ -89,5 +89,7 @@ def cabi():
         L.trw_profile_prepare_last.restype = ctypes.c_int
         L.trw_walk_counters.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_uint64)]
         L.trw_walk_counters.restype = ctypes.c_int
+        L.trw_selftest_hip.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_uint64)]
+        L.trw_selftest_hip.restype = ctypes.c_int
         _cabi = L
     return _cabi

@@ -1380,6 +1380,25 @@ int trw_walk_status(const void *workspace, void *hip_stream, int64_t status_out[
     return TRW_OK;
 }
 
+int trw_selftest_hip(void *scratch, void *hip_stream, uint64_t *failures)
+{
+    t_last_error.clear();
+    if (!scratch || !failures) return fail(TRW_E_ARG, "null argument");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    device_fill(scratch, 0u, 16, stream);
+    fastmod_selftest_kernel<<<(unsigned)(device_cu_count() * 8), kBlock, 0, stream>>>(1u, 0x80000000u,
+                                                                                       (unsigned long long *)scratch);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "fastmod_selftest_kernel");
+    unsigned long long host = 0;
+    e = hipMemcpyAsync(&host, scratch, sizeof host, hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return fail_hip(e, "hipMemcpyAsync(selftest)");
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return fail_hip(e, "hipStreamSynchronize");
+    *failures = host;
+    return TRW_OK;
+}
+
 // ---- deferred status: asynchronous read-backs of status blocks -----------------------------------
 namespace {
 struct StatusSlot {

@@ -673,7 +673,7 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
             return 0;
         }
         FastMod fm;
-        fm.init(cnt);
+        fm.init_exact(cnt);
         P[EF_Z][slot] = fm.z;
         set_kind(slot, fbits, 0u);
         return 0;
@@ -1015,7 +1015,7 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
                     } else {
                         const uint32_t rc = draw(pos), ru = draw(pos + 1u);
                         pos += 2u;
-                        const uint32_t idx = fm.mod(rc);
+                        const uint32_t idx = fm.mod31(rc);
                         const uint32_t sh = idx & 31u;
                         const uint32_t nbw = P[EF_NB0 + (int)((idx >> 5) & 3u)][slot];  // (by address: cf. biased_pool_kernel)
                         const bool nbb = !tnonb && ((nbw >> sh) & 1u);

@@ -327,7 +327,56 @@ struct FastMod {
         if (r >= d) r -= d;
         return r;
     }
+    // The walker pools run one r % d per rejection trial and are bound by instruction issue: with the reciprocal
+    // made EXACT, z = floor((2^32 - 1) / d), one correction is enough for the 31-bit draws they reduce:
+    //   delta = 2^32/d - z is in (0, 1], so x*z/2^32 = x/d - x*delta/2^32 > x/d - 1/2 for x < 2^31, i.e. the quotient
+    //   estimate is floor(x/d) or one less, never more.
+    // init() leaves z at most two below the exact value (never above: the estimate is built to underestimate), which
+    // trw_selftest_hip checks for every divisor a row can have.
+    __device__ __forceinline__ void init_exact(uint32_t den)
+    {
+        init(den);
+        uint32_t rem = 0xFFFFFFFFu - z * den;  // z * den <= 2^32 - 1 because z <= floor((2^32 - 1) / den)
+        if (rem >= den) {
+            ++z;
+            rem -= den;
+        }
+        if (rem >= den) ++z;
+    }
+    __device__ __forceinline__ uint32_t mod31(uint32_t x) const  // x < 2^31, z from init_exact
+    {
+        const uint32_t r = x - __umulhi(x, z) * d;
+        const uint32_t r1 = r - d;
+        return r1 < r ? r1 : r;  // (r >= d  <=>  r - d does not wrap)
+    }
 };
+
+// Self-test of the arithmetic above (trw_selftest_hip): every divisor in [d_lo, d_hi) -- is init_exact's reciprocal
+// exact, did init() stay within two below it, does mod31 agree with % on the corner draws and a few hashed ones.
+__global__ void __launch_bounds__(kBlock)
+fastmod_selftest_kernel(uint32_t d_lo, uint32_t d_hi, unsigned long long *__restrict__ failures)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    uint32_t bad = 0;
+    for (uint64_t d64 = (uint64_t)d_lo + (uint64_t)blockIdx.x * kBlock + threadIdx.x; d64 < d_hi; d64 += stride) {
+        const uint32_t d = (uint32_t)d64;
+        FastMod a, b;
+        a.init(d);
+        b.init_exact(d);
+        const uint32_t exact = 0xFFFFFFFFu / d;
+        if (b.z != exact || a.z > exact || exact - a.z > 2u) ++bad;
+        const uint32_t top = 0x7FFFFFFFu;
+        uint32_t h = d * 0x9E3779B1u;
+        const uint32_t xs[10] = {0u, d - 1u, d & top, top, top - (d - 1u), (top / d) * d, (top / d) * d - 1u,
+                                 (h ^ (h >> 15)) & top, (h * 0x85EBCA77u) & top, ((h + 0x165667B1u) * 0xC2B2AE3Du) & top};
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            const uint32_t x = xs[k] & top;
+            if (b.mod31(x) != x % d || a.mod(x) != x % d) ++bad;
+        }
+    }
+    if (bad) atomicAdd(failures, (unsigned long long)bad);
+}
 
 // First offset in [0, n) whose entry is >= x (n if none); rows sorted ascending.
 __device__ __forceinline__ uint32_t lower_bound32(const uint32_t *__restrict__ col32, uint32_t start, uint32_t n,
@@ -1682,7 +1731,7 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                         // burst as an "odd trial on block -1": the burst's next block is block 0, word 0 is the draw.
 #if TRW_POOL_FIRST_IN_BURST
                         FastMod fm;
-                        fm.init(deg);
+                        fm.init_exact(deg);
                         P[PF_START][slot] = start;
                         P[PF_DEG][slot] = deg;
                         P[PF_Z][slot] = fm.z;
@@ -1732,7 +1781,7 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                         to_free = true;
                     } else {
                         FastMod fm;
-                        fm.init(deg);
+                        fm.init_exact(deg);
                         P[PF_T][slot] = prev;
                         P[PF_PREV][slot] = x;
                         P[PF_START][slot] = e0.y;
@@ -1946,7 +1995,7 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
 
             auto trial = [&](uint32_t rc, uint32_t ru, bool forced) {
                 if (kCount && !forced) ++n_trials;
-                const uint32_t idx = fm.mod(rc);
+                const uint32_t idx = fm.mod31(rc);
                 // the mask word comes straight from the slot (one LDS read by computed address: the four-way select
                 // between registers compiled to branches, ~15 instructions of a kernel that is bound by issue)
                 const uint32_t word = P[PF_M0 + (int)((idx >> 5) & 3u)][slot];
