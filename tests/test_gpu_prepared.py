@@ -56,6 +56,23 @@ def test_second_walk_reuses_the_prepared_graph_and_third_has_full_marks(rw):
     rw.check_status()
 
 
+def test_ninth_walk_builds_the_long_row_masks_unless_prepared_by_hand(rw):
+    rp, ci = hub_graph(1500, 6)
+    tg = np.random.default_rng(3).integers(0, 1500, 8000)
+    d_rp, d_ci, d_tg = _dev(rp, ci, tg)
+    ref = O.walk(rp, ci, tg, 0.25, 4.0, 12, 4, rng_mode=O.RNG_WALKER)
+    for k in range(10):
+        assert (rw.walk(d_rp, d_ci, d_tg, 0.25, 4.0, 12, 4).cpu().numpy() == ref).all()
+        full = bool(rw.cache_info()[0][2] & rw.PREP_MARKS_FULL)
+        assert full == (k >= 8), (k, rw.cache_info())
+    rw.clear_cache()
+    assert rw.prepare(d_rp, d_ci) == rw.PREP_BIASED | rw.PREP_MARKS          # the caller's choice stays as it is
+    for k in range(10):
+        rw.walk(d_rp, d_ci, d_tg, 0.25, 4.0, 12, 4)
+    assert rw.cache_info()[0][2] == rw.PREP_BIASED | rw.PREP_MARKS
+    rw.check_status()
+
+
 def test_in_place_write_invalidates(rw):
     rp, ci = random_graph(400, 6, 3)
     tg = np.arange(400).repeat(20)

@@ -133,7 +133,8 @@ torch::Tensor walk_cpu_leg(const torch::Tensor &row_ptr, const torch::Tensor &co
 // not match) and unmodified (tensor version counters: an in-place write invalidates).  Policy: the first walk
 // builds what a single call of its shape is worth; the second node2vec walk over the same graph also builds the
 // neighbourhood masks of longer rows (TRW_PREP_MARKS: about 3.5x the prepare time, then every later walk is 30 %
-// faster); rw.prepare() asks for them up front, and for TRW_PREP_MARKS_FULL with marks="full".  Least-recently-used graphs beyond `capacity` are dropped; entries whose
+// faster) and the ninth those of rows up to 1 024 entries (TRW_PREP_MARKS_FULL); rw.prepare() asks for them up front
+// (marks=True / marks="full").  Least-recently-used graphs beyond `capacity` are dropped; entries whose
 // tensors died are dropped at the next call.  TRW_CACHE=0 (or set_cache(False)) turns the cache off: every
 // call then prepares into its own workspace, as trw_walk_csr_hip does.  Calls on a stream that is being captured
 // into a HIP graph never use the cache (a replay must not depend on memory the cache may drop).
@@ -157,6 +158,7 @@ struct PreparedGraph {
     ~PreparedGraph() { trw_event_destroy(ready); }
 };
 
+constexpr int64_t kFullMarksAfter = 8;  // node2vec walks over one graph before the cache builds TRW_PREP_MARKS_FULL
 std::mutex g_cache_mu;
 std::list<std::shared_ptr<PreparedGraph>> g_cache;  // most recently used first
 std::atomic<int64_t> g_cache_capacity{2};
@@ -271,6 +273,10 @@ PreparedUse prepared_for(const torch::Tensor &rp, const torch::Tensor &ci, int32
     if (kind == 0) {
         // the second node2vec walk over a graph is the sign that it is walked repeatedly: worth the full masks
         if (biased_walk && (want & TRW_PREP_BIASED) && hit->biased_walks >= 1) want |= TRW_PREP_MARKS;
+        // ... and the ninth that it is walked epoch after epoch: the masks of rows up to 1 024 entries cost 70 ms more
+        // (R-MAT 10M/110M) and take 13 % off every later walk.  Not behind rw.prepare()'s back: that graph has what was asked.
+        if (biased_walk && (want & TRW_PREP_MARKS) && hit->biased_walks >= kFullMarksAfter && !hit->pinned)
+            want |= TRW_PREP_MARKS_FULL;
         want &= ~hit->refused;
         if (want & TRW_PREP_MARKS_FULL) want |= TRW_PREP_MARKS;
         if (want & TRW_PREP_MARKS) want |= TRW_PREP_BIASED;
