@@ -123,9 +123,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # the persistent walk kernel leaves 64 of its 768 workgroup slots empty so that the gather's RCCL kernels get
+        # the persistent walk kernel leaves 64 of its 1024 workgroup slots empty so that the gather's RCCL kernels get
         # on the chip WHILE the next step walks (profiles/r02_overlap_probe.txt: with every slot taken a side-stream
-        # kernel starts only when the walk is over; with 64 spare it runs beside it, walk 54 -> 58 ms)
+        # kernel starts only when the walk is over; with 64 spare it runs beside it, walk 48 -> 56 ms)
         os.environ.setdefault("TRW_POOL_SPARE_BLOCKS", "64")
         if dry:
             dist.init_process_group("gloo")
