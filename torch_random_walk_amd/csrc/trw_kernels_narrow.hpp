@@ -726,6 +726,9 @@ __device__ __forceinline__ bool edge_table_find(const uint32_t *__restrict__ tab
     }
 }
 
+#ifndef TRW_HEAVY_PIVOTS
+#define TRW_HEAVY_PIVOTS 1
+#endif
 struct Mask128 {
     uint32_t w[4];
     __device__ __forceinline__ void clear() { w[0] = w[1] = w[2] = w[3] = 0u; }
@@ -814,6 +817,62 @@ __device__ __forceinline__ void common_mask_bisect(const uint32_t *__restrict__ 
     }
 }
 
+// row_find32 for the wave-per-entry pass: every lane of the wave searches the SAME long row, so the top six levels of
+// the bisection are the same 63 entries for all of them.  The wave loads them once per entry into LDS (`piv[k]` = last
+// entry of the k-th sixty-fourth of the row), a lane finds its sixty-fourth there and bisects only inside it: six
+// global loads less per search (10 of 17 left for a 100 000-entry hub row, 4 of 10 for a 1 000-entry one).
+__device__ __forceinline__ uint32_t row_find32_pivots(const uint32_t *__restrict__ col32, uint32_t start, uint32_t n,
+                                                      const uint32_t *piv, uint32_t x, uint32_t &run)
+{
+    uint32_t k = 0;
+#pragma unroll
+    for (uint32_t s = 32; s; s >>= 1)
+        if (piv[k + s - 1] < x) k += s;
+    run = 0;
+    if (piv[k] < x) return n;  // beyond the row's last entry
+    uint32_t lo = (uint32_t)(((uint64_t)k * n) >> 6), len = (uint32_t)(((uint64_t)(k + 1) * n) >> 6) - lo;
+    while (len > 0) {
+        const uint32_t half = len >> 1;
+        if (col32[start + lo + half] < x) {
+            lo += half + 1;
+            len -= half + 1;
+        } else {
+            len = half;
+        }
+    }
+    while (lo + run < n && col32[start + lo + run] == x) ++run;
+    return lo;
+}
+
+// common_mask_bisect with the longer row's pivots in `piv` (64 words of LDS owned by the calling wave, filled here)
+__device__ __forceinline__ void common_mask_pivots(const uint32_t *__restrict__ col32, uint32_t u_lo, uint32_t u_hi,
+                                                   uint32_t v_start, uint32_t v_deg, int lane, uint32_t *piv, Mask128 &m)
+{
+    const uint32_t u_deg = u_hi - u_lo;
+    const bool walk_u = u_deg <= v_deg;
+    const uint32_t b_start = walk_u ? v_start : u_lo, b_n = walk_u ? v_deg : u_deg;  // the row searched (wave-uniform)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    piv[lane] = col32[b_start + (uint32_t)(((uint64_t)(lane + 1) * b_n) >> 6) - 1u];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint32_t run;
+    if (walk_u) {  // walk u's row: each distinct w in it, located in v's row
+        for (uint32_t i = (uint32_t)lane; i < u_deg; i += 64u) {
+            const uint32_t w = col32[u_lo + i];
+            if (i > 0 && col32[u_lo + i - 1] == w) continue;  // a run of equal entries is one node
+            const uint32_t lo = row_find32_pivots(col32, v_start, v_deg, piv, w, run);
+            if (run) m.set_run(lo, run);
+        }
+    } else {  // walk v's row: the node at each offset, located in u's row
+        for (uint32_t j = (uint32_t)lane; j < v_deg; j += 64u) {
+            row_find32_pivots(col32, u_lo, u_deg, piv, col32[v_start + j], run);
+            if (run) m.set(j);
+        }
+    }
+}
+
 struct HeavyItem {
     uint32_t e, u;
 };
@@ -885,6 +944,7 @@ csr_ext32_heavy_kernel(const uint32_t *__restrict__ row32, const uint32_t *__res
                        const uint32_t *__restrict__ table, uint64_t tmask, u32x4_a16 *__restrict__ ext,
                        const HeavyItem *__restrict__ heavy, uint32_t heavy_room, const int64_t *__restrict__ header)
 {
+    __shared__ uint32_t piv_mem[kBlock / 64][64];
     const uint64_t queued = (uint64_t)header[kStHeavyCount];
     const uint32_t count = queued < heavy_room ? (uint32_t)queued : heavy_room;
     const int lane = threadIdx.x & 63;
@@ -896,7 +956,12 @@ csr_ext32_heavy_kernel(const uint32_t *__restrict__ row32, const uint32_t *__res
         load_row32(row32, v, start, deg);
         Mask128 m;
         m.clear();
-        common_mask_bisect(col32, row32[h.u], row32[h.u + 1], start, deg, (uint32_t)lane, 64u, m);
+        const uint32_t u_lo = row32[h.u], u_hi = row32[h.u + 1];
+        const uint32_t longer = (u_hi - u_lo) <= deg ? deg : u_hi - u_lo;
+        if (TRW_HEAVY_PIVOTS && longer > 64u)
+            common_mask_pivots(col32, u_lo, u_hi, start, deg, lane, piv_mem[threadIdx.x >> 6], m);
+        else
+            common_mask_bisect(col32, u_lo, u_hi, start, deg, (uint32_t)lane, 64u, m);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
