@@ -527,7 +527,7 @@ constexpr int kElSlots = TRW_ELPOOL_SLOTS;  // walkers resident per wave
 constexpr int kElWin = 12;                  // draws a burst can see: the slot's current Philox block + the next two
 enum : uint32_t { EK_RANGE = 0, EK_ENTRY, EK_TEST, EK_MEMBER, EK_FIXNB, EK_PEEK, EK_NOENTRY };
 // 22 words per walker + 2 KB of draw window per wave: 13.3 KB per wave, 53.4 KB per workgroup, THREE workgroups per CU
-// (26 words and a 3 KB window fitted two: 10.6 -> ms on the R-MAT 1M/10M list)
+// (26 words and a 3 KB window fitted two: 10.6 -> 9.1 ms on the R-MAT 1M/10M list)
 enum : int {
     EF_T = 0, EF_PREV, EF_FIRST, EF_CNT, EF_Z, EF_NB0, EF_NB1, EF_NB2, EF_NB3,
     EF_TM,     // where t sits in PREV's range: word 8 of the entry, read as flag bits 2..3 say
