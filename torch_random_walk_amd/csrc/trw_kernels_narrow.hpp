@@ -1647,13 +1647,6 @@ constexpr int kQueueCap = TRW_POOL_SLOTS > 128 ? 256 : 128;  // ring capacity of
 constexpr int kPoolPairs = TRW_POOL_PAIRS;  // Philox blocks (pairs of trials) per visit of the burst
 constexpr int kPoolWaves = kBlock / 64;
 // A phase runs when its queue holds at least this many slots (or when nothing else can make progress)
-#ifndef TRW_POOL_PAIR_STORES
-#define TRW_POOL_PAIR_STORES 0
-#endif
-typedef int64_t i64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
-#ifndef TRW_POOL_FIRST_IN_BURST
-#define TRW_POOL_FIRST_IN_BURST 1
-#endif
 #ifndef TRW_POOL_ISSUE_MIN
 #define TRW_POOL_ISSUE_MIN 48
 #endif
@@ -1721,16 +1714,10 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                   "pool size must be 64..256 slots (slot numbers travel as bytes)");
     if (status[kStDescents] != status[kStBoundary]) return;  // unsorted rows: biased_hash_kernel's job
     __shared__ uint32_t pool_mem[kPoolWaves][PF_COUNT][kPoolSlots];
-#ifndef TRW_POOL_SPLIT_ISSUE
-#define TRW_POOL_SPLIT_ISSUE 0
-#endif
-    // TRW_POOL_SPLIT_ISSUE=1: two issue queues -- slots that want an ENTRY (or their start row) and slots that want a
-    // table slot / a candidate to test; an issue pass pops from ONE of them, so the adopt pass that follows runs one
-    // kind's code with all of its lanes instead of every kind's code with a share each.  Measured SLOWER (53.2 vs 46.4 ms):
-    // 128 walkers per wave are too few to keep three queues filled (adopt passes 54 -> 41 lanes, bursts 59 -> 49).
-    // Kept as the A/B switch it was.
-    constexpr bool kSplit = TRW_POOL_SPLIT_ISSUE != 0;
-    __shared__ uint8_t queue_mem[kPoolWaves][kSplit ? 4 : 3][kQueueCap];
+    // (Tried: a second issue queue, entries / table probes apart, so that an adopt pass runs one kind's code with all of
+    // its lanes: 53.2 vs 46.4 ms -- 128 walkers per wave are too few to keep three queues filled, adopt passes went
+    // from 54 to 41 lanes, bursts from 59 to 49.)
+    __shared__ uint8_t queue_mem[kPoolWaves][3][kQueueCap];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         status[2] = TRW_RNG_WALKER;
         status[3] = 5;
@@ -1739,7 +1726,6 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t(*P)[kPoolSlots] = pool_mem[wv];
     PoolQueue trial_q = {queue_mem[wv][0], 0u, 0u}, issue_q = {queue_mem[wv][1], 0u, 0u}, free_q = {queue_mem[wv][2], 0u, 0u};
-    PoolQueue probe_q = {queue_mem[wv][kSplit ? 3 : 1], 0u, 0u};  // (unused when !kSplit)
     for (int i = lane; i < kPoolSlots; i += 64) free_q.q[i] = (uint8_t)i;
     free_q.count = kPoolSlots;
     pool_fence();
@@ -1766,6 +1752,9 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
 
     // Columns go out one 8-byte store each: this kernel runs out of instruction issue, not of write requests, and
     // a plain store is an address and one instruction where combining four columns cost 25 and four words of state.
+    // (Without any column store the kernel takes 43.9 ms instead of 46.6; columns (s-1, s) as one 16-byte store every
+    // second step -- the slot holds the last two nodes anyway -- measured 46.4 against 46.0: rows of 81 columns are
+    // 8-byte aligned and the wider store is split again.)
     auto row_of = [&](uint32_t slot) { return out + (int64_t)P[PF_WALKER][slot] * cols; };
 
     while (true) {
@@ -1794,7 +1783,6 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                         // NOT worked out here: a wave adopts a start row in almost every other iteration, one lane
                         // at a time, and ten rounds for one lane cost what they cost for 64.  The slot goes to the
                         // burst as an "odd trial on block -1": the burst's next block is block 0, word 0 is the draw.
-#if TRW_POOL_FIRST_IN_BURST
                         FastMod fm;
                         fm.init_exact(deg);
                         P[PF_START][slot] = start;
@@ -1804,45 +1792,20 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                         P[PF_BLK][slot] = 0xFFFFFFFFu;
                         P[PF_FLAGS][slot] = kPfOdd | kPfFirst;
                         to_trial = true;
-#else  // (the A/B baseline: the block worked out where the row arrives)
-                        uint32_t blk[4];
-                        walker_block((uint64_t)walker_base + (uint64_t)P[PF_WALKER][slot], 0u, seed, blk);
-                        P[PF_W1][slot] = blk[1];
-                        P[PF_W2][slot] = blk[2];
-                        P[PF_W3][slot] = blk[3];
-                        P[PF_BLK][slot] = 0u;
-                        P[PF_AT][slot] = start + (blk[0] >> 1) % deg;
-                        P[PF_FLAGS][slot] = PK_ENTRY << 4;
-                        if (kCount) ++n_fetch;
-                        to_issue = true;
-#endif
                     }
                 } else if (hkind == PK_ENTRY) {  // e0, e1 = the accepted entry: step onto it
                     const uint32_t x = e0.x;
                     int32_t s = (int32_t)P[PF_S][slot];
                     const uint32_t prev = P[PF_PREV][slot];
                     int64_t *r = row_of(slot);
-                    // TRW_POOL_PAIR_STORES=1: columns leave in pairs -- the slot holds the last two nodes of the walk anyway
-                    // (prev becomes t), so every second step stores columns (s-1, s) as 16 bytes.  Without any stores the
-                    // kernel takes 43.9 ms instead of 46.6, but the pairs measured 46.4 against 46.0 for single stores
-                    // (rows of 81 columns are 8-byte aligned: the 16-byte store is split again); off, kept as the switch.
-#if TRW_POOL_PAIR_STORES
-                    if ((s & 1) == 0) {
-                        i64x2_a8 two = {(int64_t)prev, (int64_t)x};
-                        *reinterpret_cast<i64x2_a8 *>(r + s - 1) = two;
-                    } else if (s == L) {
-                        r[s] = (int64_t)x;
-                    }
-#else
                     r[s] = (int64_t)x;
-#endif
                     ++s;
                     const uint32_t deg = e0.z & ~kMaskIsFilter;
                     if (s > L) {
                         to_free = true;
                     } else if (deg == 0) {  // dead end: reported, the walker stays
                         st |= TRW_ST_DEGREE0;
-                        for (--s; s <= L; ++s) r[s] = (int64_t)x;  // (from this column on: its pair may not have left yet)
+                        for (; s <= L; ++s) r[s] = (int64_t)x;
                         to_free = true;
                     } else {
                         FastMod fm;
@@ -1933,13 +1896,7 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                 }
             }
             trial_q.push(to_trial, hs);
-            if (kSplit) {  // (every to_issue of this phase except the accepted-after-lookup entry is a probe)
-                const bool entry = to_issue && ((P[PF_FLAGS][hs] & kPfKind) >> 4) == PK_ENTRY;
-                issue_q.push(entry, hs);
-                probe_q.push(to_issue && !entry, hs);
-            } else {
-                issue_q.push(to_issue, hs);
-            }
+            issue_q.push(to_issue, hs);
             free_q.push(to_free, hs);
             hold = false;
             pool_fence();
@@ -1947,8 +1904,7 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
         lap(0);
 
         // ================= refill: new walkers into free slots =================
-        if (more_walkers && (free_q.count >= 32u || trial_q.count + issue_q.count + (kSplit ? probe_q.count : 0u) < 64u) &&
-            free_q.count > 0u) {
+        if (more_walkers && (free_q.count >= 32u || trial_q.count + issue_q.count < 64u) && free_q.count > 0u) {
             uint32_t n, slot;
             const uint32_t avail = free_q.count < 64u ? free_q.count : 64u;
             long long base = 0;
@@ -1992,11 +1948,9 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
         if (!more_walkers && free_q.count == (uint32_t)kPoolSlots) break;  // every walker of this wave is done
 
         // ================= issue: gathers for the slots that want one =================
-        auto issue_most = [&]() { return kSplit && probe_q.count > issue_q.count ? probe_q.count : issue_q.count; };
-        if (issue_most() >= kPoolIssueMin || (issue_most() > 0u && trial_q.count < kPoolTrialMin)) {
+        if (issue_q.count >= kPoolIssueMin || (issue_q.count > 0u && trial_q.count < kPoolTrialMin)) {
             uint32_t n, slot;
-            if (kSplit && probe_q.count > issue_q.count) probe_q.pop(lane, n, slot);
-            else issue_q.pop(lane, n, slot);
+            issue_q.pop(lane, n, slot);
             if (kCount) {
                 ++w_pass[1];
                 w_lanes[1] += n;
@@ -2024,7 +1978,7 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
 
         lap(2);
         // ================= burst: trials for a wave of slots that are between gathers =================
-        if (trial_q.count >= kPoolTrialMin || (trial_q.count > 0u && issue_most() < kPoolIssueMin)) {
+        if (trial_q.count >= kPoolTrialMin || (trial_q.count > 0u && issue_q.count < kPoolIssueMin)) {
             uint32_t n, slot;
             trial_q.pop(lane, n, slot);
             if (kCount) {
@@ -2051,12 +2005,8 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
             // outcome of the lane's last trial: accepted / the candidate has to be looked at (filter bit) / neither
             bool take = false, test = false;
             uint32_t at = 0u;
-            // (looking at the runaway-rejection cap only when some lane is within a burst of it -- TRW_LAZY_CAP=1 --
-            // measured 1.5 % SLOWER than the plain per-trial compare: kept as the A/B switch it was)
-#ifndef TRW_LAZY_CAP
-#define TRW_LAZY_CAP 0
-#endif
-            const bool near_cap = TRW_LAZY_CAP ? __ballot(busy && rejected + 2u * kPoolPairs >= kTrialCap) != 0 : true;
+            // (looking at the runaway-rejection cap only when some lane is within a burst of it measured 1.5 % SLOWER
+            // than the plain per-trial compare)
 
             auto trial = [&](uint32_t rc, uint32_t ru, bool forced) {
                 if (kCount && !forced) ++n_trials;
@@ -2073,11 +2023,9 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                 uint32_t v = (idx - pos_lo < pos_cnt) ? (ru < bp.t0 ? 1u : 0u) : v_other;
                 v = forced ? 1u : v;  // the first step takes whatever it drew (no acceptance draw is consumed)
                 rejected = v == 0u ? rejected + 1u : rejected;
-                if (near_cap) {
-                    if (rejected >= kTrialCap) {  // take whatever this trial drew
-                        st |= (uint32_t)kStTrialCap;
-                        v = 1u;
-                    }
+                if (rejected >= kTrialCap) {  // take whatever this trial drew
+                    st |= (uint32_t)kStTrialCap;
+                    v = 1u;
                 }
                 take = v == 1u;
                 test = v == 2u;
@@ -2131,12 +2079,7 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                 }
                 P[PF_FLAGS][slot] = nf;
             }
-            if (kSplit) {
-                issue_q.push(to_issue && take, slot);
-                probe_q.push(to_issue && !take, slot);
-            } else {
-                issue_q.push(to_issue, slot);
-            }
+            issue_q.push(to_issue, slot);
             trial_q.push(to_trial, slot);
             pool_fence();
         }
