@@ -73,6 +73,27 @@ def test_ninth_walk_builds_the_long_row_masks_unless_prepared_by_hand(rw):
     rw.check_status()
 
 
+def test_uniform_entries_join_once_the_calls_add_up_to_the_graph(rw):
+    """One uniform call smaller than the graph is not worth the 16-byte entries (trw_prepare_plan); several are: the cache
+    builds them with the call at which the steps made so far reach the entry count, and the walks stay the reference's."""
+    from torch_random_walk_amd import graphs
+    n = 1_000_000
+    d_rp, d_ci = graphs.rmat(n, 9_000_000, seed=3, device=DEV)          # 10 M entries: beyond the caches
+    nnz = d_ci.numel()
+    d_tg = torch.arange(0, n, 3, device=DEV)                              # 333 334 walkers x 12 = 4 M steps a call
+    rp, ci, tg = d_rp.cpu().numpy(), d_ci.cpu().numpy(), d_tg.cpu().numpy()
+    head = O.walk(rp, ci, tg[:64], 1.0, 1.0, 12, 5)                      # (the uniform stream is indexed by walker)
+    tail = O.walk(rp, ci, tg[-64:], 1.0, 1.0, 12, 5, walker_base=len(tg) - 64)
+    calls_needed = -(-nnz // (len(tg) * 12))
+    assert calls_needed >= 2
+    for k in range(1, calls_needed + 2):
+        got = rw.walk(d_rp, d_ci, d_tg, 1.0, 1.0, 12, 5)
+        has = bool(rw.cache_info()[0][2] & rw.PREP_UNIFORM)
+        assert has == (k >= calls_needed), (k, calls_needed, rw.cache_info())
+        assert (got[:64].cpu().numpy() == head).all() and (got[-64:].cpu().numpy() == tail).all()
+    rw.check_status()
+
+
 def test_in_place_write_invalidates(rw):
     rp, ci = random_graph(400, 6, 3)
     tg = np.arange(400).repeat(20)

@@ -151,6 +151,7 @@ struct PreparedGraph {
     void *ready = nullptr;        // event recorded after the prepare kernels
     void *built_on = nullptr;     // the stream they ran on
     int64_t biased_walks = 0;
+    int64_t uniform_steps = 0;    // steps of reference-exact uniform walks made over this graph so far
     int32_t refused = 0;          // TRW_PREP_* bits whose allocation failed once: not asked for again
     bool pinned = false;          // rw.prepare(): not upgraded/evicted behind the caller's back
     PreparedGraph(c10::weak_intrusive_ptr<c10::StorageImpl> a, c10::weak_intrusive_ptr<c10::StorageImpl> b)
@@ -238,7 +239,8 @@ struct PreparedUse {
 // The prepared graph for this call (built or upgraded as needed); !valid when the call should prepare for
 // itself (cache off, capture in progress, uncacheable tensors).
 PreparedUse prepared_for(const torch::Tensor &rp, const torch::Tensor &ci, int32_t needed, bool biased_walk, bool pin,
-                         const c10::hip::HIPStreamMasqueradingAsCUDA &torch_stream, int kind = 0, int64_t pad = 0)
+                         const c10::hip::HIPStreamMasqueradingAsCUDA &torch_stream, int kind = 0, int64_t pad = 0,
+                         int64_t uniform_steps = 0)
 {
     void *const stream = (void *)torch_stream.stream();
     PreparedUse use;
@@ -277,6 +279,13 @@ PreparedUse prepared_for(const torch::Tensor &rp, const torch::Tensor &ci, int32
         // (R-MAT 10M/110M) and take 13 % off every later walk.  Not behind rw.prepare()'s back: that graph has what was asked.
         if (biased_walk && (want & TRW_PREP_MARKS) && hit->biased_walks >= kFullMarksAfter && !hit->pinned)
             want |= TRW_PREP_MARKS_FULL;
+        // One uniform call is worth the 16-byte entries when it makes more steps than the graph has entries
+        // (trw_prepare_plan); calls that are smaller than that each -- one GPU's shard of BASELINE configs[3] -- are
+        // worth them together: from the call on with which the steps made over this graph reach its entry count.
+        hit->uniform_steps += uniform_steps;
+        const int64_t nnz = ci.numel();
+        if (uniform_steps > 0 && !hit->pinned && hit->uniform_steps >= nnz && (rp.numel() + nnz) * 4 > (int64_t(32) << 20))
+            want |= TRW_PREP_UNIFORM;
         want &= ~hit->refused;
         if (want & TRW_PREP_MARKS_FULL) want |= TRW_PREP_MARKS;
         if (want & TRW_PREP_MARKS) want |= TRW_PREP_BIASED;
@@ -358,8 +367,11 @@ torch::Tensor walk_ex(const torch::Tensor &row_ptr, const torch::Tensor &col_idx
     const bool biased_parallel = !(p == 1.0 && q == 1.0) && !serial_replay;
     PreparedUse prepared;
     // (a strided input was copied by .contiguous() above: a temporary is not worth a cache entry)
+    // reference-exact uniform walks over the narrow layout: their steps count towards the 16-byte entries
+    const bool uniform_exact = p == 1.0 && q == 1.0 && rng_mode != TRW_RNG_WALKER;
     if (n_walkers > 0 && needed >= 0 && rp.is_same(row_ptr) && ci.is_same(col_idx))
-        prepared = prepared_for(rp, ci, needed, biased_parallel, false, stream);
+        prepared = prepared_for(rp, ci, needed, biased_parallel, false, stream, 0, 0,
+                                uniform_exact ? n_walkers * walk_length : 0);
 
     torch::Tensor workspace;
     int rc;

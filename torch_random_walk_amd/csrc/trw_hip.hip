@@ -642,10 +642,12 @@ static int walk_prepared(const void *prepared, size_t prepared_bytes, int32_t wh
             trw::seed_window(seed, sw.w);
             glibc_windows_kernel<<<lane_grid, kBlock, 0, stream>>>(sw, (uint64_t)walker_base * (uint64_t)L,
                                                                   (uint64_t)cl.G * (uint64_t)L, cl.nlanes, win);
-            // fat entries pay from about nnz steps in the batch (see plan_what); below that the compact shadow wins
-            // even when the entries are there
-            const bool use_fat = pl.ext16 && (env_long("TRW_EXT", 0, 1, -1) == 1 ||
-                                              (__int128)n_walkers * L >= (__int128)nnz);
+            // BUILDING the fat entries pays from about nnz steps (plan_what: in one batch; the torch layer's cache: over
+            // the calls made so far).  Once they are there they are used by every batch that is not small next to the
+            // graph -- one gather per step instead of two (a shard of BASELINE configs[3], 0.65 nnz steps: 41.7 -> 30.4
+            // ms); a small batch revisits few rows and is better off with the compact shadow.
+            const long ext_forced = env_long("TRW_EXT", 0, 1, -1);
+            const bool use_fat = pl.ext16 && (ext_forced == 1 || (ext_forced == -1 && (__int128)n_walkers * L * 4 >= (__int128)nnz));
             if (pl.narrow && rows_fit && use_fat)
                 uniform_glibc_rows_kernel<true><<<lane_grid, kBlock, 0, stream>>>(
                     row32, col32, (const u32x4_a16 *)(pw + pl.off_ext16), targets, n_nodes, n_walkers, walk_length,
