@@ -1670,6 +1670,7 @@ enum : int {
 };
 // kPfFirst: the slot's next draw is the walk's first step; kPfWide: t's run in prev's row does not fit PF_RPOS
 constexpr uint32_t kPfExact = 1u, kPfOdd = 2u, kPfFirst = 4u, kPfWide = 8u;
+constexpr uint32_t kPfSkip = 128u;  // table lookup, first pair: the chain starts at the pair's SECOND slot
 constexpr uint32_t kPfKind = 7u << 4, kPfRejShift = 8, kPfRejMask = 0x1FFFFFu << 8, kPfProbeShift = 29, kPfProbe = 7u << 29;
 static_assert(kTrialCap <= (kPfRejMask >> kPfRejShift), "the rejection count must fit its field");
 
@@ -1836,16 +1837,27 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                     P[PF_X][slot] = e0.x;
                     P[PF_FLAGS][slot] = (P[PF_FLAGS][slot] & ~(kPfKind | kPfProbe)) | (PK_MEMBER << 4);
                     to_issue = true;
-                } else {  // PK_MEMBER / PK_POS: e0 = {u, v, lo, cnt-1} of one table slot
+                } else {  // PK_MEMBER / PK_POS: e0, e1 = an aligned PAIR of table slots {u, v, lo, cnt-1}
+                    // (both halves of one 32-byte chunk, i.e. of one cache line: the probe chain of a key starts at its
+                    // slot s0 and runs slot by slot; pair p of a lookup is slots 2 (s0/2 + p), +1 -- in pair 0 the
+                    // slot BEFORE an odd s0 is not part of the chain)
                     if (kCount) ++n_probes;
                     const uint32_t t = P[PF_T][slot], prev = P[PF_PREV][slot];
                     const uint32_t ku = hkind == PK_MEMBER ? t : prev, kv = hkind == PK_MEMBER ? P[PF_X][slot] : t;
                     uint32_t flags = P[PF_FLAGS][slot];
-                    bool empty = e0.x == 0xFFFFFFFFu;
-                    bool match = e0.x == ku && e0.y == kv;
+                    const bool skip0 = (flags & kPfSkip) != 0u;  // (set by the issue phase, which has the slot number)
+                    flags &= ~kPfSkip;
+                    bool empty = !skip0 && e0.x == 0xFFFFFFFFu;
+                    bool match = !skip0 && e0.x == ku && e0.y == kv;
+                    if (!empty && !match) {  // the second slot of the pair
+                        empty = e1.x == 0xFFFFFFFFu;
+                        match = e1.x == ku && e1.y == kv;
+                        e0.z = e1.z;
+                        e0.w = e1.w;
+                    }
                     if (!empty && !match && (flags & kPfProbe) == kPfProbe) {
                         // the chain is longer than the probe field counts: this lane walks the rest of it here
-                        uint64_t sl = (edge_slot(ku, kv, mask) + 8u) & mask;
+                        uint64_t sl = (((edge_slot(ku, kv, mask) >> 1) + 8u) << 1) & mask;
                         while (true) {
                             const u32x4_a16 g = *reinterpret_cast<const u32x4_a16 *>(table + 4 * sl);
                             if (kCount) ++n_probes;
@@ -1966,10 +1978,11 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                 } else {
                     const uint32_t t = P[PF_T][slot], prev = P[PF_PREV][slot];
                     const uint64_t s0 = kind == PK_MEMBER ? edge_slot(t, P[PF_X][slot], mask) : edge_slot(prev, t, mask);
-                    addr = table + 4 * ((s0 + (flags >> kPfProbeShift)) & mask);
+                    addr = table + 4 * ((((s0 >> 1) + (flags >> kPfProbeShift)) << 1) & mask);  // an aligned pair of slots
+                    if ((flags & kPfProbe) == 0u && (s0 & 1u) != 0u) P[PF_FLAGS][slot] = flags | kPfSkip;
                 }
                 e0 = *reinterpret_cast<const u32x4_a4 *>(addr);
-                if (kind == PK_ENTRY) e1 = *reinterpret_cast<const u32x4_a4 *>(addr + 4);
+                if (kind != PK_ROW && kind != PK_TEST) e1 = *reinterpret_cast<const u32x4_a4 *>(addr + 4);
                 hold = true;
                 hs = slot;
                 hkind = kind;
