@@ -481,8 +481,9 @@ def main():
         if family in (4, 5):
             # biased_pool_kernel / biased_mask_kernel, bytes the algorithm as run must move: per walker 8 B target + 8 B row32 pair; per
             # column 8 B stored; 32 B per fat entry gathered (every accepted offset, plus candidates the table is
-            # asked about); per table probe 32 B in the walker pool (an aligned pair of slots), 16 B in the mask kernel.
-            alg_bytes = B * 16 + 8 * B * (L + 1) + 32 * fetches + (32 if family == 5 else 16) * probes
+            # asked about); 16 B per table probe (the walker pool reads an aligned PAIR of slots per probe, 32 B of one
+            # line; the second slot is speculation and is not counted).
+            alg_bytes = B * 16 + 8 * B * (L + 1) + 32 * fetches + 16 * probes
         else:
             # int64-API-layout bytes (with this kernel's own counts): per walker 8 B target + 8 B column 0
             # + 32 B first step; per later step 16 B row_ptr pair + 8 B stored column; 8 B per candidate entry loaded
