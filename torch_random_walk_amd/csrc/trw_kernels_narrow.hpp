@@ -12,9 +12,15 @@
 //   csr_ext_kernel            fat entries {v, start(v), deg(v)}: one gather per step
 //   uniform_glibc_rows_kernel reference-exact uniform walk; the wave writes its 64 rows one
 //                             aligned 64-byte line at a time through an LDS ring (WaveRows)
-//   biased_hash_kernel        node2vec rejection sampling on the per-walker stream, large
-//                             batches: edge table + per-lane state machine
+//   edge_table_build_kernel   open-addressing set of the edges {u, v, first offset, multiplicity}
+//   csr_ext32_kernel (+heavy) 32-byte entries for the biased walk: the neighbour's row, where the node
+//                             being left sits in it, a 128-bit mask answering is_neighbor per offset
+//   biased_pool_kernel        node2vec rejection sampling on the per-walker stream, the default: a pool of
+//                             walkers per wave in LDS, lanes as executors (sorted rows, prepared entries)
+//   biased_mask_kernel        the same over the same entries, one walker per lane (>= 2^32 walkers)
+//   biased_hash_kernel        the same for graphs with unsorted rows: edge table + per-lane state machine
 //   biased_walker_kernel      the same walk for small batches (bisection instead of the table)
+//   biased_glibc_wave_kernel  the reference's ONE serial glibc stream, replayed by a whole wave
 //
 // Included by trw_hip.hip only.  Valid for n_nodes < 2^31 and nnz < 2^32.
 #pragma once
