@@ -8,7 +8,7 @@ TAG=${2:-r02}
 OUT=gpurun_out/prof_${TAG}_${WL}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 bench.py --workload $WL --steps 3 --warmup 2 --no-cpu-baseline"
+BENCH="python3 bench.py --workload $WL --steps 3 --warmup 2 --no-cpu-baseline --steady"   # (--steady: every launch of the walk kernel is a steady-state one)
 echo "== stats pass" | tee "$OUT/log.txt"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- $BENCH > "$OUT/bench_stats.json" 2>> "$OUT/log.txt" || echo "stats pass rc=$?" >> "$OUT/log.txt"
 for PASS in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_THREAD_CYCLES_VALU" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum" "GRBM_GUI_ACTIVE GRBM_COUNT" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA"; do
