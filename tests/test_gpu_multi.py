@@ -95,6 +95,35 @@ def test_bench_launches_its_own_ranks():
     assert line["config"]["global_walkers"] == 2 * line["config"]["walkers_per_gpu"]
 
 
+def test_bench_line_carries_the_contract_fields():
+    """One JSON line with the driver's fields, the roofline of the dominant kernel and the CPU baseline."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "rmat1m_biased", "--steps", "2",
+                          "--warmup", "1", "--cpu-seconds", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["metric"] == "walk-steps/s" and line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1
+    assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["vs_baseline"] is None
+    assert line["dtype"] == "int64" and "synthetic" in line["data"] and line["config"]["workload"] == "rmat1m_biased"
+    roof = line["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and roof["kernel"] == "biased_pool_kernel"
+    cpu = line["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cpu, key
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["unit"] == line["unit"]
+    assert line["value"] > 1e3 * cpu["value"]
+
+
 def _sparse_host_csr(rp, ci, nodes):
     """Host CSR with the same node count in which only `nodes` keep their rows (the others are empty, so an
     oracle walk that left the GPU's path would stop with a degree-0 error): lets the oracle check rows of a
