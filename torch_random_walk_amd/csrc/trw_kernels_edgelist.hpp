@@ -728,6 +728,9 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
 
     while (true) {
         // ================= adopt =================
+#if TRW_POOL_PRIO
+        __builtin_amdgcn_s_setprio(TRW_POOL_PRIO == 1 ? 3 : 0);  // (cf. biased_pool_kernel)
+#endif
         {
             bool to_trial = false, to_issue = false, to_free = false;
             if (kCount) {  // how many gathers of each kind were consumed (status[12 + kind]) and in how many passes ([19])
@@ -953,6 +956,9 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
         }
 
         // ================= burst =================
+#if TRW_POOL_PRIO
+        __builtin_amdgcn_s_setprio(TRW_POOL_PRIO == 1 ? 0 : 3);
+#endif
         if (trial_q.count >= kPoolTrialMin || (trial_q.count > 0u && issue_q.count < kPoolIssueMin)) {
             uint32_t n, slot;
             trial_q.pop(lane, n, slot);
