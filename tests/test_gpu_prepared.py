@@ -56,20 +56,29 @@ def test_second_walk_reuses_the_prepared_graph_and_third_has_full_marks(rw):
     rw.check_status()
 
 
-def test_ninth_walk_builds_the_long_row_masks_unless_prepared_by_hand(rw):
+def test_masks_of_longer_rows_join_with_the_steps_made_unless_prepared_by_hand(rw):
+    """The wave-per-entry marking passes are built by the first node2vec walk that finds 6 (rows up to 256) / 55 (up to
+    1 024) steps per CSR entry behind it on this graph -- never by the first walk, never behind rw.prepare()'s back."""
     rp, ci = hub_graph(1500, 6)
     tg = np.random.default_rng(3).integers(0, 1500, 8000)
     d_rp, d_ci, d_tg = _dev(rp, ci, tg)
     ref = O.walk(rp, ci, tg, 0.25, 4.0, 12, 4, rng_mode=O.RNG_WALKER)
-    for k in range(10):
+    steps, nnz = len(tg) * 12, len(ci)
+    n_calls = 55 * nnz // steps + 3
+    seen = set()
+    for k in range(n_calls):
         assert (rw.walk(d_rp, d_ci, d_tg, 0.25, 4.0, 12, 4).cpu().numpy() == ref).all()
-        full = bool(rw.cache_info()[0][2] & rw.PREP_MARKS_FULL)
-        assert full == (k >= 8), (k, rw.cache_info())
+        what = rw.cache_info()[0][2]
+        behind = k * steps // nnz                                    # steps per entry made before this walk
+        assert bool(what & rw.PREP_MARKS) == (k >= 1 and behind >= 6), (k, behind, what)
+        assert bool(what & rw.PREP_MARKS_FULL) == (behind >= 55), (k, behind, what)
+        seen.add(what)
+    assert len(seen) == 3                                             # entries -> + marks -> + long-row marks
     rw.clear_cache()
-    assert rw.prepare(d_rp, d_ci) == rw.PREP_BIASED | rw.PREP_MARKS          # the caller's choice stays as it is
-    for k in range(10):
+    assert rw.prepare(d_rp, d_ci, marks=False) == rw.PREP_BIASED     # the caller's choice stays as it is
+    for k in range(n_calls):
         rw.walk(d_rp, d_ci, d_tg, 0.25, 4.0, 12, 4)
-    assert rw.cache_info()[0][2] == rw.PREP_BIASED | rw.PREP_MARKS
+    assert rw.cache_info()[0][2] == rw.PREP_BIASED
     rw.check_status()
 
 
@@ -156,7 +165,7 @@ def test_every_marking_path_walks_the_same_rows(rw, deg, inline_cap, monkeypatch
     if inline_cap is not None:
         monkeypatch.setenv("TRW_COMMON_MAX", inline_cap)
     rp, ci = random_graph(400, deg, 11)
-    tg = np.random.default_rng(1).integers(0, 400, 5000)
+    tg = np.random.default_rng(1).integers(0, 400, 20000)       # (enough steps per entry for the second walk to add the marks)
     d_rp, d_ci, d_tg = _dev(rp, ci, tg)
     for p, q in ((0.25, 4.0), (4.0, 0.25)):
         ref = O.walk(rp, ci, tg, p, q, 25, 9, rng_mode=O.RNG_WALKER)

@@ -131,10 +131,9 @@ torch::Tensor walk_cpu_leg(const torch::Tensor &row_ptr, const torch::Tensor &co
 // the walk kernel (SURVEY 8(b) "Ownership": cached derived data keyed on data_ptr/version).  An entry is valid for
 // exactly the storages it was built from, while they are alive (weak references: a freed-and-reused address can
 // not match) and unmodified (tensor version counters: an in-place write invalidates).  Policy: the first walk
-// builds what a single call of its shape is worth; the second node2vec walk over the same graph also builds the
-// neighbourhood masks of longer rows (TRW_PREP_MARKS: about 3.5x the prepare time, then every later walk is 30 %
-// faster) and the ninth those of rows up to 1 024 entries (TRW_PREP_MARKS_FULL); rw.prepare() asks for them up front
-// (marks=True / marks="full").  Least-recently-used graphs beyond `capacity` are dropped; entries whose
+// builds what a single call of its shape is worth; later node2vec walks over the same graph also build the
+// neighbourhood masks of longer rows (TRW_PREP_MARKS, TRW_PREP_MARKS_FULL) once the steps made over the graph
+// warrant the pass (kMarksAfterStepsPerEntry below); rw.prepare() asks for them up front (marks=True / marks="full").  Least-recently-used graphs beyond `capacity` are dropped; entries whose
 // tensors died are dropped at the next call.  TRW_CACHE=0 (or set_cache(False)) turns the cache off: every
 // call then prepares into its own workspace, as trw_walk_csr_hip does.  Calls on a stream that is being captured
 // into a HIP graph never use the cache (a replay must not depend on memory the cache may drop).
@@ -151,6 +150,7 @@ struct PreparedGraph {
     void *ready = nullptr;        // event recorded after the prepare kernels
     void *built_on = nullptr;     // the stream they ran on
     int64_t biased_walks = 0;
+    int64_t biased_steps = 0;     // steps of node2vec walks (per-walker stream) made over this graph so far
     int64_t uniform_steps = 0;    // steps of reference-exact uniform walks made over this graph so far
     int32_t refused = 0;          // TRW_PREP_* bits whose allocation failed once: not asked for again
     bool pinned = false;          // rw.prepare(): not upgraded/evicted behind the caller's back
@@ -159,7 +159,13 @@ struct PreparedGraph {
     ~PreparedGraph() { trw_event_destroy(ready); }
 };
 
-constexpr int64_t kFullMarksAfter = 8;  // node2vec walks over one graph before the cache builds TRW_PREP_MARKS_FULL
+// When a graph that is walked again gets more of its neighbourhood masks, in node2vec steps already made over it per
+// CSR entry.  The wave-per-entry pass for rows up to 256 entries costs 0.6 ns per entry and takes 0.05 ns off every
+// later step: it is built by the first walk that finds 6 steps per entry behind it -- the SECOND walk of a batch with one
+// 80-step walker per node of a graph of average degree 11, the eleventh of one GPU's eighth of such a batch, and not at
+// all by a stream of 400-walker batches (a 100 ms pass in front of a 3 ms walk).  Rows up to 1 024: 0.5 ns per entry
+// for 0.006 ns per step, from 55 steps per entry on (the ninth full batch).
+constexpr int64_t kMarksAfterStepsPerEntry = 6, kFullMarksAfterStepsPerEntry = 55;
 std::mutex g_cache_mu;
 std::list<std::shared_ptr<PreparedGraph>> g_cache;  // most recently used first
 std::atomic<int64_t> g_cache_capacity{2};
@@ -240,7 +246,7 @@ struct PreparedUse {
 // itself (cache off, capture in progress, uncacheable tensors).
 PreparedUse prepared_for(const torch::Tensor &rp, const torch::Tensor &ci, int32_t needed, bool biased_walk, bool pin,
                          const c10::hip::HIPStreamMasqueradingAsCUDA &torch_stream, int kind = 0, int64_t pad = 0,
-                         int64_t uniform_steps = 0)
+                         int64_t uniform_steps = 0, int64_t biased_steps = 0)
 {
     void *const stream = (void *)torch_stream.stream();
     PreparedUse use;
@@ -273,12 +279,15 @@ PreparedUse prepared_for(const torch::Tensor &rp, const torch::Tensor &ci, int32
     int32_t want = needed < 0 ? 0 : needed;
     if (hit->what >= 0) want |= hit->what;
     if (kind == 0) {
-        // the second node2vec walk over a graph is the sign that it is walked repeatedly: worth the full masks
-        if (biased_walk && (want & TRW_PREP_BIASED) && hit->biased_walks >= 1) want |= TRW_PREP_MARKS;
-        // ... and the ninth that it is walked epoch after epoch: the masks of rows up to 1 024 entries cost 70 ms more
-        // (R-MAT 10M/110M) and take 13 % off every later walk.  Not behind rw.prepare()'s back: that graph has what was asked.
-        if (biased_walk && (want & TRW_PREP_MARKS) && hit->biased_walks >= kFullMarksAfter && !hit->pinned)
+        // a graph that is walked again, and enough, is worth the masks of its longer rows (thresholds above); not behind
+        // rw.prepare()'s back: that graph has what was asked
+        const int64_t entries = ci.numel() > 0 ? ci.numel() : 1;
+        if (biased_walk && (want & TRW_PREP_BIASED) && hit->biased_walks >= 1 && !hit->pinned &&
+            hit->biased_steps / entries >= kMarksAfterStepsPerEntry)
+            want |= TRW_PREP_MARKS;
+        if (biased_walk && (want & TRW_PREP_MARKS) && !hit->pinned && hit->biased_steps / entries >= kFullMarksAfterStepsPerEntry)
             want |= TRW_PREP_MARKS_FULL;
+        hit->biased_steps += biased_steps;
         // One uniform call is worth the 16-byte entries when it makes more steps than the graph has entries
         // (trw_prepare_plan); calls that are smaller than that each -- one GPU's shard of BASELINE configs[3] -- are
         // worth them together: from the call on with which the steps made over this graph reach its entry count.
@@ -371,7 +380,7 @@ torch::Tensor walk_ex(const torch::Tensor &row_ptr, const torch::Tensor &col_idx
     const bool uniform_exact = p == 1.0 && q == 1.0 && rng_mode != TRW_RNG_WALKER;
     if (n_walkers > 0 && needed >= 0 && rp.is_same(row_ptr) && ci.is_same(col_idx))
         prepared = prepared_for(rp, ci, needed, biased_parallel, false, stream, 0, 0,
-                                uniform_exact ? n_walkers * walk_length : 0);
+                                uniform_exact ? n_walkers * walk_length : 0, biased_parallel ? n_walkers * walk_length : 0);
 
     torch::Tensor workspace;
     int rc;
