@@ -692,7 +692,12 @@ static int walk_prepared(const void *prepared, size_t prepared_bytes, int32_t wh
         const bool pool_kernel = mask_kernel && n_walkers < ((int64_t)1 << 32) && env_long("TRW_POOL_KERNEL", 0, 1, 1) == 1;
         if (pool_kernel) {
             // 4 workgroups per CU: a wave's pool is 9.9 KB of LDS (kPoolSlots walkers x 19 words), 39.5 KB per workgroup
-            int64_t pblocks = (n_walkers + (int64_t)kPoolWaves * kPoolSlots - 1) / ((int64_t)kPoolWaves * kPoolSlots);
+            // (a batch that does not even give every CU one workgroup of 64-walker waves is bound by latency: its grid is
+            // sized for 64 walkers per wave instead of full pools -- 405 / 4 096 / 50 000 walkers: 2.0 / 2.1 / 2.3 ->
+            // 1.7 / 1.8 / 2.0 ms; from 200 000 walkers on half-filled pools lose, 2.5 -> 2.8 ms)
+            const bool small = n_walkers <= (int64_t)device_cu_count() * kPoolWaves * 64;
+            const int64_t per_block = (int64_t)kPoolWaves * (small ? 64 : kPoolSlots);
+            int64_t pblocks = (n_walkers + per_block - 1) / per_block;
             // TRW_POOL_SPARE_BLOCKS: workgroups to leave out of the persistent grid.  With every CU holding three of them
             // a kernel on another stream (an RCCL send/recv group) does not get on the chip until the walk is over
             // (scripts/overlap_probe.py); a few CUs with only two leave it room.  bench.py sets it for N > 1.
