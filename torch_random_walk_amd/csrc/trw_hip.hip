@@ -1000,7 +1000,9 @@ static int walk_edge_list_prepared(const void *prepared, size_t prepared_bytes, 
                 el_table, pl.hash_mask, out, status);
         else if (pl.ent && n_walkers < ((int64_t)1 << 32) && env_long("TRW_ELPOOL", 0, 1, 1) == 1) {
             // walker pool over the prepared entries: 3 workgroups per CU (a wave's pool: 124 walkers x 22 words + windows)
-            int64_t pblocks = (n_walkers + (int64_t)kPoolWaves * kElSlots - 1) / ((int64_t)kPoolWaves * kElSlots);
+            // (small batches: 64 walkers per wave, cf. the CSR pool)
+            const int64_t el_per_block = (int64_t)kPoolWaves * (n_walkers <= (int64_t)device_cu_count() * kPoolWaves * 64 ? 64 : kElSlots);
+            int64_t pblocks = (n_walkers + el_per_block - 1) / el_per_block;
             const int64_t president = (int64_t)device_cu_count() * env_long("TRW_ELPOOL_BLOCKS", 1, 8, 3);
             if (pblocks > president) pblocks = president;
             if (g_prof.count)
