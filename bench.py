@@ -39,7 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); a device copy sustains 4750 (machine probe)
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md; a float4 device copy sustains 6.29 TB/s there)
 
 WORKLOADS = {
     "rmat10m_biased": dict(graph="rmat", nodes=10_000_000, edges=100_000_000, p=0.25, q=4.0, walks_per_node=1),
@@ -92,6 +92,10 @@ def main():
     ap.add_argument("--seed", type=int, default=10)
     ap.add_argument("--graph-seed", type=int, default=1)
     ap.add_argument("--no-gather", action="store_true", help="N>1: leave the row blocks on their ranks")
+    ap.add_argument("--gather-chunks", type=int, default=4,
+                    help="N>1, CSR walks: row chunks per step; each chunk's transfer starts when its walk is done")
+    ap.add_argument("--wire", default="auto", choices=["auto", "int64"],
+                    help="N>1: what the row blocks travel as (auto: uint32 while node ids fit, widened on arrival)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo is a dry-run aid for the N>1 control flow on a single-GPU box (all ranks share "
@@ -213,15 +217,30 @@ def main():
     mode = rw.RNG_WALKER if (kg or elist or not uniform) else rw.RNG_GLIBC
     gather = (world > 1) and not args.no_gather
     full = None
-    fulls, step_no = [], [0]
-    # the CSR walk can write straight into the root's slice of the gathered result (walk_ex(out=...)); two result
-    # buffers alternate because the gather of step k is still landing while step k+1 walks
-    direct_root = gather and rank == 0 and not (windows or elist or kg)
+    fulls, lands, wires, step_no = [], [], [], [0]
+    csr = not (windows or elist or kg)
+    if windows:
+        cols = (L + 1 - cfg["window_size"] + 1) * (cfg["window_size"] - 1)
+    # What a block travels as (dist.wire_dtype_for): uint32 while every value fits -- node ids < n, the edge-list /
+    # triples walks' padding id n, relation ids < n -- half the bytes per xGMI link; widened where it lands.
+    wire32 = gather and args.wire != "int64" and (n + 1) <= (1 << 32)
+    wire_bytes = 4 if wire32 else 8
+    # The CSR walk is made in row chunks, each walked straight into its slice (walk_ex(out=...)) and handed to the
+    # transport as soon as it is enqueued: the gather of a step overlaps the rest of the SAME step's walk, and the
+    # next step's.  Two sets of buffers alternate because step k's blocks are still landing while step k+1 walks.
+    chunks = max(1, args.gather_chunks) if (gather and csr) else 1
+    side = torch.cuda.Stream(device=dev) if gather else None
     if gather and rank == 0:
-        if windows:
-            cols = (L + 1 - cfg["window_size"] + 1) * (cfg["window_size"] - 1)
-        fulls = [torch.empty((world * B, cols), dtype=torch.int64, device=dev) for _ in range(2 if direct_root else 1)]
+        fulls = [torch.empty((world * B, cols), dtype=torch.int64, device=dev) for _ in range(2)]
+        if wire32 or dry:
+            lands = [torch.empty((world * B, cols), dtype=torch.int32 if wire32 else torch.int64,
+                                 device="cpu" if dry else dev) for _ in range(2)]
         full = fulls[0]
+    elif gather:
+        if csr:
+            fulls = [torch.empty((B, cols), dtype=torch.int64, device=dev) for _ in range(2)]
+        if wire32:
+            wires = [torch.empty((B, cols), dtype=torch.int32, device=dev) for _ in range(2)]
 
     def walk(tg, base, check):
         if windows:   # "walkers" are walks here; the result the bench tracks is the negatives tensor
@@ -236,46 +255,84 @@ def main():
                                       check=check)
         return rw.walk_ex(row_ptr, col_idx, tg, p, q, L, args.seed, walker_base=base, rng_mode=mode, check=check)
 
-    def walk_once():
-        if direct_root:
-            dst = fulls[step_no[0] % 2]
-            return rw.walk_ex(row_ptr, col_idx, targets, p, q, L, args.seed, walker_base=walker_base, rng_mode=mode,
-                              check=False, out=dst[:B])
-        return walk(targets, walker_base, False)
-
     class _Pending:
-        def __init__(self, works, keep, after=None):
-            self.works, self.keep, self.after = works, keep, after
+        """The transfers of one step.  wait(): they have landed (and, on the root, have been widened into the int64
+        result) as far as the streams are concerned; nothing here blocks the host under RCCL."""
+        def __init__(self):
+            self.works, self.keep, self.pieces, self.k = [], [], [], 0
+            self.ev_first = self.ev_walked = self.ev_done = None
 
         def wait(self):
-            for w in self.works:
-                w.wait()
-            if self.after is not None:   # gloo dry run: the blocks came through host memory
-                self.after()
-                self.after = None
+            if rank != 0:
+                for w in self.works:
+                    w.wait()
+                return
+            land = lands[self.k % 2] if lands else None
+            dst = fulls[self.k % 2]
+            with torch.cuda.stream(side):
+                for w in self.works:
+                    w.wait()           # RCCL: the side stream waits; gloo (dry run): the host does
+                for lo_, hi_ in self.pieces:
+                    if land is None:
+                        continue
+                    got = land[lo_:hi_].to(dev, non_blocking=True) if dry else land[lo_:hi_]
+                    if wire32:
+                        rw.widen_rows(got, out=dst[lo_:hi_])
+                    else:
+                        dst[lo_:hi_].copy_(got)
+                self.ev_done = torch.cuda.Event(enable_timing=True)
+                self.ev_done.record(side)
 
-    def gather_async(walks):
-        """The one collective of the path: every rank's [B, cols] block lands in its slice of rank 0's
-        buffer.  Issued as one RCCL group of point-to-point transfers (what a gather is on xGMI: each
-        peer -> root pair rides its own link), straight into the destination slices -- no staging copy."""
+    walk_events = []   # (start, end) event pairs of the walk calls of the timed steps (N > 1)
+
+    def step_once(timed=False):
+        """One step: this rank's walks and, for N > 1, its share of the gather (posted, not waited for)."""
         nonlocal full
-        after = None
+        if not gather:
+            return walk(targets, walker_base, False), None
+        from torch_random_walk_amd.dist import chunk_bounds
+        k = step_no[0]
+        step_no[0] += 1
+        pend = _Pending()
+        pend.k = k
+        main = torch.cuda.current_stream()
         if rank == 0:
-            full = fulls[step_no[0] % 2] if direct_root else fulls[0]
-            step_no[0] += 1
-            if not direct_root:
-                full[:B].copy_(walks, non_blocking=True)
-            dst = full
-            if dry:   # gloo moves host memory: receive there, copy in when the transfers are done
-                dst = torch.empty((world * B, full.shape[1]), dtype=torch.int64)
-                tgt = full
-
-                def after(dst=dst, tgt=tgt):
-                    tgt[B:].copy_(dst[B:])
-            ops = [dist.P2POp(dist.irecv, dst[r * B:(r + 1) * B], r) for r in range(1, world)]
-        else:
-            ops = [dist.P2POp(dist.isend, walks.cpu() if dry else walks, 0)]
-        return _Pending(dist.batch_isend_irecv(ops) if ops else [], walks, after)
+            full = fulls[k % 2]
+            main.wait_stream(side)   # step k-2's blocks were widened out of / into these two buffers on the side stream
+        mine = fulls[k % 2][:B] if (csr or rank == 0) else None
+        for c in range(chunks):
+            c_lo, c_hi = chunk_bounds(0, B, chunks, c)
+            if c_hi <= c_lo:
+                continue
+            if rank == 0:   # receives first: the peers' chunk c travels while the root walks its own
+                recv_into = lands[k % 2] if lands else fulls[k % 2]
+                ops = [dist.P2POp(dist.irecv, recv_into[r * B + c_lo:r * B + c_hi], r) for r in range(1, world)]
+                pend.works += dist.batch_isend_irecv(ops)
+                pend.pieces += [(r * B + c_lo, r * B + c_hi) for r in range(1, world)]
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev0.record(main)
+            if csr:
+                blk = rw.walk_ex(row_ptr, col_idx, targets[c_lo:c_hi], p, q, L, args.seed, walker_base=walker_base + c_lo,
+                                 rng_mode=mode, check=False, out=mine[c_lo:c_hi])
+            else:
+                blk = walk(targets, walker_base, False)
+                if rank == 0:
+                    mine.copy_(blk, non_blocking=True)
+            ev1.record(main)
+            if timed:
+                walk_events.append((k, ev0, ev1))
+            if rank == 0:
+                if pend.ev_first is None:
+                    pend.ev_first = ev1
+                pend.ev_walked = ev1
+            else:
+                w = rw.narrow_rows(blk, out=wires[k % 2][c_lo:c_hi]) if wire32 else blk
+                if dry:
+                    w = w.cpu()
+                pend.keep.append(w)
+                pend.works += dist.batch_isend_irecv([dist.P2POp(dist.isend, w, 0)])
+        return (mine if mine is not None else blk), pend
 
     walks = None
     # Warm-up calls are where a graph gets prepared (rw.walk keeps the prepared graph of the tensors it has seen:
@@ -292,9 +349,9 @@ def main():
             # (1) the first call over a graph nobody has prepared: what a one-off caller pays, prepare pass included
             torch.cuda.synchronize()
             t_c = time.perf_counter()
-            walks = walk_once()
-            if gather:
-                gather_async(walks).wait()
+            walks, pend = step_once()
+            if pend is not None:
+                pend.wait()
             torch.cuda.synchronize()
             cold = dict(first_call_ms=(time.perf_counter() - t_c) * 1e3)
             if lib.trw_profile_prepare_last(ctypes.byref(pm)) == 0:
@@ -313,9 +370,9 @@ def main():
             cold["prepare_kernels_ms"] = pm.value
     for _ in range(args.warmup):
         walks = None   # let the allocator hand the same block out again (matters when a result is tens of GB)
-        walks = walk_once()
-        if gather:
-            gather_async(walks).wait()
+        walks, pend = step_once()
+        if pend is not None:
+            pend.wait()
         pm = ctypes.c_double()
         if lib.trw_profile_prepare_last(ctypes.byref(pm)) == 0:
             cold_prepare_ms.append(pm.value)
@@ -330,17 +387,20 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     pending = None
+    timed_steps = []
     for _ in range(args.steps):
         walks = None
-        walks = walk_once()
-        if gather:
-            work = gather_async(walks)
+        walks, work = step_once(timed=True)
+        if work is not None:
+            timed_steps.append(work)
             if pending is not None:
                 pending.wait()
             pending = work
         a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         # reading the events of step k waits for that step's kernels; the next step is not queued yet
-        if lib.trw_profile_last(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) == 0:
+        # (N > 1 with a gather: the walk calls are timed with events read after the region instead -- nothing may
+        # hold the host back between a chunk's walk and the next one's)
+        if not gather and lib.trw_profile_last(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) == 0:
             prepare_ms.append(a.value)
             kernel_ms.append(b.value)
             finish_ms.append(c.value)
@@ -353,10 +413,29 @@ def main():
     elapsed = time.perf_counter() - t0
     lib.trw_profile_enable(0)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dry else dev)
+    multi = None
+    if gather:
+        # walk time of a step = its chunk calls, from events on the launch stream (whole calls: launch checks, the walk
+        # kernel, the status seed); max over ranks.  Gather: on the root, from the moment its first own chunk is
+        # walked (the peers' first chunks start travelling about then) until the last block is widened in place.
+        per_step = {}
+        for k, ev0, ev1 in walk_events:
+            per_step[k] = per_step.get(k, 0.0) + ev0.elapsed_time(ev1)
+        kernel_ms = [per_step[k] for k in sorted(per_step)]
+        g_ms = [w.ev_first.elapsed_time(w.ev_done) for w in timed_steps] if rank == 0 else []
+        g_tail = [max(0.0, w.ev_walked.elapsed_time(w.ev_done)) for w in timed_steps] if rank == 0 else []
+        multi = dict(wire_dtype="uint32" if wire32 else "int64", bytes_per_rank=B * cols * wire_bytes,
+                     gather_chunks=chunks, backend=args.backend,
+                     gather_ms=sum(g_ms) / max(1, len(g_ms)),
+                     gather_after_root_walk_ms=sum(g_tail) / max(1, len(g_tail)),
+                     root_ingest_bytes_per_step=(world - 1) * B * cols * wire_bytes)
+    t = torch.tensor([elapsed, sum(kernel_ms) / max(1, len(kernel_ms)) if gather else 0.0], dtype=torch.float64,
+                     device="cpu" if dry else dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = float(t[0].item())
+    if multi is not None:
+        multi["walk_kernel_ms"] = float(t[1].item())   # max over ranks of the mean walk time per step
 
     # ---- device-side status of the last step (validity of what was timed) -------------------
     if not args.steady:
@@ -530,7 +609,9 @@ def main():
             # (scripts/machine_probe.hip measures it on the box: the same for 4-, 8- and 16-byte gathers), not by
             # bytes: quote the kernel's miss rate against that measured ceiling next to the HBM roofline.
             ceiling, copy_gbs = None, None
-            with open(os.path.join(ROOT, "profiles", "r01_machine_probe.txt")) as f:
+            import glob
+            probe_path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_machine_probe.txt")))[-1]
+            with open(probe_path) as f:
                 for ln in f:
                     tok = ln.split()
                     if ln.startswith("stream_copy"):
@@ -542,8 +623,9 @@ def main():
                 request_rate = dict(l2_misses_per_launch=misses, achieved_per_s=misses / (k_ms * 1e-3),
                                     ceiling_per_s=ceiling, frac=misses / (k_ms * 1e-3) / ceiling,
                                     measured_stream_copy_GBps=copy_gbs,
-                                    source="profiles/pmc_traffic.json (TCC_MISS) / profiles/r01_machine_probe.txt "
-                                           "(dependent random gathers over >= 4 GB, 8 waves per SIMD)")
+                                    source="profiles/pmc_traffic.json (TCC_MISS) / profiles/%s "
+                                           "(dependent random gathers over >= 4 GB, 8 waves per SIMD)"
+                                           % os.path.basename(probe_path))
     except Exception as e:   # noqa: BLE001 -- the PMC figures are optional
         traffic_source = dict(file="profiles/pmc_traffic.json", error=repr(e))
 
@@ -674,9 +756,10 @@ def main():
                 "walkers_per_gpu": B, "global_walkers": world * B,
                 "rng": "per-walker philox4x32-10" if mode == rw.RNG_WALKER else "glibc-indexed (csrc/cpu-exact)",
                 "partition": "start nodes block-sharded, CSR replicated",
-                "collective": ("one RCCL gather to rank 0 per step (a group of peer->root transfers into the "
-                               "destination slices), inside the timed region, overlapped with the next step's "
-                               "walk") if gather else "none",
+                "collective": ("one RCCL gather to rank 0 per step (groups of peer->root transfers, %d row chunks, %s on "
+                               "the wire, widened into the destination slices), inside the timed region, overlapped "
+                               "with the rest of the step's walk and the next step's" % (
+                                   chunks, "uint32" if wire32 else "int64")) if gather else "none",
             },
             "roofline": {
                 "bound": "hbm",
@@ -700,6 +783,7 @@ def main():
                 "reference_accounting": reference_accounting,
             },
             "cpu_baseline": cpu,
+            "multi_gpu": multi,
             "graph_build_s": t_graph,
             "peak_hbm_gb": torch.cuda.max_memory_allocated() / 1e9,   # rank 0: graph + workspace + results (+ generator temporaries)
         }

@@ -345,6 +345,19 @@ int trw_to_windows_triples_cpu(const int64_t *walks, int64_t num_walks, int64_t 
                                int64_t padding_idx, const int64_t *triples, int64_t num_triples, int32_t seed,
                                int32_t cbow, int64_t *target_triples, int64_t *pos_windows, int64_t *neg);
 
+/*
+ * Wire format of the multi-GPU gather (no reference counterpart: the reference is single-device,
+ * csrc/cuda/rw_cuda.cu:198).  Node ids are < n_nodes, so while n_nodes <= 2^32 a block of rows travels as uint32 --
+ * half the bytes per xGMI link -- and is widened where it lands.  `rows` / `wire`: `count` elements each, any
+ * alignment (16-byte aligned blocks take the vector path); asynchronous on `hip_stream`.  `overflow` (optional,
+ * device int64, zeroed by the caller): bit 0 is set when some value did not fit 32 bits.  The *_cpu forms are the
+ * host legs (HOST pointers, synchronous).
+ */
+int trw_rows_narrow_hip(const int64_t *rows, int64_t count, uint32_t *wire, int64_t *overflow, void *hip_stream);
+int trw_rows_widen_hip(const uint32_t *wire, int64_t count, int64_t *rows, void *hip_stream);
+int trw_rows_narrow_cpu(const int64_t *rows, int64_t count, uint32_t *wire, int64_t *overflow);
+int trw_rows_widen_cpu(const uint32_t *wire, int64_t count, int64_t *rows);
+
 /* Synchronises `hip_stream` and copies the status block of the last walk that
  * used `workspace` to the host: status[0] = OR of TRW_ST_* bits,
  * status[1] = 1 if some CSR row was found unsorted (biased walks only; the

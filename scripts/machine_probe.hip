@@ -99,6 +99,48 @@ static double run_gather(const uint32_t *buf, size_t footprint_bytes, int blocks
     return (double)blocks * 256.0 * iters * kIlp / (ms * 1e-3);
 }
 
+// float4 copy kernels (the yardstick MI355X_MICROARCH.md quotes: 6.29 TB/s read+write): every thread moves `per`
+// float4 per trip, the trips of a block are contiguous; plain or non-temporal accesses.
+typedef float f32x4_p __attribute__((ext_vector_type(4)));
+template <int kPer, bool kNt>
+__global__ void __launch_bounds__(256) copy_kernel(const float4 *__restrict__ src_, float4 *__restrict__ dst_, size_t n16)
+{
+    const f32x4_p *__restrict__ src = reinterpret_cast<const f32x4_p *>(src_);
+    f32x4_p *__restrict__ dst = reinterpret_cast<f32x4_p *>(dst_);
+    const size_t stride = (size_t)gridDim.x * 256 * kPer;
+    for (size_t base = (size_t)blockIdx.x * 256 * kPer + threadIdx.x; base < n16; base += stride) {
+        f32x4_p v[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k)
+            if (base + (size_t)k * 256 < n16)
+                v[k] = kNt ? __builtin_nontemporal_load(src + base + (size_t)k * 256) : src[base + (size_t)k * 256];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k)
+            if (base + (size_t)k * 256 < n16) {
+                if (kNt) __builtin_nontemporal_store(v[k], dst + base + (size_t)k * 256);
+                else dst[base + (size_t)k * 256] = v[k];
+            }
+    }
+}
+
+template <int kPer, bool kNt>
+static double time_copy(const void *src, void *dst, size_t bytes, int blocks, int reps)
+{
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a));
+    CHECK(hipEventCreate(&b));
+    copy_kernel<kPer, kNt><<<blocks, 256>>>((const float4 *)src, (float4 *)dst, bytes / 16);
+    CHECK(hipEventRecord(a));
+    for (int i = 0; i < reps; ++i) copy_kernel<kPer, kNt><<<blocks, 256>>>((const float4 *)src, (float4 *)dst, bytes / 16);
+    CHECK(hipEventRecord(b));
+    CHECK(hipEventSynchronize(b));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, a, b));
+    CHECK(hipEventDestroy(a));
+    CHECK(hipEventDestroy(b));
+    return ms / reps;
+}
+
 int main(int argc, char **argv)
 {
     const size_t max_mb = argc > 1 ? strtoull(argv[1], nullptr, 10) : 16384;
@@ -147,8 +189,34 @@ int main(int argc, char **argv)
         CHECK(hipEventSynchronize(b));
         float ms = 0;
         CHECK(hipEventElapsedTime(&ms, a, b));
-        printf("stream_copy: 4 GiB device-to-device, %.3f ms per copy, %.0f GB/s read+write\n", ms / reps,
+        printf("copy_variant hipMemcpyAsync(D2D): %.3f ms per copy, %.0f GB/s read+write\n", ms / reps,
                2.0 * bytes * reps / (ms * 1e-3) / 1e9);
+        double best = ms / reps;
+        const char *best_name = "hipMemcpyAsync";
+        // hand-written float4 copies: blocks per CU x float4 per thread and trip x plain / non-temporal
+        const int cus = prop.multiProcessorCount;
+        struct { const char *name; double ms; } v[] = {
+            {"float4 x1, 8 blocks/CU", time_copy<1, false>(src, dst, bytes, cus * 8, reps)},
+            {"float4 x1, 32 blocks/CU", time_copy<1, false>(src, dst, bytes, cus * 32, reps)},
+            {"float4 x4, 8 blocks/CU", time_copy<4, false>(src, dst, bytes, cus * 8, reps)},
+            {"float4 x4, 16 blocks/CU", time_copy<4, false>(src, dst, bytes, cus * 16, reps)},
+            {"float4 x1 nt, 8 blocks/CU", time_copy<1, true>(src, dst, bytes, cus * 8, reps)},
+            {"float4 x4 nt, 8 blocks/CU", time_copy<4, true>(src, dst, bytes, cus * 8, reps)},
+            {"float4 x4 nt, 16 blocks/CU", time_copy<4, true>(src, dst, bytes, cus * 16, reps)},
+            {"float4 x8 nt, 8 blocks/CU", time_copy<8, true>(src, dst, bytes, cus * 8, reps)},
+            {"float4 x1, one trip per thread", time_copy<1, false>(src, dst, bytes, (int)(bytes / 16 / 256), reps)},
+            {"float4 x4, one trip per thread", time_copy<4, false>(src, dst, bytes, (int)(bytes / 16 / 1024), reps)},
+            {"float4 x4 nt, one trip per thread", time_copy<4, true>(src, dst, bytes, (int)(bytes / 16 / 1024), reps)},
+        };
+        for (auto &x : v) {
+            printf("copy_variant %s: %.3f ms per copy, %.0f GB/s read+write\n", x.name, x.ms, 2.0 * bytes / (x.ms * 1e-3) / 1e9);
+            if (x.ms < best) {
+                best = x.ms;
+                best_name = x.name;
+            }
+        }
+        printf("stream_copy: 4 GiB device-to-device, %.3f ms per copy, %.0f GB/s read+write (best: %s)\n", best,
+               2.0 * bytes / (best * 1e-3) / 1e9, best_name);
         CHECK(hipFree(src));
         CHECK(hipFree(dst));
     }

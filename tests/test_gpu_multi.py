@@ -32,26 +32,29 @@ import torch.distributed as dist
 sys.path.insert(0, {root!r})
 rank, world, port, gather, p, q, outdir = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], \
     float(sys.argv[5]), float(sys.argv[6]), sys.argv[7]
+wire, chunks = sys.argv[8], int(sys.argv[9])
 from torch_random_walk_amd import graphs
 from torch_random_walk_amd.dist import walk_sharded
 torch.cuda.set_device(0)                      # one card on this box: both ranks share it
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
 rp, ci = graphs.rmat(3000, 30000, seed=4, device="cuda:0")
 tg = torch.arange(3000, device="cuda:0").repeat(7)[:20001]        # not divisible by the world size
-res = walk_sharded(rp, ci, tg, p, q, 33, 42, gather=gather)       # walk_fn=None: the HIP path
-assert res.is_cuda
+res = walk_sharded(rp, ci, tg, p, q, 33, 42, gather=gather, wire=wire, chunks=chunks)   # walk_fn=None: the HIP path
+assert res.is_cuda and res.dtype == torch.int64
 torch.save(res.cpu(), os.path.join(outdir, "r%d.pt" % rank))
 dist.barrier()
 dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("gather", ["root", "all"])
+@pytest.mark.parametrize("gather,wire,chunks", [("root", "auto", 1), ("all", "auto", 1), ("root", "int64", 1),
+                                                ("root", "uint32", 4), ("all", "int64", 1)])
 @pytest.mark.parametrize("p,q", [(1.0, 1.0), (0.25, 4.0)])
-def test_sharded_walk_two_ranks_on_the_hip_path(tmp_path, gather, p, q):
+def test_sharded_walk_two_ranks_on_the_hip_path(tmp_path, gather, wire, chunks, p, q):
     """world_size 2, both ranks on cuda:0 with the HIP kernels doing the walking (the gloo transport
     stages the blocks through the host; under RCCL the same code hands device tensors over): the assembled
-    result equals the single call and the oracle."""
+    result equals the single call and the oracle -- whether the blocks travel as int64 or in the uint32 wire
+    format (narrowed and widened by the library's kernels), in one piece or in four row chunks."""
     from torch_random_walk_amd import graphs
     from torch_rw import rw
     script = tmp_path / "worker.py"
@@ -59,7 +62,7 @@ def test_sharded_walk_two_ranks_on_the_hip_path(tmp_path, gather, p, q):
     port = _free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", str(port), gather, str(p), str(q),
-                               str(tmp_path)], env=env) for r in range(2)]
+                               str(tmp_path), wire, str(chunks)], env=env) for r in range(2)]
     codes = [pr.wait(timeout=600) for pr in procs]
     assert codes == [0, 0]
     rp, ci = graphs.rmat(3000, 30000, seed=4, device=DEV)
@@ -78,6 +81,87 @@ def test_sharded_walk_two_ranks_on_the_hip_path(tmp_path, gather, p, q):
         assert torch.equal(r1, single[10001:])
 
 
+_RCCL_SMOKE = r"""
+import os, sys, torch
+import torch.distributed as dist
+sys.path.insert(0, {root!r})
+port = int(sys.argv[1])
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)          # bench.py's init call
+x = torch.arange(1 << 20, device=dev, dtype=torch.int64)
+dist.all_reduce(x, op=dist.ReduceOp.MAX)                                      # the replica checksum's collective
+assert int(x[-1]) == (1 << 20) - 1
+dist.barrier()
+t = torch.tensor([1.5], dtype=torch.float64, device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert float(t) == 1.5
+# the gather's transport: a group of point-to-point transfers of DEVICE tensors in the int32 wire dtype (to itself:
+# the one peer a single card has)
+from torch_rw import rw
+rows = torch.randint(0, 2**32, (4096, 81), device=dev, dtype=torch.int64)
+wire = rw.narrow_rows(rows)
+land = torch.empty_like(wire)
+works = dist.batch_isend_irecv([dist.P2POp(dist.irecv, land, 0), dist.P2POp(dist.isend, wire, 0)])
+for w in works:
+    w.wait()
+assert torch.equal(rw.widen_rows(land), rows)
+got = torch.empty((1 * 4096, 81), dtype=torch.int32, device=dev)
+dist.all_gather_into_tensor(got, wire)
+assert torch.equal(got, wire)
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("rccl smoke ok")
+"""
+
+
+def test_rccl_smoke_world_1(tmp_path):
+    """librccl loads and the calls the N > 1 path makes work on this box, in a fresh child process: init_process_group
+    ("nccl", device_id=...) as bench.py does it, device all_reduce, barrier, a batch_isend_irecv group of device tensors
+    in the wire dtype, all_gather_into_tensor, destroy.  One card, so world_size 1."""
+    script = tmp_path / "rccl_smoke.py"
+    script.write_text(_RCCL_SMOKE.format(root=ROOT))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, str(script), str(_free_port())], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert "rccl smoke ok" in out.stdout
+
+
+def test_walk_sharded_world_1_rccl(tmp_path):
+    """walk_sharded itself under backend "nccl" (world_size 1: the code path of a rank that is both root and only
+    member -- init, the walk on the HIP path, destroy)."""
+    script = tmp_path / "w1.py"
+    script.write_text(r"""
+import os, sys, torch
+import torch.distributed as dist
+sys.path.insert(0, %r)
+os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", sys.argv[1]
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from torch_random_walk_amd import graphs
+from torch_random_walk_amd.dist import walk_sharded
+from torch_rw import rw
+rp, ci = graphs.rmat(3000, 30000, seed=4, device="cuda:0")
+tg = torch.arange(3000, device="cuda:0")
+for gather in ("root", "all", "none"):
+    a = walk_sharded(rp, ci, tg, 0.25, 4.0, 20, 7, gather=gather, chunks=3)
+    assert torch.equal(a, rw.walk_ex(rp, ci, tg, 0.25, 4.0, 20, 7, rng_mode=rw.RNG_WALKER))
+dist.barrier()
+dist.destroy_process_group()
+print("ok")
+""" % ROOT)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, str(script), str(_free_port())], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` from a plain shell (no torchrun around it): the parent starts the ranks
     before it has touched the GPU and relays the one JSON line; gloo here because the box has one card."""
@@ -93,6 +177,11 @@ def test_bench_launches_its_own_ranks():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0
     assert line["config"]["global_walkers"] == 2 * line["config"]["walkers_per_gpu"]
+    # the N > 1 line says what the gather cost and what travelled
+    mg = line["multi_gpu"]
+    assert mg["wire_dtype"] == "uint32" and mg["gather_chunks"] >= 1
+    assert mg["bytes_per_rank"] == line["config"]["walkers_per_gpu"] * 81 * 4
+    assert mg["gather_ms"] > 0 and mg["walk_kernel_ms"] > 0
 
 
 def test_bench_line_carries_the_contract_fields():

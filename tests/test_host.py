@@ -98,7 +98,7 @@ def _free_port():
     return port
 
 
-def _gloo_worker(rank, world, port, gather, p, q, outdir):
+def _gloo_worker(rank, world, port, gather, p, q, outdir, wire="auto", chunks=1):
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
     from torch_random_walk_amd import graphs
@@ -112,21 +112,25 @@ def _gloo_worker(rank, world, port, gather, p, q, outdir):
         return torch.from_numpy(O.walk(row_ptr.numpy(), col_idx.numpy(), targets.numpy(), p, q, walk_length, seed,
                                        rng_mode=mode, walker_base=walker_base))
 
-    res = walk_sharded(rp, ci, tg, p, q, 11, 42, gather=gather, walk_fn=oracle_walk)
+    res = walk_sharded(rp, ci, tg, p, q, 11, 42, gather=gather, walk_fn=oracle_walk, wire=wire, chunks=chunks)
+    assert res.dtype == torch.int64
     torch.save(res, os.path.join(outdir, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("gather", ["root", "all"])
+@pytest.mark.parametrize("gather,wire,chunks", [("root", "auto", 1), ("all", "auto", 1), ("root", "int64", 1),
+                                                ("root", "uint32", 3), ("all", "int64", 1), ("root", "int64", 300)])
 @pytest.mark.parametrize("p,q", [(1.0, 1.0), (0.25, 4.0)])
-def test_sharded_walk_equals_single_shot_gloo(tmp_path, gather, p, q):
-    """world_size-2 gloo run of the shard + gather logic; the per-shard compute is the oracle
-    here (no GPU in this tier) -- the same test runs on the HIP path under -m gpu."""
+def test_sharded_walk_equals_single_shot_gloo(tmp_path, gather, wire, chunks, p, q):
+    """world_size-2 gloo run of the shard + gather logic -- both wire formats (uint32 narrowed / widened by the
+    library's host legs here, int64), the gather in one piece and in row chunks (300 chunks of a 258-row block: some
+    are empty) -- the per-shard compute is the oracle here (no GPU in this tier); the same test runs on the HIP path
+    under -m gpu."""
     import torch.multiprocessing as mp
     from torch_random_walk_amd import graphs
     port = _free_port()
-    mp.spawn(_gloo_worker, args=(2, port, gather, p, q, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_gloo_worker, args=(2, port, gather, p, q, str(tmp_path), wire, chunks), nprocs=2, join=True)
     rp, ci = graphs.rmat(300, 2000, seed=4)
     tg = torch.arange(300).repeat(2)[:517]
     mode = O.RNG_GLIBC_SEQ if (p == 1.0 and q == 1.0) else O.RNG_WALKER
@@ -138,3 +142,52 @@ def test_sharded_walk_equals_single_shot_gloo(tmp_path, gather, p, q):
         assert torch.equal(r1, full)
     else:
         assert torch.equal(r1, full[259:])
+
+
+def test_wire_format_round_trip_and_bounds():
+    """uint32 wire format of the gather (include/trw.h trw_rows_narrow_cpu / _widen_cpu through the extension):
+    round trip over the whole uint32 range, any shape / alignment, overflow reported in strict mode only."""
+    from torch_rw import rw
+    from torch_random_walk_amd.dist import chunk_bounds, wire_dtype_for
+    g = torch.Generator().manual_seed(3)
+    for shape in [(0, 7), (1, 1), (5, 81), (1001,), (64, 3)]:
+        x = torch.randint(0, 2**32, shape, generator=g, dtype=torch.int64)
+        if x.numel():
+            x.view(-1)[0] = 2**32 - 1
+        w = rw.narrow_rows(x, strict=True)
+        assert w.dtype == torch.int32 and w.shape == x.shape
+        assert torch.equal(w.to(torch.int64) & 0xFFFFFFFF, x)
+        assert torch.equal(rw.widen_rows(w), x)
+    x = torch.arange(40, dtype=torch.int64)[3:]          # an unaligned window into a larger tensor
+    out = torch.empty(40, dtype=torch.int32)[1:38]
+    assert torch.equal(rw.widen_rows(rw.narrow_rows(x, out=out)), x)
+    big = torch.tensor([1, 2**32, 3])
+    assert rw.narrow_rows(big).tolist() == [1, 0, 3]      # not strict: the low words, silently
+    with pytest.raises(RuntimeError, match="does not fit"):
+        rw.narrow_rows(big, strict=True)
+    with pytest.raises(RuntimeError):
+        rw.narrow_rows(big.to(torch.int32))
+    assert wire_dtype_for(10_000_000) == "uint32" and wire_dtype_for(2**32) == "uint32"
+    assert wire_dtype_for(2**32 + 1) == "int64" and wire_dtype_for(5, "int64") == "int64"
+    with pytest.raises(ValueError):
+        wire_dtype_for(2**32 + 1, "uint32")
+    for lo, hi, chunks in [(0, 10, 3), (7, 7, 4), (5, 6, 8), (259, 517, 300), (0, 1000, 1)]:
+        cuts = [chunk_bounds(lo, hi, chunks, c) for c in range(chunks)]
+        assert cuts[0][0] == lo and cuts[-1][1] == hi
+        assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:])) and all(a <= b for a, b in cuts)
+
+
+def test_cache_eviction_rule_is_per_device():
+    """The prepared-graph cache keeps `capacity` graphs PER DEVICE: the rule, on its own.
+    Entries are most-recently-used first, [0] is the current call's; positions to drop come back in descending order."""
+    from torch_random_walk_amd import _native
+    victims = _native.ext._cache_victims
+    assert victims([], [], 2) == []
+    assert victims([0, 0], [False, False], 2) == []
+    assert victims([0, 0, 0], [False, False, False], 2) == [2]
+    assert victims([0, 1, 0, 1, 0], [False] * 5, 2) == [4]            # device 1's two graphs are not device 0's problem
+    assert victims([1, 0, 0, 0, 1, 1], [False] * 6, 2) == [5]         # the current call is on device 1
+    assert victims([0, 0, 0, 0], [False, False, True, False], 2) == [3, 1]   # pinned graphs stay ...
+    assert victims([0, 0, 0, 0], [False, True, True, True], 2) == []      # ... even beyond the capacity
+    assert victims([0, 0, 0, 0], [False] * 4, 1) == [3, 2, 1]
+    assert victims([0, 0, 0], [False] * 3, 0) == [2, 1]               # capacity < 1 behaves as 1: the call's own graph stays

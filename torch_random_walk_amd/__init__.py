@@ -9,8 +9,11 @@ reference's own surface::
 
 The compute lives in ``libtrw_hip.so`` (hand-written HIP, C ABI in
 ``include/trw.h``); ``torch_rw_native`` is the pybind host extension that
-mirrors the reference's native module.  There is no CPU walker and no fallback:
-importing this package without the built extension raises.
+mirrors the reference's native module and its dispatcher: GPU tensors run the HIP
+kernels, CPU tensors the library's own host legs (``csrc/trw_cpu.cpp``, what the
+reference's ``csrc/cpu`` computes on one thread).  Nothing falls back silently:
+importing this package without the built extension raises, and a GPU call never
+runs on the host.
 """
 from . import _native  # noqa: F401  (raises if the HIP extension is not built)
 from . import rw, utils  # noqa: F401

@@ -10,14 +10,14 @@ HIP_LIB_PATH = os.path.join(_HERE, "libtrw_hip.so")
 if not os.path.exists(HIP_LIB_PATH):
     raise ImportError(
         "torch_random_walk_amd: %s is missing. Build it with `python torch_random_walk_amd/_build.py` "
-        "(hipcc --offload-arch=gfx950). There is no CPU fallback." % HIP_LIB_PATH)
+        "(hipcc --offload-arch=gfx950). Nothing stands in for it: GPU kernels and host legs both live there." % HIP_LIB_PATH)
 
 try:
     from . import torch_rw_native as ext  # the pybind module, same name as the reference's
 except ImportError as e:  # pragma: no cover - exercised only on a broken build
     raise ImportError(
         "torch_random_walk_amd: the torch_rw_native extension failed to load (%s). Rebuild with "
-        "`python torch_random_walk_amd/_build.py --force`. There is no CPU fallback." % e) from e
+        "`python torch_random_walk_amd/_build.py --force`. Nothing stands in for it." % e) from e
 
 RNG_AUTO = int(ext.RNG_AUTO)
 RNG_GLIBC = int(ext.RNG_GLIBC)

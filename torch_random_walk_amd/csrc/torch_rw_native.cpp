@@ -184,13 +184,38 @@ bool cache_enabled()
 
 bool cacheable(const torch::Tensor &t) { return !t.is_inference() && t.has_storage(); }
 
-bool entry_matches(const PreparedGraph &e, const torch::Tensor &rp, const torch::Tensor &ci, int kind, int64_t pad)
+// Same graph MEMORY (storages alive and identical, same window into them, same kind / padding id, same device) ...
+bool entry_same_memory(const PreparedGraph &e, const torch::Tensor &rp, const torch::Tensor &ci, int kind, int64_t pad)
 {
     const auto a = e.rp_storage.lock(), b = e.ci_storage.lock();
     return e.kind == kind && e.pad == pad && a && b && a.get() == rp.storage().unsafeGetStorageImpl() && b.get() == ci.storage().unsafeGetStorageImpl() &&
            e.rp_ptr == rp.data_ptr() && e.ci_ptr == ci.data_ptr() && e.rp_numel == rp.numel() &&
-           e.ci_numel == ci.numel() && e.rp_version == rp._version() && e.ci_version == ci._version() &&
-           e.device == rp.device();
+           e.ci_numel == ci.numel() && e.device == rp.device();
+}
+
+// ... and same CONTENT as far as torch can tell (no in-place write since the entry was built).
+bool entry_matches(const PreparedGraph &e, const torch::Tensor &rp, const torch::Tensor &ci, int kind, int64_t pad)
+{
+    return entry_same_memory(e, rp, ci, kind, pad) && e.rp_version == rp._version() && e.ci_version == ci._version();
+}
+
+// The eviction rule, on its own so that it can be tested without a GPU (`_cache_victims`): the cache holds `capacity`
+// graphs PER DEVICE (a process that drives several GPUs keeps each card's working set).  Entries
+// are listed most recently used first, [0] being the current call's; among the entries of [0]'s device beyond the
+// capacity the least recently used unpinned ones go, never [0] itself.
+std::vector<int64_t> cache_victims(const std::vector<int64_t> &device_of, const std::vector<bool> &pinned, int64_t capacity)
+{
+    std::vector<int64_t> victims;
+    if (device_of.empty()) return victims;
+    const int64_t cap = capacity < 1 ? 1 : capacity, dev = device_of[0];
+    int64_t on_device = 0;
+    for (const int64_t d : device_of) on_device += d == dev ? 1 : 0;
+    for (int64_t i = (int64_t)device_of.size() - 1; i >= 1 && on_device > cap; --i) {
+        if (device_of[i] != dev || pinned[i]) continue;
+        victims.push_back(i);
+        --on_device;
+    }
+    return victims;
 }
 
 // (Re)builds the prepared blob of `entry` with `what`; falls back to leaner layouts when the device is short of
@@ -259,6 +284,10 @@ PreparedUse prepared_for(const torch::Tensor &rp, const torch::Tensor &ci, int32
             it = g_cache.erase(it);
         } else if ((*it)->rp_storage.expired() || (*it)->ci_storage.expired()) {
             it = g_cache.erase(it);  // its graph is gone
+        } else if (entry_same_memory(**it, rp, ci, kind, pad)) {
+            // the same tensors, written in place since: this entry can never match again -- it goes now,
+            // pinned or not, so that its blob is free before the successor's is allocated
+            it = g_cache.erase(it);
         } else {
             ++it;
         }
@@ -306,12 +335,15 @@ PreparedUse prepared_for(const torch::Tensor &rp, const torch::Tensor &ci, int32
     if (biased_walk) ++hit->biased_walks;
     hit->pinned = hit->pinned || pin;
     g_cache.push_front(hit);
-    const int64_t cap = g_cache_capacity.load();
-    while ((int64_t)g_cache.size() > (cap < 1 ? 1 : cap)) {
-        auto victim = std::prev(g_cache.end());
-        while (victim != g_cache.begin() && (*victim)->pinned) --victim;
-        if (victim == g_cache.begin()) break;  // only pinned graphs (and this call's) left
-        g_cache.erase(victim);
+    {
+        std::vector<int64_t> device_of;
+        std::vector<bool> pinned;
+        for (const auto &e : g_cache) {
+            device_of.push_back((int64_t)e->device.index());
+            pinned.push_back(e->pinned);
+        }
+        const auto victims = cache_victims(device_of, pinned, g_cache_capacity.load());  // (descending positions)
+        for (const int64_t v : victims) g_cache.erase(std::next(g_cache.begin(), v));
     }
     if (hit->built_on != stream) {  // built on another stream: order after it, keep the blob alive for this one
         const int rc = trw_event_wait(hit->ready, stream);
@@ -426,6 +458,63 @@ torch::Tensor walk_ex(const torch::Tensor &row_ptr, const torch::Tensor &col_idx
     TORCH_CHECK(rc == TRW_OK, "torch_rw walk failed (", rc, "): ", trw_last_error());
     finish_status(workspace, hs, check_mode, "walk");
     return walks;
+}
+
+// ---- wire format of the multi-GPU gather (include/trw.h: trw_rows_narrow / trw_rows_widen) ---------------
+// rows: contiguous int64, any shape; wire: int32 of the same shape holding the uint32 bit patterns (torch's
+// collectives know int32).  `strict`: synchronise and raise when a value did not fit (node ids >= 2^32).
+torch::Tensor narrow_rows(const torch::Tensor &rows, const c10::optional<torch::Tensor> &out, bool strict)
+{
+    TORCH_CHECK(rows.scalar_type() == torch::kInt64 && rows.is_contiguous(), "rows must be a contiguous int64 tensor");
+    torch::Tensor wire;
+    if (out.has_value() && out->defined()) {
+        wire = *out;
+        TORCH_CHECK(wire.scalar_type() == torch::kInt32 && wire.is_contiguous() && wire.device() == rows.device() &&
+                        wire.numel() == rows.numel(), "out must be a contiguous int32 tensor of rows' size and device");
+    } else {
+        wire = torch::empty(rows.sizes(), rows.options().dtype(torch::kInt32));
+    }
+    int rc;
+    if (!rows.is_cuda()) {
+        int64_t overflow = 0;
+        rc = trw_rows_narrow_cpu(rows.data_ptr<int64_t>(), rows.numel(), (uint32_t *)wire.data_ptr<int32_t>(), &overflow);
+        TORCH_CHECK(rc == TRW_OK, "torch_rw narrow_rows failed (", rc, "): ", trw_last_error());
+        TORCH_CHECK(!strict || overflow == 0, "narrow_rows: a value does not fit the uint32 wire format");
+        return wire;
+    }
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(rows.device());
+    const auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(rows.device().index());
+    torch::Tensor flag;
+    if (strict) flag = torch::zeros({1}, rows.options());
+    rc = trw_rows_narrow_hip(rows.data_ptr<int64_t>(), rows.numel(), (uint32_t *)wire.data_ptr<int32_t>(),
+                             strict ? flag.data_ptr<int64_t>() : nullptr, (void *)stream.stream());
+    TORCH_CHECK(rc == TRW_OK, "torch_rw narrow_rows failed (", rc, "): ", trw_last_error());
+    if (strict) TORCH_CHECK(flag.item<int64_t>() == 0, "narrow_rows: a value does not fit the uint32 wire format");
+    return wire;
+}
+
+torch::Tensor widen_rows(const torch::Tensor &wire, const c10::optional<torch::Tensor> &out)
+{
+    TORCH_CHECK(wire.scalar_type() == torch::kInt32 && wire.is_contiguous(), "wire must be a contiguous int32 tensor");
+    torch::Tensor rows;
+    if (out.has_value() && out->defined()) {
+        rows = *out;
+        TORCH_CHECK(rows.scalar_type() == torch::kInt64 && rows.is_contiguous() && rows.device() == wire.device() &&
+                        rows.numel() == wire.numel(), "out must be a contiguous int64 tensor of wire's size and device");
+    } else {
+        rows = torch::empty(wire.sizes(), wire.options().dtype(torch::kInt64));
+    }
+    int rc;
+    if (!wire.is_cuda()) {
+        rc = trw_rows_widen_cpu((const uint32_t *)wire.data_ptr<int32_t>(), wire.numel(), rows.data_ptr<int64_t>());
+    } else {
+        const c10::hip::HIPGuardMasqueradingAsCUDA guard(wire.device());
+        const auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(wire.device().index());
+        rc = trw_rows_widen_hip((const uint32_t *)wire.data_ptr<int32_t>(), wire.numel(), rows.data_ptr<int64_t>(),
+                                (void *)stream.stream());
+    }
+    TORCH_CHECK(rc == TRW_OK, "torch_rw widen_rows failed (", rc, "): ", trw_last_error());
+    return rows;
 }
 
 // rw.prepare(): build (or upgrade) the cached prepared graph now; returns the TRW_PREP_* bits it holds.
@@ -827,6 +916,13 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
             g_cache.clear();
         }
     }, pybind11::arg("on"), pybind11::arg("capacity") = (int64_t)0);
+    m.def("narrow_rows", &narrow_rows, "int64 rows -> the uint32 wire format of the multi-GPU gather (as int32)",
+          pybind11::arg("rows"), pybind11::arg("out") = c10::optional<torch::Tensor>(), pybind11::arg("strict") = false);
+    m.def("widen_rows", &widen_rows, "uint32 wire format (as int32) -> int64 rows", pybind11::arg("wire"),
+          pybind11::arg("out") = c10::optional<torch::Tensor>());
+    m.def("_cache_victims", &cache_victims,
+          "the prepared-graph cache's eviction rule (positions to drop; capacity counts per device)",
+          pybind11::arg("device_of"), pybind11::arg("pinned"), pybind11::arg("capacity"));
     m.def("clear_cache", []() {
         std::lock_guard<std::mutex> lock(g_cache_mu);
         g_cache.clear();

@@ -601,3 +601,28 @@ extern "C" int trw_to_windows_triples_cpu(const int64_t *walks, int64_t num_walk
     }
     return TRW_OK;
 }
+
+// ---- wire format of the multi-GPU gather, host legs (CPU tensors through dist.walk_sharded) ------------------
+extern "C" int trw_rows_narrow_cpu(const int64_t *rows, int64_t count, uint32_t *wire, int64_t *overflow)
+{
+    using namespace trw_cpu;
+    set_last_error("");
+    if (count < 0 || (count > 0 && (!rows || !wire))) return fail(TRW_E_ARG, "null pointer or negative count");
+    uint64_t high = 0;
+    for (int64_t i = 0; i < count; ++i) {
+        const uint64_t v = (uint64_t)rows[i];
+        high |= v >> 32;
+        wire[i] = (uint32_t)v;
+    }
+    if (overflow && high) *overflow |= 1;
+    return TRW_OK;
+}
+
+extern "C" int trw_rows_widen_cpu(const uint32_t *wire, int64_t count, int64_t *rows)
+{
+    using namespace trw_cpu;
+    set_last_error("");
+    if (count < 0 || (count > 0 && (!rows || !wire))) return fail(TRW_E_ARG, "null pointer or negative count");
+    for (int64_t i = 0; i < count; ++i) rows[i] = (int64_t)wire[i];
+    return TRW_OK;
+}

@@ -32,6 +32,7 @@
 #include "trw_kernels_triples.hpp"
 #include "trw_kernels_edgelist.hpp"
 #include "trw_kernels_windows.hpp"
+#include "trw_kernels_wire.hpp"
 
 namespace {
 
@@ -1413,6 +1414,7 @@ namespace {
 struct StatusSlot {
     int64_t *host = nullptr;  // pinned, 16 words
     hipEvent_t ev = nullptr;
+    int device = -1;          // the device `ev` was created on: an event is only ever recorded on a stream of its own device
     bool busy = false;
 };
 constexpr int kStatusSlots = 64;
@@ -1476,29 +1478,54 @@ int trw_status_post(const void *workspace, void *hip_stream)
     hipStream_t stream = (hipStream_t)hip_stream;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return TRW_OK;
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);  // (the caller's device guard made the stream's device current)
+    if (e != hipSuccess) return fail_hip(e, "hipGetDevice");
     std::lock_guard<std::mutex> lock(g_status_mu);
+    // A slot is reused on the device that made its event only: free slots of this device first, then
+    // one that has no event yet, then -- every slot taken by other devices -- a free foreign one, re-made here.
     StatusSlot *slot = nullptr;
     for (int round = 0; round < 2 && !slot; ++round) {
-        for (auto &sl : g_status_slots)
-            if (!sl.busy) {
+        StatusSlot *fresh = nullptr, *foreign = nullptr;
+        for (auto &sl : g_status_slots) {
+            if (sl.busy) continue;
+            if (sl.device == device) {
                 slot = &sl;
                 break;
             }
+            if (sl.device < 0) {
+                if (!fresh) fresh = &sl;
+            } else if (!foreign) {
+                foreign = &sl;
+            }
+        }
+        if (!slot) slot = fresh ? fresh : foreign;
         if (!slot) status_sweep(true, &g_status_carry);  // every slot in flight: finish them, keep their bits
     }
     if (!slot) return fail(TRW_E_HIP, "no status slot free");
-    hipError_t e = hipSuccess;
+    if (slot->device != device && slot->ev) {
+        (void)hipEventDestroy(slot->ev);
+        slot->ev = nullptr;
+    }
     if (!slot->host) {
-        e = hipHostMalloc((void **)&slot->host, 16 * sizeof(int64_t), hipHostMallocDefault);
+        e = hipHostMalloc((void **)&slot->host, 16 * sizeof(int64_t), hipHostMallocPortable);
         if (e != hipSuccess) return fail_hip(e, "hipHostMalloc(status slot)");
+    }
+    if (!slot->ev) {
+        slot->device = -1;
         e = hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming);
         if (e != hipSuccess) return fail_hip(e, "hipEventCreate(status slot)");
+        slot->device = device;
     }
     slot->host[0] = 0;
     e = hipMemcpyAsync(slot->host, workspace, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, stream);
     if (e != hipSuccess) return fail_hip(e, "hipMemcpyAsync(status)");
     e = hipEventRecord(slot->ev, stream);
-    if (e != hipSuccess) return fail_hip(e, "hipEventRecord(status)");
+    if (e != hipSuccess) {
+        // the copy is in flight into a slot nobody will wait for: let it land before the slot can be handed out again
+        (void)hipStreamSynchronize(stream);
+        return fail_hip(e, "hipEventRecord(status)");
+    }
     slot->busy = true;
     return TRW_OK;
 }
@@ -1511,6 +1538,39 @@ int trw_status_collect(int wait, int64_t *bits)
     *bits = g_status_carry;
     g_status_carry = 0;
     return status_sweep(wait != 0, bits);
+}
+
+// ---- wire format of the multi-GPU gather (trw_kernels_wire.hpp) -----------------------------------------
+int trw_rows_narrow_hip(const int64_t *rows, int64_t count, uint32_t *wire, int64_t *overflow, void *hip_stream)
+{
+    t_last_error.clear();
+    if (count < 0 || (count > 0 && (!rows || !wire))) return fail(TRW_E_ARG, "null pointer or negative count");
+    if (count == 0) return TRW_OK;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const bool aligned = (((uintptr_t)rows | (uintptr_t)wire) & 15u) == 0;
+    const unsigned grid = stream_grid(aligned ? (count + 3) / 4 : count);
+    if (aligned)
+        rows_narrow_kernel<<<grid, 256, 0, stream>>>(rows, count, wire, (unsigned long long *)overflow);
+    else
+        rows_narrow_scalar_kernel<<<grid, 256, 0, stream>>>(rows, count, wire, (unsigned long long *)overflow);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? TRW_OK : fail_hip(e, "rows_narrow_kernel");
+}
+
+int trw_rows_widen_hip(const uint32_t *wire, int64_t count, int64_t *rows, void *hip_stream)
+{
+    t_last_error.clear();
+    if (count < 0 || (count > 0 && (!rows || !wire))) return fail(TRW_E_ARG, "null pointer or negative count");
+    if (count == 0) return TRW_OK;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const bool aligned = (((uintptr_t)rows | (uintptr_t)wire) & 15u) == 0;
+    const unsigned grid = stream_grid(aligned ? (count + 3) / 4 : count);
+    if (aligned)
+        rows_widen_kernel<<<grid, 256, 0, stream>>>(wire, count, rows);
+    else
+        rows_widen_scalar_kernel<<<grid, 256, 0, stream>>>(wire, count, rows);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? TRW_OK : fail_hip(e, "rows_widen_kernel");
 }
 
 int trw_walk_counters(const void *workspace, void *hip_stream, uint64_t counters_out[4])

@@ -21,6 +21,26 @@ def shard_bounds(n, world_size, rank):
     return lo, hi, block
 
 
+def chunk_bounds(lo, hi, chunks, c):
+    """Row sub-block c of the block [lo, hi) cut into `chunks` pieces of ceil((hi-lo)/chunks) rows (the last ones
+    may be short or empty).  Sender and root derive the same cuts from the shard bounds alone."""
+    size = (hi - lo + chunks - 1) // chunks if chunks > 0 else hi - lo
+    c_lo = min(hi, lo + c * size)
+    return c_lo, min(hi, c_lo + size)
+
+
+def wire_dtype_for(n_nodes, wire="auto"):
+    """What a row block travels as: "uint32" (half the bytes per xGMI link; node ids are < n_nodes) while
+    n_nodes <= 2^32, "int64" otherwise or on request."""
+    if wire == "auto":
+        return "uint32" if n_nodes <= (1 << 32) else "int64"
+    if wire == "uint32" and n_nodes > (1 << 32):
+        raise ValueError("node ids of a graph with more than 2^32 nodes do not fit the uint32 wire format")
+    if wire not in ("uint32", "int64"):
+        raise ValueError("wire must be 'auto', 'uint32' or 'int64'")
+    return wire
+
+
 def _host_staged(group, tensor):
     """gloo moves host memory only (its send/recv and all_gather refuse device tensors): device blocks
     are staged through the host then.  RCCL (backend "nccl") takes the device tensors as they are."""
@@ -28,7 +48,7 @@ def _host_staged(group, tensor):
 
 
 def walk_sharded(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, group=None, gather="root",
-                 rng_mode=None, walk_fn=None):
+                 rng_mode=None, walk_fn=None, wire="auto", chunks=1):
     """Walk ``target_nodes`` (the full batch, same on every rank) across the ranks of ``group``.
 
     gather: "root"  -> rank 0 returns the full ``[N, L+1]`` tensor, other ranks return their block
@@ -40,6 +60,12 @@ def walk_sharded(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, group=
               biased batch (N <= 32768/(L+1)): AUTO replays the reference's one serial glibc chain there,
               and a serial chain cannot be sharded -- asking for RNG_GLIBC on a biased walk with more
               than one rank raises.
+    wire:   "auto" | "uint32" | "int64" -- what the blocks travel as (``wire_dtype_for``): uint32 halves the bytes
+            on every link; the blocks are narrowed by a kernel of the library before they leave and widened into
+            the int64 result where they land.  The result is the same tensor either way.
+    chunks: gather="root": a rank walks its block in this many row sub-blocks and posts each one's transfer as
+            soon as its walk is enqueued, so the gather overlaps the rest of the same call's walk instead of
+            starting when the whole block is done.
     walk_fn: override of ``rw.walk_ex`` (the CPU tests plug the oracle in here).
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -52,50 +78,101 @@ def walk_sharded(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, group=
     if world > 1 and rng_mode == rw.RNG_GLIBC and not uniform:
         raise ValueError("RNG_GLIBC biased walks replay one serial stream (walker i's draws depend on every "
                          "earlier walker's): they cannot be sharded; use RNG_WALKER")
-    fn = walk_fn or rw.walk_ex
+    if gather not in ("root", "all", "none"):
+        raise ValueError("gather must be 'root', 'all' or 'none'")
+    narrow = wire_dtype_for(int(row_ptr.numel()) - 1, wire) == "uint32"
+    chunks = max(1, int(chunks)) if (world > 1 and gather == "root") else 1
     cols = walk_length + 1
-    full = None
+    dev = target_nodes.device
     staged = world > 1 and _host_staged(group, target_nodes)
-    if world > 1 and gather == "root" and rank == 0 and walk_fn is None and not staged:
+
+    def walk_into(dst, c_lo, c_hi):
+        """rows [c_lo, c_hi) of the batch, walked into `dst` (a [c_hi-c_lo, cols] slice of a result tensor)"""
+        if walk_fn is None:
+            rw.walk_ex(row_ptr, col_idx, target_nodes[c_lo:c_hi], p, q, walk_length, seed, walker_base=c_lo,
+                       rng_mode=rng_mode, out=dst)
+        else:
+            dst.copy_(walk_fn(row_ptr, col_idx, target_nodes[c_lo:c_hi], p, q, walk_length, seed, walker_base=c_lo,
+                              rng_mode=rng_mode))
+
+    def to_wire(rows):
+        """what travels for a block of rows: the rows themselves, or their uint32 form; on the host under gloo"""
+        w = rw.narrow_rows(rows) if narrow else rows
+        return w.cpu() if staged else w
+
+    root_gather = world > 1 and gather == "root"
+    if root_gather and rank == 0:
         # the root walks straight into its slice of the result: no copy of its own block
-        full = torch.empty((world * block, cols), dtype=torch.int64, device=target_nodes.device)
-        mine = fn(row_ptr, col_idx, target_nodes[lo:hi], p, q, walk_length, seed, walker_base=lo, rng_mode=rng_mode,
-                  out=full[lo:hi])
+        full = torch.empty((world * block, cols), dtype=torch.int64, device=dev)
+        mine = full[lo:hi]
     else:
-        mine = fn(row_ptr, col_idx, target_nodes[lo:hi], p, q, walk_length, seed, walker_base=lo, rng_mode=rng_mode)
-    if world == 1 or gather == "none":
+        full = None
+        mine = torch.empty((hi - lo, cols), dtype=torch.int64, device=dev)
+
+    if not root_gather:
+        walk_into(mine, lo, hi)
+        if world == 1 or gather == "none":
+            return mine
+        # gather == "all": equal-sized pieces for the collective; the pad rows are dropped below
+        w = to_wire(mine)
+        if hi - lo < block:
+            padded = torch.zeros((block, cols), dtype=w.dtype, device=w.device)
+            padded[: hi - lo] = w
+            w = padded
+        got = torch.empty((world * block, cols), dtype=w.dtype, device=w.device)
+        dist.all_gather_into_tensor(got, w.contiguous(), group=group)
+        got = got[:n]
+        if staged:
+            got = got.to(dev)
+        return rw.widen_rows(got.contiguous()) if narrow else got
+
+    # gather == "root": a gather on xGMI is world-1 independent peer -> root transfers; issued as groups of
+    # point-to-point operations they land directly in the root's buffers, chunk by chunk
+    if rank != 0:
+        dst = 0 if group is None else dist.get_global_rank(group, 0)
+        works, keep = [], []
+        for c in range(chunks):
+            c_lo, c_hi = chunk_bounds(lo, hi, chunks, c)
+            if c_hi <= c_lo:
+                continue
+            walk_into(mine[c_lo - lo:c_hi - lo], c_lo, c_hi)
+            w = to_wire(mine[c_lo - lo:c_hi - lo]).contiguous()
+            keep.append(w)   # (alive until the transfer is done)
+            works += dist.batch_isend_irecv([dist.P2POp(dist.isend, w, dst, group)])
+        for w in works:
+            w.wait()
         return mine
-    wire = mine.cpu() if staged else mine            # what travels
-    padded = wire
-    if hi - lo < block:  # equal-sized pieces for the collective; the pad rows are dropped below
-        padded = torch.zeros((block, cols), dtype=wire.dtype, device=wire.device)
-        padded[: hi - lo] = wire
-    if gather == "all":
-        got = torch.empty((world * block, cols), dtype=wire.dtype, device=wire.device)
-        dist.all_gather_into_tensor(got, padded.contiguous(), group=group)
-        return got[:n].to(mine.device) if staged else got[:n]
-    if gather == "root":
-        # a gather on xGMI is world-1 independent peer -> root transfers; issued as one group of
-        # point-to-point operations they land directly in the root's result, no staging copy
-        if rank == 0:
-            if full is None:
-                full = torch.empty((world * block, cols), dtype=mine.dtype, device=mine.device)
-                full[: hi - lo] = mine
-            land = torch.empty((world * block, cols), dtype=wire.dtype) if staged else full
-            ops = []
-            for r in range(1, world):
-                r_lo, r_hi, _ = shard_bounds(n, world, r)
-                if r_hi > r_lo:
-                    src = r if group is None else dist.get_global_rank(group, r)
-                    ops.append(dist.P2POp(dist.irecv, land[r_lo:r_hi], src, group))
-            for w in (dist.batch_isend_irecv(ops) if ops else []):
-                w.wait()
-            if staged:
-                full[hi - lo:n] = land[hi - lo:n].to(full.device)
-            return full[:n]
-        if hi > lo:
-            dst = 0 if group is None else dist.get_global_rank(group, 0)
-            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, wire.contiguous(), dst, group)]):
-                w.wait()
-        return mine
-    raise ValueError("gather must be 'root', 'all' or 'none'")
+
+    wire_dtype = torch.int32 if narrow else torch.int64
+    land = None
+    if narrow or staged:   # where the peers' blocks arrive before they are widened / copied into `full`
+        land = torch.empty((world * block, cols), dtype=wire_dtype, device="cpu" if staged else dev)
+    pending = []
+    for c in range(chunks):
+        ops, pieces = [], []
+        for r in range(1, world):
+            r_lo, r_hi, _ = shard_bounds(n, world, r)
+            c_lo, c_hi = chunk_bounds(r_lo, r_hi, chunks, c)
+            if c_hi <= c_lo:
+                continue
+            src = r if group is None else dist.get_global_rank(group, r)
+            ops.append(dist.P2POp(dist.irecv, (land if land is not None else full)[c_lo:c_hi], src, group))
+            pieces.append((c_lo, c_hi))
+        # receives first, then this chunk of the root's own walk: the peers' chunk c travels while the root walks
+        works = dist.batch_isend_irecv(ops) if ops else []
+        c_lo, c_hi = chunk_bounds(lo, hi, chunks, c)
+        if c_hi > c_lo:
+            walk_into(full[c_lo:c_hi], c_lo, c_hi)
+        pending.append((works, pieces))
+    for works, pieces in pending:
+        for w in works:
+            w.wait()
+        if land is None:
+            continue
+        for c_lo, c_hi in pieces:
+            got = land[c_lo:c_hi].to(dev) if staged else land[c_lo:c_hi]
+            if narrow:
+                rw.widen_rows(got, out=full[c_lo:c_hi])
+            else:
+                full[c_lo:c_hi].copy_(got)
+    return full[:n]

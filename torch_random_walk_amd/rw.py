@@ -14,6 +14,12 @@ def walk(row_ptr, col_idx, target_nodes, p, q, walk_length, seed):
     int64 CSR tensors in, ``[len(target_nodes), walk_length+1]`` int64 out on the
     inputs' device, column 0 = start node; ``p == 1.0 and q == 1.0`` selects the
     uniform walk, anything else the node2vec rejection sampler.
+
+    Random streams (``RNG_AUTO``): uniform walks always reproduce ``csrc/cpu``'s libc stream.  A
+    node2vec batch of at most ``32768 // (walk_length + 1)`` walkers (404 at L=80: the reference's ``parallel_for``
+    grain, below which its output is defined) replays that ONE serial stream too; a larger batch runs the
+    per-walker Philox stream -- so the same ``(seed, node)`` walks differently in a 404- and in a 405-walker call.
+    ``walk_ex(rng_mode=RNG_WALKER)`` (or ``set_rng_mode``) makes small batches use the per-walker stream as well.
     """
     return torch_rw_native.walk(row_ptr, col_idx, target_nodes, p, q, walk_length, seed)
 
@@ -47,6 +53,18 @@ def walk_ex(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, walker_base
     """
     return torch_rw_native.walk_ex(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, walker_base,
                                    rng_mode, _check_code(check), out)
+
+
+def narrow_rows(rows, out=None, strict=False):
+    """The uint32 wire format of a block of int64 rows (multi-GPU gather, include/trw.h ``trw_rows_narrow_*``):
+    an int32 tensor of the same shape holding the low 32 bits.  ``strict`` synchronises and raises when a value
+    did not fit.  GPU tensors run the HIP kernel, CPU tensors the library's host leg."""
+    return torch_rw_native.narrow_rows(rows, out, strict)
+
+
+def widen_rows(wire, out=None):
+    """Inverse of ``narrow_rows``: zero-extends the uint32 values of an int32 tensor into int64 rows."""
+    return torch_rw_native.widen_rows(wire, out)
 
 
 PREP_UNIFORM, PREP_BIASED, PREP_MARKS, PREP_MARKS_FULL = (
