@@ -1658,6 +1658,9 @@ constexpr int kPoolWaves = kBlock / 64;
 #ifndef TRW_POOL_PRIO
 #define TRW_POOL_PRIO 1
 #endif
+#ifndef TRW_POOL_UNROLL
+#define TRW_POOL_UNROLL 0
+#endif
 #ifndef TRW_POOL_ISSUE_MIN
 #define TRW_POOL_ISSUE_MIN 48
 #endif
@@ -1666,21 +1669,9 @@ constexpr int kPoolWaves = kBlock / 64;
 #endif
 constexpr uint32_t kPoolIssueMin = TRW_POOL_ISSUE_MIN, kPoolTrialMin = TRW_POOL_TRIAL_MIN;
 enum : uint32_t { PK_ROW = 0, PK_ENTRY = 1, PK_TEST = 2, PK_MEMBER = 3, PK_POS = 4 };  // what a slot's gather is for
-// 19 words per walker: with 128 walkers per wave that is 9.9 KB of LDS, 39.5 KB per workgroup, FOUR workgroups per CU
-// (160 KB) -- 22 words fitted three, and both the waves per SIMD and the walkers per wave pay (measured).
-enum : int {
-    PF_T = 0, PF_PREV, PF_START, PF_DEG, PF_Z,
-    PF_RPOS,    // where t sits in prev's row, packed as in the entry: multiplicity << 28 | first offset (0: nowhere)
-    PF_M0, PF_M1, PF_M2, PF_M3,  // (kPfWide: M2 / M3 = first offset / multiplicity instead, the mask reads as all ones)
-    PF_FLAGS,   // bits 0..3 kPf*, bits 4..6 PK_* of the queued / in-flight gather, bits 8..28 rejections at this step,
-                // bits 29..31 how far the probe chain of the current table lookup has gone
-    PF_S, PF_WALKER, PF_W1, PF_W2, PF_W3, PF_BLK,
-    PF_X,       // the candidate node a table probe asks about
-    PF_AT,      // fat entry index to gather
-    PF_COUNT
-};
-// kPfFirst: the slot's next draw is the walk's first step; kPfWide: t's run in prev's row does not fit PF_RPOS
-constexpr uint32_t kPfExact = 1u, kPfOdd = 2u, kPfFirst = 4u, kPfWide = 8u;
+// kPfExact: the slot's mask bits are exact answers (a filter otherwise); kPfOdd: the stream stands at word 3 of the
+// current block; kPfWide: t's run in prev's row does not fit PF_RPOS
+constexpr uint32_t kPfExact = 1u, kPfOdd = 2u, kPfWide = 8u;
 constexpr uint32_t kPfSkip = 128u;  // table lookup, first pair: the chain starts at the pair's SECOND slot
 constexpr uint32_t kPfKind = 7u << 4, kPfRejShift = 8, kPfRejMask = 0x1FFFFFu << 8, kPfProbeShift = 29, kPfProbe = 7u << 29;
 static_assert(kTrialCap <= (kPfRejMask >> kPfRejShift), "the rejection count must fit its field");
@@ -1715,20 +1706,47 @@ __device__ __forceinline__ void pool_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// The burst (round 3).  The round-2 form of this kernel was bound by the NUMBER of vector instructions
+// (profiles/r02: SQ_INSTS_VALU x ~4.3 cycles, scripts/alu_probe*.hip, = all of its SIMD time), 80 % of them the
+// burst's trial pairs: 144 per Philox block, 58 for the block and 86 for two trials and their bookkeeping.  Now 116:
+//   * a pair of trials is straight-line code over four draws x0..x3 picked by the stream's parity once (the
+//     second trial is evaluated for every lane; it simply does not count when the first one finished the step) --
+//     no exec-mask regions, no moves under them;
+//   * the verdict is arithmetic on two per-slot thresholds: with bit = "offset idx may hold a neighbour of t",
+//         thrA = in_run ? t0 : (bit ? A : t2)      accept            iff  ru <  thrA
+//         thrR = in_run ? t0 : (bit ? R : t2)      look at candidate iff  thrA <= ru < thrR
+//     A = R = t1 for an exact mask, (A, R) = (lo, hi) for a filter: one v_bfe_i32 turns the mask bit into a lane
+//     mask, one v_bfi per threshold, one select for the run of t;
+//   * the 128-bit mask of a slot is 16 contiguous bytes, the word is read at base + ((idx >> 3) & 12); a slot whose
+//     run of t does not fit RPOS ("wide") points its base at sixteen 0xFF bytes instead of testing a flag per trial;
+//   * the first step's draw is worked out where new walkers are taken on, a full pass of lanes at a time (it was a
+//     special case inside every trial), and goes straight to the issue queue when the start row arrives;
+//   * rejections are counted per pair, the runaway cap is looked at once per pair;
+//   * the Philox key schedule lives in vector registers (philox4x32_10_keyed).
+// 19 words per walker (15 + the 4 mask words): with 128 walkers per wave that is 9.9 KB of LDS, 39.6 KB per workgroup,
+// FOUR workgroups per CU (160 KB) -- 22 words fitted three, and both the waves per SIMD and the walkers per wave pay.
+enum : int {
+    PF_T = 0, PF_PREV, PF_START, PF_DEG, PF_Z,
+    PF_RPOS,    // where t sits in prev's row, packed as in the entry: multiplicity << 28 | first offset (0: nowhere)
+    PF_FLAGS,   // bits 0..3 kPf*, bits 4..6 PK_* of the queued / in-flight gather, bits 8..28 rejections at this step,
+                // bits 29..31 how far the probe chain of the current table lookup has gone
+    PF_S, PF_WALKER,
+    PF_W1, PF_W2, PF_W3, PF_BLK,  // words 1..3 of the walker's current Philox block, and its number
+    PF_X,       // the candidate node a table probe asks about (before the start row has arrived: the first step's draw)
+    PF_AT,      // fat entry index to gather
+    PF_COUNT
+};
+
 template <bool kCount>
 __global__ void __launch_bounds__(kBlock)
 biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restrict__ ext,
-                   const uint32_t *__restrict__ table, uint64_t mask, const int64_t *__restrict__ targets,
-                   int64_t n_nodes, int64_t n_walkers, int64_t walker_base, int32_t L, uint32_t seed, BiasedParams bp,
-                   int64_t *__restrict__ out, int64_t *__restrict__ status)
+                    const uint32_t *__restrict__ table, uint64_t mask, const int64_t *__restrict__ targets,
+                    int64_t n_nodes, int64_t n_walkers, int64_t walker_base, int32_t L, uint32_t seed, BiasedParams bp,
+                    int64_t *__restrict__ out, int64_t *__restrict__ status)
 {
-    static_assert(kPoolSlots >= 64 && kPoolSlots <= kQueueCap && (kQueueCap & (kQueueCap - 1)) == 0 && kQueueCap <= 256,
-                  "pool size must be 64..256 slots (slot numbers travel as bytes)");
     if (status[kStDescents] != status[kStBoundary]) return;  // unsorted rows: biased_hash_kernel's job
     __shared__ uint32_t pool_mem[kPoolWaves][PF_COUNT][kPoolSlots];
-    // (Tried: a second issue queue, entries / table probes apart, so that an adopt pass runs one kind's code with all of
-    // its lanes: 53.2 vs 46.4 ms -- 128 walkers per wave are too few to keep three queues filled, adopt passes went
-    // from 54 to 41 lanes, bursts from 59 to 49.)
+    __shared__ u32x4_a16 mask_mem[kPoolWaves][kPoolSlots + 1];  // [kPoolSlots]: all ones, the mask of a "wide" slot
     __shared__ uint8_t queue_mem[kPoolWaves][3][kQueueCap];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         status[2] = TRW_RNG_WALKER;
@@ -1737,21 +1755,30 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t(*P)[kPoolSlots] = pool_mem[wv];
+    u32x4_a16 *M = mask_mem[wv];
     PoolQueue trial_q = {queue_mem[wv][0], 0u, 0u}, issue_q = {queue_mem[wv][1], 0u, 0u}, free_q = {queue_mem[wv][2], 0u, 0u};
     for (int i = lane; i < kPoolSlots; i += 64) free_q.q[i] = (uint8_t)i;
     free_q.count = kPoolSlots;
+    if (lane == 0) M[kPoolSlots] = u32x4_a16{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     pool_fence();
     const bool band_takes_near = bp.t1 > bp.t2;
-    const uint32_t v_clear = band_takes_near ? 0u : 1u, v_set_exact = band_takes_near ? 1u : 0u;
     const int32_t cols = L + 1;
+    // the Philox key schedule and the threshold of a return to t, in vector registers (see philox4x32_10_keyed)
+    uint32_t key_r[10];
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        key_r[r] = seed + (uint32_t)r * 0x9E3779B9u;
+        asm volatile("" : "+v"(key_r[r]));
+    }
+    uint32_t t0_v = bp.t0;
+    asm volatile("" : "+v"(t0_v));
 
     uint32_t st = 0;
     uint32_t n_trials = 0, n_fetch = 0, n_tests = 0, n_probes = 0;
-    bool hold = false;         // this lane issued a gather for slot `hs` in the previous iteration
+    bool hold = false;
     uint32_t hs = 0, hkind = 0;
     u32x4_a4 e0 = {0u, 0u, 0u, 0u}, e1 = {0u, 0u, 0u, 0u};
-    bool more_walkers = true;  // wave-uniform: the device counter has not run out yet
-    // counting variant only: passes / lanes / shader-clock cycles per phase of this wave (status[12..23])
+    bool more_walkers = true;
     uint64_t w_iters = 0, w_pass[3] = {0, 0, 0}, w_lanes[3] = {0, 0, 0}, w_cycles[4] = {0, 0, 0, 0}, w_trial_passes = 0;
     uint64_t t_mark = kCount ? clock64() : 0;
     auto lap = [&](int phase) {
@@ -1761,12 +1788,6 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
             t_mark = now;
         }
     };
-
-    // Columns go out one 8-byte store each: this kernel runs out of instruction issue, not of write requests, and
-    // a plain store is an address and one instruction where combining four columns cost 25 and four words of state.
-    // (Without any column store the kernel takes 43.9 ms instead of 46.6; columns (s-1, s) as one 16-byte store every
-    // second step -- the slot holds the last two nodes anyway -- measured 46.4 against 46.0: rows of 81 columns are
-    // 8-byte aligned and the wider store is split again.)
     auto row_of = [&](uint32_t slot) { return out + (int64_t)P[PF_WALKER][slot] * cols; };
 
     while (true) {
@@ -1794,19 +1815,13 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                         int64_t *r = row_of(slot);
                         for (int32_t s = 1; s <= L; ++s) r[s] = (int64_t)prev;
                         to_free = true;
-                    } else {  // first step: plain uniform neighbour, draw 0 (rw_cpu.cpp:159).  Its Philox block is
-                        // NOT worked out here: a wave adopts a start row in almost every other iteration, one lane
-                        // at a time, and ten rounds for one lane cost what they cost for 64.  The slot goes to the
-                        // burst as an "odd trial on block -1": the burst's next block is block 0, word 0 is the draw.
+                    } else {  // first step: plain uniform neighbour, draw 0 (rw_cpu.cpp:159), drawn at refill (PF_X)
                         FastMod fm;
                         fm.init_exact(deg);
-                        P[PF_START][slot] = start;
-                        P[PF_DEG][slot] = deg;
-                        P[PF_Z][slot] = fm.z;
-                        P[PF_RPOS][slot] = 0u;
-                        P[PF_BLK][slot] = 0xFFFFFFFFu;
-                        P[PF_FLAGS][slot] = kPfOdd | kPfFirst;
-                        to_trial = true;
+                        P[PF_AT][slot] = start + fm.mod31(P[PF_X][slot] >> 1);
+                        P[PF_FLAGS][slot] = PK_ENTRY << 4;
+                        if (kCount) ++n_fetch;
+                        to_issue = true;
                     }
                 } else if (hkind == PK_ENTRY) {  // e0, e1 = the accepted entry: step onto it
                     const uint32_t x = e0.x;
@@ -1830,10 +1845,7 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                         P[PF_START][slot] = e0.y;
                         P[PF_DEG][slot] = deg;
                         P[PF_Z][slot] = fm.z;
-                        P[PF_M0][slot] = e1.x;
-                        P[PF_M1][slot] = e1.y;
-                        P[PF_M2][slot] = e1.z;
-                        P[PF_M3][slot] = e1.w;
+                        M[slot] = u32x4_a16{e1.x, e1.y, e1.z, e1.w};
                         P[PF_S][slot] = (uint32_t)s;
                         P[PF_RPOS][slot] = e0.w;
                         const uint32_t keep = P[PF_FLAGS][slot] & kPfOdd;  // (rejections and probe count start at 0)
@@ -1852,9 +1864,6 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                     P[PF_FLAGS][slot] = (P[PF_FLAGS][slot] & ~(kPfKind | kPfProbe)) | (PK_MEMBER << 4);
                     to_issue = true;
                 } else {  // PK_MEMBER / PK_POS: e0, e1 = an aligned PAIR of table slots {u, v, lo, cnt-1}
-                    // (both halves of one 32-byte chunk, i.e. of one cache line: the probe chain of a key starts at its
-                    // slot s0 and runs slot by slot; pair p of a lookup is slots 2 (s0/2 + p), +1 -- in pair 0 the
-                    // slot BEFORE an odd s0 is not part of the chain)
                     if (kCount) ++n_probes;
                     const uint32_t t = P[PF_T][slot], prev = P[PF_PREV][slot];
                     const uint32_t ku = hkind == PK_MEMBER ? t : prev, kv = hkind == PK_MEMBER ? P[PF_X][slot] : t;
@@ -1894,8 +1903,10 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                         if (cnt <= 15u && lo < (1u << 28)) {
                             P[PF_RPOS][slot] = cnt ? (cnt << 28 | lo) : 0u;
                         } else {  // the run goes where two mask words were; the mask then says "look" for every offset
-                            P[PF_M2][slot] = lo;
-                            P[PF_M3][slot] = cnt;
+                            u32x4_a16 mm = M[slot];
+                            mm.z = lo;
+                            mm.w = cnt;
+                            M[slot] = mm;
                             flags = (flags & ~kPfExact) | kPfWide;
                         }
                         P[PF_FLAGS][slot] = flags;
@@ -1940,7 +1951,6 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
             left = left < 0 ? 0 : left;
             const uint32_t take = left < (int64_t)avail ? (uint32_t)left : avail;
             if (take < avail) more_walkers = false;
-            // pop `take` slots only
             const uint32_t keep_count = free_q.count;
             free_q.pop(lane, n, slot);
             if (take < n) {  // hand the unused ones back (they are the last ones popped)
@@ -1957,11 +1967,21 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                     for (int32_t c = 0; c <= L; ++c) rowp[c] = tg;
                     back = true;
                 } else {
+                    // block 0 of the walker's stream, for the whole pass of new walkers at once: word 0 is the first
+                    // step's draw (kept in PF_X until the start row has arrived), words 1..3 the first trials'
+                    uint32_t nb[4];
+                    const uint64_t gw0 = (uint64_t)walker_base + (uint64_t)walker;
+                    philox4x32_10_keyed((uint32_t)gw0, (uint32_t)(gw0 >> 32), 0u, 0u, key_r, nb);
                     P[PF_WALKER][slot] = (uint32_t)walker;
                     out[walker * cols] = tg;  // column 0
                     P[PF_PREV][slot] = (uint32_t)tg;  // step 1 leaves the start node
                     P[PF_T][slot] = (uint32_t)tg;
                     P[PF_S][slot] = 1u;
+                    P[PF_X][slot] = nb[0];
+                    P[PF_W1][slot] = nb[1];
+                    P[PF_W2][slot] = nb[2];
+                    P[PF_W3][slot] = nb[3];
+                    P[PF_BLK][slot] = 0u;
                     P[PF_FLAGS][slot] = PK_ROW << 4;
                     to_issue = true;
                 }
@@ -2007,7 +2027,7 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
 #if TRW_POOL_PRIO
         __builtin_amdgcn_s_setprio(TRW_POOL_PRIO == 1 ? 0 : 3);
 #endif
-        // ================= burst: trials for a wave of slots that are between gathers =================
+        // ================= burst: pairs of trials for a wave of slots that are between gathers =================
         if (trial_q.count >= kPoolTrialMin || (trial_q.count > 0u && issue_q.count < kPoolIssueMin)) {
             uint32_t n, slot;
             trial_q.pop(lane, n, slot);
@@ -2015,80 +2035,94 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                 ++w_pass[2];
                 w_lanes[2] += n;
             }
-            bool busy = (uint32_t)lane < n;
-            // the slot's trial state, into registers
-            const uint32_t t_start = P[PF_START][slot], deg = P[PF_DEG][slot];
-            FastMod fm;
-            fm.d = busy ? deg : 1u;
-            fm.z = P[PF_Z][slot];
+            const bool busy = (uint32_t)lane < n;
+            const uint32_t t_start = P[PF_START][slot];
+            const uint32_t deg = busy ? P[PF_DEG][slot] : 1u, z = P[PF_Z][slot];
             const uint32_t flags = P[PF_FLAGS][slot], rpos = P[PF_RPOS][slot];
-            const bool exact = (flags & kPfExact) != 0u, first = (flags & kPfFirst) != 0u, wide = (flags & kPfWide) != 0u;
+            const bool exact = (flags & kPfExact) != 0u, wide = (flags & kPfWide) != 0u;
             uint32_t pos_lo = rpos & 0x0FFFFFFFu, pos_cnt = rpos >> 28;
+            // the mask of the slot; a wide slot reads sixteen 0xFF bytes and keeps its run of t where mask words 2 and 3
+            // would be
+            const uint32_t *mask_at = reinterpret_cast<const uint32_t *>(M + (wide ? (uint32_t)kPoolSlots : slot));
             if (wide) {
-                pos_lo = P[PF_M2][slot];
-                pos_cnt = P[PF_M3][slot];
+                const u32x4_a16 mm = M[slot];
+                pos_lo = mm.z;
+                pos_cnt = mm.w;
             }
+            // thresholds of a candidate whose mask bit is set: an exact bit says "neighbour of t" (t1 either way), a
+            // filter bit says "maybe": accepted below lo whatever it is, looked at inside [lo, hi)
+            const uint32_t thr_a = exact ? bp.t1 : bp.lo, thr_r = exact ? bp.t1 : bp.hi;
             bool odd = (flags & kPfOdd) != 0u;
             uint32_t rejected = (flags & kPfRejMask) >> kPfRejShift;
             uint32_t w1 = P[PF_W1][slot], w2 = P[PF_W2][slot], w3 = P[PF_W3][slot], blk_at = P[PF_BLK][slot];
             const uint64_t gw = (uint64_t)walker_base + (uint64_t)P[PF_WALKER][slot];
-            // outcome of the lane's last trial: accepted / the candidate has to be looked at (filter bit) / neither
             bool take = false, test = false;
             uint32_t at = 0u;
-            // (looking at the runaway-rejection cap only when some lane is within a burst of it measured 1.5 % SLOWER
-            // than the plain per-trial compare)
 
-            auto trial = [&](uint32_t rc, uint32_t ru, bool forced) {
-                if (kCount && !forced) ++n_trials;
-                const uint32_t idx = fm.mod31(rc);
-                // the mask word comes straight from the slot (one LDS read by computed address: the four-way select
-                // between registers compiled to branches, ~15 instructions of a kernel that is bound by issue)
-                const uint32_t word = P[PF_M0 + (int)((idx >> 5) & 3u)][slot];
-                const bool bit = wide || ((word >> (idx & 31u)) & 1u);
-                // verdict 0 reject / 1 accept / 2 look at the candidate, by selects: the same logic written as lane-mask
-                // algebra (compares + scalar and/or) measured 59 ms instead of 52 -- with three waves per SIMD the
-                // VALU -> SALU -> exec round trips cost more than the v_cndmask chain
-                const uint32_t v_band = bit ? (exact ? v_set_exact : 2u) : v_clear;
-                const uint32_t v_other = ru < bp.lo ? 1u : (ru >= bp.hi ? 0u : v_band);
-                uint32_t v = (idx - pos_lo < pos_cnt) ? (ru < bp.t0 ? 1u : 0u) : v_other;
-                v = forced ? 1u : v;  // the first step takes whatever it drew (no acceptance draw is consumed)
-                rejected = v == 0u ? rejected + 1u : rejected;
-                if (rejected >= kTrialCap) {  // take whatever this trial drew
-                    st |= (uint32_t)kStTrialCap;
-                    v = 1u;
-                }
-                take = v == 1u;
-                test = v == 2u;
-                at = t_start + idx;
+            // one trial: candidate draw word rc_w, acceptance draw word ru_w (the draws are the words >> 1)
+            auto trial = [&](uint32_t rc_w, uint32_t ru_w, uint32_t &idx, bool &acc, bool &tst) {
+                const uint32_t rc = rc_w >> 1, ru = ru_w >> 1;
+                const uint32_t r = rc - __umulhi(rc, z) * deg, r1 = r - deg;
+                idx = r1 < r ? r1 : r;  // FastMod::mod31
+                const uint32_t word = mask_at[(idx >> 5) & 3u];
+                int32_t bitm;  // all ones iff mask bit idx & 127 is set
+                asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(bitm) : "v"(word), "v"(idx));
+                const uint32_t m = (uint32_t)bitm;
+                const uint32_t band_a = (thr_a & m) | (bp.t2 & ~m), band_r = (thr_r & m) | (bp.t2 & ~m);
+                const bool in_run = idx - pos_lo < pos_cnt;
+                const uint32_t ta = in_run ? t0_v : band_a, tr = in_run ? t0_v : band_r;
+                acc = ru < ta;
+                tst = !acc && ru < tr;
             };
+
             bool running = busy;
+#if TRW_POOL_UNROLL
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
             for (int rep = 0; rep < kPoolPairs; ++rep) {
+#if !TRW_POOL_UNROLL
                 if (__ballot(running) == 0) break;
+#endif
                 if (kCount) ++w_trial_passes;
                 if (running) {
                     uint32_t nb[4];
-                    walker_block(gw, blk_at + 1u, seed, nb);
-                    const bool was_odd = odd;
-                    trial((was_odd ? (first ? nb[0] : w3) : w1) >> 1, (was_odd ? nb[0] : w2) >> 1, first);
-                    if (was_odd) {  // moved on to the next block (now an even trial on it)
-                        w1 = nb[1];
-                        w2 = nb[2];
-                        w3 = nb[3];
-                        ++blk_at;
-                    }
-                    odd = !was_odd;
-                    if (!(take || test)) {  // second trial of the pair
-                        trial((was_odd ? w1 : w3) >> 1, (was_odd ? w2 : nb[0]) >> 1, false);
-                        if (!was_odd) {
-                            w1 = nb[1];
-                            w2 = nb[2];
-                            w3 = nb[3];
-                            ++blk_at;
+                    philox4x32_10_keyed((uint32_t)gw, (uint32_t)(gw >> 32), blk_at + 1u, 0u, key_r, nb);
+                    // the pair's four draws: words 1, 2, 3 of the current block and word 0 of the next one, or -- the
+                    // stream stands one trial further on (odd) -- words 3 | 0, 1, 2
+                    const uint32_t x0 = odd ? w3 : w1, x1 = odd ? nb[0] : w2, x2 = odd ? nb[1] : w3, x3 = odd ? nb[2] : nb[0];
+                    uint32_t idx1, idx2;
+                    bool acc1, tst1, acc2, tst2;
+                    trial(x0, x1, idx1, acc1, tst1);
+                    trial(x2, x3, idx2, acc2, tst2);
+                    // (lane masks combined as masks: a select between two bools would go through 0 / 1 integers)
+                    const bool f1 = acc1 || tst1;
+                    bool fin = f1 || acc2 || tst2;
+                    take = acc1 || (!f1 && acc2);
+                    uint32_t idx = f1 ? idx1 : idx2;
+                    rejected += f1 ? 0u : 1u;
+                    rejected += fin ? 0u : 1u;
+                    if (kCount) n_trials += f1 ? 1u : 2u;
+                    if (rejected >= kTrialCap) {  // runaway rejection loop: take what the pair's last trial drew
+                        st |= (uint32_t)kStTrialCap;
+                        if (!fin) {
+                            fin = true;
+                            take = true;
+                            idx = idx2;
                         }
-                        odd = was_odd;
                     }
-                    running = !(take || test);
+                    test = fin && !take;
+                    at = t_start + idx;
+                    // where the stream stands now: a pair used up moves on one block at the same parity; a step
+                    // finished by the pair's first trial flips the parity (and, from even, stays on its block)
+                    const bool stay = !odd && f1;
+                    w1 = nb[1];
+                    w2 = nb[2];
+                    w3 = stay ? w3 : nb[3];
+                    blk_at += stay ? 0u : 1u;
+                    odd = odd != f1;
+                    running = !fin;
                 }
             }
             // write back what moved

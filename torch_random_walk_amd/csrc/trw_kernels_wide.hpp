@@ -134,6 +134,27 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
 
+// The same ten rounds with the first key word's schedule handed in (seed + r * 0x9E3779B9, r = 0..9) -- by the
+// walker pools, which keep it in VECTOR registers: a v_xor_b32 with a scalar operand costs 4.3 cycles per wave where
+// one between vector registers or with a literal costs 2.6 (scripts/alu_probe2.hip), and a block has ten of them.
+// (The second key word is 0 + r * 0xBB67AE85: literals.)
+__device__ __forceinline__ void philox4x32_10_keyed(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                    const uint32_t (&k0r)[10], uint32_t (&o)[4])
+{
+    uint32_t k1 = 0u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0, lo0, hi1, lo1;
+        mulhilo32(0xD2511F53u, c0, hi0, lo0);
+        mulhilo32(0xCD9E8D57u, c2, hi1, lo1);
+        const uint32_t n0 = hi1 ^ c1 ^ k0r[r];
+        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
 // Block `blk` of walker `w`'s stream: key (seed, 0), counter (w_lo, w_hi, blk, 0).
 __device__ __forceinline__ void walker_block(uint64_t w, uint32_t blk, uint32_t seed, uint32_t (&o)[4])
 {
