@@ -64,6 +64,9 @@ WORKLOADS = {
     "elist_rmat1m_uniform": dict(graph="elist", nodes=1_000_000, edges=10_000_000, p=1.0, q=1.0, walks_per_node=1),
     "windows_1m": dict(graph="windows", nodes=10_000_000, edges=0, p=1.0, q=1.0, walks_per_node=1, walks=1_000_000,
                        window_size=5),
+    # rw.walk_windows: the uniform walk and to_windows as one call (R-MAT 1 M / 10 M, one walker per node, window 5)
+    "walk_windows_1m": dict(graph="rmat", nodes=1_000_000, edges=10_000_000, p=1.0, q=1.0, walks_per_node=1,
+                            fused_window=5),
     # small variants for quick checks / CI on the GPU box
     "rmat1m_biased": dict(graph="rmat", nodes=1_000_000, edges=10_000_000, p=0.25, q=4.0, walks_per_node=1),
     "rmat1m_uniform": dict(graph="rmat", nodes=1_000_000, edges=10_000_000, p=1.0, q=1.0, walks_per_node=1),
@@ -218,9 +221,11 @@ def main():
     gather = (world > 1) and not args.no_gather
     full = None
     fulls, lands, wires, step_no = [], [], [], [0]
-    csr = not (windows or elist or kg)
+    csr = not (windows or elist or kg or cfg.get("fused_window"))
     if windows:
         cols = (L + 1 - cfg["window_size"] + 1) * (cfg["window_size"] - 1)
+    if cfg.get("fused_window"):
+        cols = (L + 1 - cfg["fused_window"] + 1) * (cfg["fused_window"] - 1)
     # What a block travels as (dist.wire_dtype_for): uint32 while every value fits -- node ids < n, the edge-list /
     # triples walks' padding id n, relation ids < n -- half the bytes per xGMI link; widened where it lands.
     wire32 = gather and args.wire != "int64" and (n + 1) <= (1 << 32)
@@ -242,7 +247,12 @@ def main():
         if wire32:
             wires = [torch.empty((B, cols), dtype=torch.int32, device=dev) for _ in range(2)]
 
+    fused_ws = cfg.get("fused_window", 0)
+
     def walk(tg, base, check):
+        if fused_ws:  # walk + to_windows in one call; the result the bench tracks is pos_windows, one row per walker
+            return rw.walk_windows(row_ptr, col_idx, tg, p, q, L, args.seed, fused_ws, n, walker_base=base,
+                                   check=check)[1].view(tg.numel(), -1)
         if windows:   # "walkers" are walks here; the result the bench tracks is the negatives tensor
             lo = int(tg[0]) if tg.numel() else 0
             return rw.to_windows_ex(win_walks[lo:lo + tg.numel()], cfg["window_size"], n, args.seed,
@@ -495,6 +505,14 @@ def main():
         counters = dict(live_hops=live_hops, hops=B * L)
         alg_bytes = B * 16 + 32 * live_hops + 16 * B * L
         kernel_name = "triples_walker_kernel"
+    elif fused_ws:
+        # the walk's reads (8 B target + 8 B row pair per walker, one 16-byte entry gathered + 16 B of row32 per step
+        # as in the plain uniform walk's count) + every window's centre, positives and negatives written once
+        n_win = B * (L + 1 - fused_ws + 1)
+        alg_bytes = B * (16 + 24 * L) + n_win * 8 * (1 + 2 * (fused_ws - 1))
+        kernel_name = "uniform_glibc_rows_kernel<fat,windows> || glibc_fill_mod_kernel"
+        counters = dict(windows=n_win, window_size=fused_ws,
+                        fused=bool(lib.trw_walk_windows_fused(n, nnz, B, L, fused_ws, 1)))
     elif uniform:
         alg_bytes = B * (16 + 32 * L)
         # which kernel family ran: one more (untimed) call through the C ABI over a graph prepared exactly as the timed
@@ -658,6 +676,15 @@ def main():
 
             def cpu_run(tg_h):
                 return O.walk_triples(ts_h, ix_h, tg_h, L, pad, args.seed, rng_mode=O.RNG_LIBC, timed=True)[1]
+        elif fused_ws:
+            rp_h, ci_h = row_ptr.cpu().numpy(), col_idx.cpu().numpy()
+
+            def cpu_run(tg_h):   # the reference's two calls: walk, then to_windows over its rows
+                import time as _t
+                w_h, dt_w = O.walk_timed(rp_h, ci_h, tg_h, p, q, L, args.seed, rng_mode=O.RNG_LIBC)
+                t_ = _t.perf_counter()
+                O.to_windows(w_h, fused_ws, n, args.seed, rng_mode=O.RNG_LIBC)
+                return dt_w + _t.perf_counter() - t_
         else:
             rp_h, ci_h = row_ptr.cpu().numpy(), col_idx.cpu().numpy()
 
@@ -672,7 +699,7 @@ def main():
                    sample="first %d start nodes of a seeded permutation of the batch, %d steps, %.1f s, "
                           "oracle libc srand/rand single thread (the reference's csrc/cpu algorithm; its "
                           "multi-threaded run is slower and non-deterministic, SURVEY 0.2)" % (sample, sample * L, dt))
-        if not (windows or elist or kg):
+        if not (windows or elist or kg or fused_ws):
             # the reference's multi-threaded policy beside the single thread (all host threads on the
             # one locked libc rand(); non-deterministic output), a quarter of the time budget; the faster one is
             # the baseline.
@@ -701,6 +728,11 @@ def main():
             ref_w = O.walk_triples(ts_h, ix_h, tg_cpu[:m].numpy(), L, pad, args.seed, rng_mode=O.RNG_WALKER,
                                    walker_base=walker_base)
             assert (ref_w == walks[:m].cpu().numpy()).all(), "GPU rows differ from the oracle"
+        elif fused_ws:
+            assert walker_base == 0
+            ref_w = O.walk(rp_h, ci_h, tg_cpu[:m].numpy(), p, q, L, args.seed, rng_mode=O.RNG_GLIBC_INDEXED)
+            ref_p = O.to_windows(ref_w, fused_ws, n, args.seed)[1].reshape(m, -1)
+            assert (ref_p == walks[:m].cpu().numpy()).all(), "GPU windows differ from the oracle"
         elif uniform:
             ref_w = O.walk(rp_h, ci_h, tg_cpu[:m].numpy(), p, q, L, args.seed, rng_mode=O.RNG_GLIBC_INDEXED,
                            walker_base=walker_base)

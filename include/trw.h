@@ -326,6 +326,27 @@ int trw_to_windows_triples_cbow_hip(const int64_t *walks, int64_t num_walks, int
                                     size_t workspace_bytes, void *hip_stream);
 
 /*
+ * The uniform walk and to_windows as ONE call (torch_rw/rw.py:3-4 followed by :29-30; csrc/cpu/rw_cpu.cpp:58-107 then
+ * csrc/cpu/windows_cpu.cpp:5-77): target_nodes / pos_windows / neg_windows come out equal, bit for bit, to
+ *     trw_to_windows_hip(trw_walk_csr_prepared_hip(..., p = q = 1, seed, TRW_RNG_GLIBC), window_size, num_nodes,
+ *                        window_seed, walk_base = walker_base)
+ * -- when trw_walk_windows_fused() says 1 for the shape, from a single walk kernel that writes the windows out of its
+ * LDS tile (the [n_walkers, walk_length+1] rows never make the round trip through HBM; `walks` may then be NULL, or
+ * a buffer that receives them as well); otherwise as the two passes, and `walks` is required.  `prepared` / `what`: a
+ * prepared graph as for trw_walk_csr_prepared_hip.  Workspace: trw_walk_windows_workspace_bytes(); its first 256 bytes
+ * are the walk's status block (trw_walk_status).
+ */
+int trw_walk_windows_fused(int64_t n_nodes, int64_t nnz, int64_t n_walkers, int32_t walk_length, int32_t window_size,
+                           int32_t what);
+size_t trw_walk_windows_workspace_bytes(int64_t n_walkers, int32_t walk_length, int32_t window_size);
+int trw_walk_windows_csr_prepared_hip(const void *prepared, size_t prepared_bytes, int32_t what, const int64_t *row_ptr,
+                                      int64_t n_nodes, const int64_t *col_idx, int64_t nnz, const int64_t *targets,
+                                      int64_t n_walkers, int64_t walker_base, int32_t walk_length, int32_t seed,
+                                      int32_t window_size, int64_t num_nodes, int32_t window_seed, int64_t *walks,
+                                      int64_t *target_nodes, int64_t *pos_windows, int64_t *neg_windows, void *workspace,
+                                      size_t workspace_bytes, void *hip_stream);
+
+/*
  * Host legs of the rows next to the CSR walk: what the reference's dispatcher does with CPU tensors for its other
  * entry points (csrc/rw_init.cpp:27-131 -> walk_edge_list_cpu, triples::walk_triples_cpu, to_windows*_cpu).  HOST
  * pointers, synchronous, one thread, the reference's one glibc rand() stream (that is csrc/cpu on one thread);

@@ -123,6 +123,39 @@ __global__ void __launch_bounds__(256) copy_kernel(const float4 *__restrict__ sr
     }
 }
 
+// write-only stream (what the window builders' outputs can hope for): 16 or 8 bytes per thread, one trip per thread
+template <int kBytes>
+__global__ void __launch_bounds__(256) write_kernel(unsigned long long *__restrict__ dst, size_t n8, unsigned long long v)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (kBytes == 16) {
+        typedef unsigned long long u64x2_p __attribute__((ext_vector_type(2)));
+        if (2 * i + 1 < n8) reinterpret_cast<u64x2_p *>(dst)[i] = u64x2_p{v + i, v};
+    } else {
+        if (i < n8) dst[i] = v + i;
+    }
+}
+
+template <int kBytes>
+static double time_write(void *dst, size_t bytes, int reps)
+{
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a));
+    CHECK(hipEventCreate(&b));
+    const size_t n8 = bytes / 8, threads = kBytes == 16 ? n8 / 2 : n8;
+    const unsigned blocks = (unsigned)((threads + 255) / 256);
+    write_kernel<kBytes><<<blocks, 256>>>((unsigned long long *)dst, n8, 1ull);
+    CHECK(hipEventRecord(a));
+    for (int i = 0; i < reps; ++i) write_kernel<kBytes><<<blocks, 256>>>((unsigned long long *)dst, n8, 2ull + i);
+    CHECK(hipEventRecord(b));
+    CHECK(hipEventSynchronize(b));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, a, b));
+    CHECK(hipEventDestroy(a));
+    CHECK(hipEventDestroy(b));
+    return ms / reps;
+}
+
 template <int kPer, bool kNt>
 static double time_copy(const void *src, void *dst, size_t bytes, int blocks, int reps)
 {
@@ -215,6 +248,9 @@ int main(int argc, char **argv)
                 best_name = x.name;
             }
         }
+        const double w16 = time_write<16>(dst, bytes, reps), w8 = time_write<8>(dst, bytes, reps);
+        printf("stream_write: 4 GiB, 16 B per thread %.3f ms = %.0f GB/s; 8 B per thread %.3f ms = %.0f GB/s\n", w16,
+               bytes / (w16 * 1e-3) / 1e9, w8, bytes / (w8 * 1e-3) / 1e9);
         printf("stream_copy: 4 GiB device-to-device, %.3f ms per copy, %.0f GB/s read+write (best: %s)\n", best,
                2.0 * bytes / (best * 1e-3) / 1e9, best_name);
         CHECK(hipFree(src));

@@ -765,6 +765,73 @@ std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> to_windows_cbow(const to
     return windows_impl(walks, window_size, num_nodes, seed, true, 0, g_rng_mode.load());
 }
 
+// rw.walk_windows: walk followed by to_windows (torch_rw/rw.py:3-4, :29-30) as one call.  Returns (target_nodes,
+// pos_windows, neg_windows, walks-or-empty), equal to to_windows(walk_ex(...), window_size, num_nodes, window_seed)
+// with the windows numbered from walker_base.  The reference-exact uniform walk over a cached prepared graph runs as
+// ONE walk kernel that writes the windows from its LDS tile (include/trw.h: trw_walk_windows_csr_prepared_hip); every
+// other case (node2vec walks, CPU tensors, window_size > 9, no cache) is the two calls, composed here.
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
+walk_windows(const torch::Tensor &row_ptr, const torch::Tensor &col_idx, const torch::Tensor &target_nodes, double p,
+             double q, int64_t walk_length, int64_t seed, int64_t window_size, int64_t num_nodes, int64_t window_seed,
+             int64_t walker_base, bool return_walks, int64_t check)
+{
+    TORCH_CHECK(walk_length >= 1, "walk_length must be >= 1, got ", walk_length);
+    TORCH_CHECK(window_size >= 1 && window_size <= walk_length + 1, "window_size must be between 1 and the walk width");
+    TORCH_CHECK(seed >= INT32_MIN && seed <= INT32_MAX && window_seed >= INT32_MIN && window_seed <= INT32_MAX &&
+                    walk_length < (int64_t(1) << 31), "walk_length/seed must fit the reference's int arguments");
+    const bool uniform = p == 1.0 && q == 1.0;
+    const int64_t rng = uniform ? (int64_t)TRW_RNG_GLIBC : (int64_t)g_rng_mode.load();
+    auto composed = [&]() {
+        auto walks = walk_ex(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, walker_base, rng, check, c10::nullopt);
+        auto w = windows_impl(walks, window_size, num_nodes, window_seed, false, walker_base, TRW_RNG_GLIBC);
+        return std::make_tuple(std::get<0>(w), std::get<1>(w), std::get<2>(w), return_walks ? walks : torch::Tensor());
+    };
+    if (!row_ptr.is_cuda() || !uniform) return composed();
+    check_index_tensor(row_ptr, "row_ptr");
+    check_index_tensor(col_idx, "col_idx");
+    check_index_tensor(target_nodes, "target_nodes");
+    TORCH_CHECK(row_ptr.device() == col_idx.device() && row_ptr.device() == target_nodes.device(),
+                "row_ptr, col_idx and target_nodes must be on the same device");
+    TORCH_CHECK(row_ptr.numel() >= 1, "row_ptr must have num_nodes + 1 entries");
+    const int64_t n_nodes = row_ptr.numel() - 1, nnz = col_idx.numel(), n_walkers = target_nodes.numel();
+    if (n_walkers == 0 || !row_ptr.is_contiguous() || !col_idx.is_contiguous()) return composed();
+    const int check_mode = resolve_check(check);
+    if (check_mode == kCheckDeferred) raise_pending();
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(row_ptr.device());
+    const auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(row_ptr.device().index());
+    const auto tg = target_nodes.contiguous();
+    const int32_t needed = trw_prepare_plan(n_nodes, nnz, n_walkers, (int32_t)walk_length, 1.0, 1.0, TRW_RNG_GLIBC);
+    PreparedUse prepared;
+    if (needed >= 0) prepared = prepared_for(row_ptr, col_idx, needed, false, false, stream, 0, 0, n_walkers * walk_length, 0);
+    if (!prepared.valid) return composed();
+    const bool fused = trw_walk_windows_fused(n_nodes, nnz, n_walkers, (int32_t)walk_length, (int32_t)window_size,
+                                              prepared.what) == 1;
+    const int64_t W = (walk_length + 1 - window_size + 1) * n_walkers;
+    auto opts = row_ptr.options();
+    auto centre = torch::empty({W}, opts);
+    auto rest = torch::empty({W, window_size - 1}, opts);
+    auto neg = torch::empty({W, window_size - 1}, opts);
+    torch::Tensor walks;
+    if (return_walks || !fused) walks = torch::empty({n_walkers, walk_length + 1}, opts);
+    const size_t ws_bytes = trw_walk_windows_workspace_bytes(n_walkers, (int32_t)walk_length, (int32_t)window_size);
+    auto workspace = torch::empty({(int64_t)ws_bytes}, opts.dtype(torch::kUInt8));
+    void *const hs = (void *)stream.stream();
+    int rc;
+    {
+        pybind11::gil_scoped_release nogil;
+        rc = trw_walk_windows_csr_prepared_hip(prepared.blob.data_ptr(), (size_t)prepared.blob.numel(), prepared.what,
+                                               row_ptr.data_ptr<int64_t>(), n_nodes, col_idx.data_ptr<int64_t>(), nnz,
+                                               tg.data_ptr<int64_t>(), n_walkers, walker_base, (int32_t)walk_length,
+                                               (int32_t)seed, (int32_t)window_size, num_nodes, (int32_t)window_seed,
+                                               walks.defined() ? walks.data_ptr<int64_t>() : nullptr,
+                                               centre.data_ptr<int64_t>(), rest.data_ptr<int64_t>(),
+                                               neg.data_ptr<int64_t>(), workspace.data_ptr(), ws_bytes, hs);
+    }
+    TORCH_CHECK(rc == TRW_OK, "torch_rw walk_windows failed (", rc, "): ", trw_last_error());
+    finish_status(workspace, hs, check_mode, "walk_windows");
+    return std::make_tuple(centre, rest, neg, return_walks ? walks : torch::Tensor());
+}
+
 // to_windows_triples / to_windows_triples_cbow: reference dispatchers csrc/rw_init.cpp:103-131.
 std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> triples_windows_impl(const torch::Tensor &walks,
                                                                              int64_t window_size, int64_t padding_idx,
@@ -862,6 +929,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           pybind11::arg("q"), pybind11::arg("walk_length"), pybind11::arg("seed"), pybind11::arg("walker_base") = 0,
           pybind11::arg("rng_mode") = (int64_t)TRW_RNG_AUTO, pybind11::arg("check") = (int64_t)-1,
           pybind11::arg("out") = pybind11::none());
+    m.def("walk_windows", &walk_windows, "walk + to_windows in one call (the uniform walk: one fused kernel)",
+          pybind11::arg("row_ptr"), pybind11::arg("col_idx"), pybind11::arg("target_nodes"), pybind11::arg("p"),
+          pybind11::arg("q"), pybind11::arg("walk_length"), pybind11::arg("seed"), pybind11::arg("window_size"),
+          pybind11::arg("num_nodes"), pybind11::arg("window_seed"), pybind11::arg("walker_base") = (int64_t)0,
+          pybind11::arg("return_walks") = false, pybind11::arg("check") = (int64_t)-1);
     m.def("to_windows", &to_windows, "to_windows", pybind11::arg("walks"), pybind11::arg("window_size"),
           pybind11::arg("num_nodes"), pybind11::arg("seed"));
     m.def("to_windows_cbow", &to_windows_cbow, "to_windows", pybind11::arg("walks"), pybind11::arg("window_size"),

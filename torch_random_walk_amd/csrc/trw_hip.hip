@@ -533,15 +533,22 @@ size_t trw_walk_csr_prepared_workspace_bytes(int64_t n_walkers, int32_t walk_len
     return make_call_layout(n_walkers, walk_length, p == 1.0 && q == 1.0, rng_mode).total;
 }
 
+// The fused walk + to_windows (trw_walk_windows_csr_prepared_hip): where the uniform walk kernel puts the windows.
+struct FusedWindows {
+    int32_t window_size = 0;
+    int64_t *centre = nullptr, *pos = nullptr;
+};
+
 static int walk_prepared(const void *prepared, size_t prepared_bytes, int32_t what, const int64_t *row_ptr,
                          int64_t n_nodes, const int64_t *col_idx, int64_t nnz, const int64_t *targets,
                          int64_t n_walkers, int64_t walker_base, double p, double q, int32_t walk_length, int32_t seed,
                          int32_t rng_mode, int64_t *out, void *workspace, size_t workspace_bytes, void *hip_stream,
-                         bool mark_prepare);
+                         bool mark_prepare, const FusedWindows *fused = nullptr);
 
 static int check_walk_args(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col_idx, int64_t nnz,
                            const int64_t *targets, int64_t n_walkers, int64_t walker_base, double p, double q,
-                           int32_t walk_length, const int64_t *out, const void *workspace, size_t workspace_bytes)
+                           int32_t walk_length, const int64_t *out, const void *workspace, size_t workspace_bytes,
+                           bool out_optional = false)
 {
     if (n_nodes < 0 || nnz < 0 || n_walkers < 0 || walker_base < 0)
         return fail(TRW_E_ARG, "negative size argument");
@@ -549,7 +556,7 @@ static int check_walk_args(const int64_t *row_ptr, int64_t n_nodes, const int64_
     if (!(p > 0.0) || !(q > 0.0) || !std::isfinite(p) || !std::isfinite(q))
         return fail(TRW_E_ARG, "p and q must be positive and finite");
     if (!row_ptr) return fail(TRW_E_ARG, "row_ptr is null");
-    if (n_walkers > 0 && (!targets || !out)) return fail(TRW_E_ARG, "targets/out is null");
+    if (n_walkers > 0 && (!targets || (!out && !out_optional))) return fail(TRW_E_ARG, "targets/out is null");
     if (nnz > 0 && !col_idx) return fail(TRW_E_ARG, "col_idx is null");
     if (n_walkers > 0 && n_nodes == 0) return fail(TRW_E_ARG, "walkers on an empty graph");
     if (!workspace || workspace_bytes < (size_t)kStatusBytes)
@@ -573,11 +580,11 @@ static int walk_prepared(const void *prepared, size_t prepared_bytes, int32_t wh
                          int64_t n_nodes, const int64_t *col_idx, int64_t nnz, const int64_t *targets,
                          int64_t n_walkers, int64_t walker_base, double p, double q, int32_t walk_length, int32_t seed,
                          int32_t rng_mode, int64_t *out, void *workspace, size_t workspace_bytes, void *hip_stream,
-                         bool mark_prepare)
+                         bool mark_prepare, const FusedWindows *fused)
 {
     t_last_error.clear();
     if (int rc = check_walk_args(row_ptr, n_nodes, col_idx, nnz, targets, n_walkers, walker_base, p, q, walk_length, out,
-                                 workspace, workspace_bytes))
+                                 workspace, workspace_bytes, fused != nullptr))
         return rc;
     const PrepLayout pl = make_prep_layout(n_nodes, nnz, what);
     if (!prepared || prepared_bytes < pl.total || ((uintptr_t)prepared & 15u) != 0)
@@ -649,13 +656,23 @@ static int walk_prepared(const void *prepared, size_t prepared_bytes, int32_t wh
             // ms); a small batch revisits few rows and is better off with the compact shadow.
             const long ext_forced = env_long("TRW_EXT", 0, 1, -1);
             const bool use_fat = pl.ext16 && (ext_forced == 1 || (ext_forced == -1 && (__int128)n_walkers * L * 4 >= (__int128)nnz));
-            if (pl.narrow && rows_fit && use_fat)
-                uniform_glibc_rows_kernel<true><<<lane_grid, kBlock, 0, stream>>>(
+            if (fused) {  // (the caller made sure of the shape: walk_windows_fusable)
+                if (use_fat)
+                    uniform_glibc_rows_kernel<true, true><<<lane_grid, kBlock, 0, stream>>>(
+                        row32, col32, (const u32x4_a16 *)(pw + pl.off_ext16), targets, n_nodes, n_walkers, walk_length,
+                        cl.G, cl.nlanes, win, out, status, fused->window_size, fused->centre, fused->pos);
+                else
+                    uniform_glibc_rows_kernel<false, true><<<lane_grid, kBlock, 0, stream>>>(
+                        row32, col32, nullptr, targets, n_nodes, n_walkers, walk_length, cl.G, cl.nlanes, win, out,
+                        status, fused->window_size, fused->centre, fused->pos);
+            } else if (pl.narrow && rows_fit && use_fat)
+                uniform_glibc_rows_kernel<true, false><<<lane_grid, kBlock, 0, stream>>>(
                     row32, col32, (const u32x4_a16 *)(pw + pl.off_ext16), targets, n_nodes, n_walkers, walk_length,
-                    cl.G, cl.nlanes, win, out, status);
+                    cl.G, cl.nlanes, win, out, status, 0, nullptr, nullptr);
             else if (pl.narrow && rows_fit)
-                uniform_glibc_rows_kernel<false><<<lane_grid, kBlock, 0, stream>>>(
-                    row32, col32, nullptr, targets, n_nodes, n_walkers, walk_length, cl.G, cl.nlanes, win, out, status);
+                uniform_glibc_rows_kernel<false, false><<<lane_grid, kBlock, 0, stream>>>(
+                    row32, col32, nullptr, targets, n_nodes, n_walkers, walk_length, cl.G, cl.nlanes, win, out, status, 0,
+                    nullptr, nullptr);
             else
                 uniform_glibc_wide_kernel<<<lane_grid, kBlock, 0, stream>>>(row_ptr, col_idx, targets, n_nodes, nnz,
                                                                            n_walkers, walk_length, cl.G, cl.nlanes,
@@ -1094,6 +1111,166 @@ int trw_walk_edge_list_hip(const int64_t *edges, int64_t n_edges, const int64_t 
 
 // ---- window builders, reference csrc/cpu/windows_cpu.cpp ------------------------------------------
 
+// A second stream per device for work that does not depend on the call's main kernel (the negatives of the window
+// builders: glibc's stream modulo num_nodes, write-bound) so that it runs BESIDE it (the walk: bound by gather
+// latency; the window gather: its own store stream): fork() makes the side stream wait for everything queued on the
+// caller's stream so far, join() makes the caller's stream wait for the side work.  Event-based fork / join is what a
+// stream capture records as graph dependencies, so a captured call replays with the same overlap.
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    bool ok = false;
+};
+
+static SideStream *side_stream()
+{
+    static std::mutex mu;
+    static SideStream per_device[64];
+    static bool tried[64] = {false};
+    int dev = 0;
+    if (env_long("TRW_SIDE_STREAM", 0, 1, 1) == 0 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    SideStream &s = per_device[dev];
+    if (!tried[dev]) {
+        tried[dev] = true;
+        s.ok = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&s.fork_ev, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&s.join_ev, hipEventDisableTiming) == hipSuccess;
+    }
+    return s.ok ? &s : nullptr;
+}
+
+// fork: the stream side work goes to (the caller's own stream when there is no side stream); join: back
+static hipStream_t side_fork(hipStream_t main, SideStream *&side)
+{
+    side = side_stream();
+    if (side && hipEventRecord(side->fork_ev, main) == hipSuccess && hipStreamWaitEvent(side->stream, side->fork_ev, 0) == hipSuccess)
+        return side->stream;
+    side = nullptr;
+    return main;
+}
+
+static void side_join(hipStream_t main, SideStream *side)
+{
+    if (!side) return;
+    if (hipEventRecord(side->join_ev, side->stream) != hipSuccess || hipStreamWaitEvent(main, side->join_ev, 0) != hipSuccess)
+        (void)hipStreamSynchronize(side->stream);  // (never expected; keeps the ordering the caller relies on)
+}
+
+// centre / pos of every window: blocks of whole walks through LDS, or -- walks too long for the tile -- in place
+static void launch_windows_gather(const int64_t *walks, int64_t num_walks, int64_t cols, int32_t window_size,
+                                  int64_t *centre, int64_t *pos, hipStream_t stream)
+{
+    const int64_t step_end = cols - window_size + 1, per_walk = step_end * (window_size > 1 ? window_size - 1 : 1);
+    int64_t wpb = kWinTileWords / cols;
+    const int64_t by_out = (((int64_t)1 << 22) - 1) / per_walk;
+    if (wpb > by_out) wpb = by_out;
+    // enough blocks to fill the chip a few times over, each with a few thousand values to write
+    while (wpb > 1 && (num_walks + wpb - 1) / wpb < 4096 && wpb * per_walk > 2048) wpb /= 2;
+    if (wpb >= 1 && num_walks > 0 && (num_walks + wpb - 1) / wpb < ((int64_t)1 << 31))
+        windows_gather_kernel<<<(unsigned)((num_walks + wpb - 1) / wpb), kBlock, 0, stream>>>(
+            walks, num_walks, cols, window_size, (int32_t)wpb, centre, pos);
+    else
+        windows_gather_long_kernel<<<stream_grid(num_walks * step_end), kBlock, 0, stream>>>(walks, num_walks, cols,
+                                                                                           window_size, centre, pos);
+}
+
+// Can this call shape run as ONE walk kernel that emits the windows from its LDS tile?  (Reference-exact uniform walk over
+// the narrow layout; the tile's ring of 16 columns holds a window that started window_size + 6 columns ago.)
+static bool walk_windows_fusable(int64_t n_nodes, int64_t nnz, int64_t n_walkers, int32_t walk_length, int32_t window_size,
+                                 int32_t what)
+{
+    if (n_walkers <= 0 || walk_length < 1 || window_size < 1 || window_size > 9 || window_size > walk_length + 1) return false;
+    if (what < 0 || !make_prep_layout(n_nodes, nnz, what).narrow) return false;
+    const CallLayout cl = make_call_layout(n_walkers, walk_length, true, TRW_RNG_GLIBC);
+    // (a wave's 64 rows of windows are addressed with 32-bit element offsets)
+    return (int64_t)64 * cl.G * ((int64_t)walk_length + 1) < ((int64_t)1 << 29);
+}
+
+int trw_walk_windows_fused(int64_t n_nodes, int64_t nnz, int64_t n_walkers, int32_t walk_length, int32_t window_size,
+                           int32_t what)
+{
+    return walk_windows_fusable(n_nodes, nnz, n_walkers, walk_length, window_size, what) ? 1 : 0;
+}
+
+size_t trw_walk_windows_workspace_bytes(int64_t n_walkers, int32_t walk_length, int32_t window_size)
+{
+    const size_t walk_bytes = align_up(make_call_layout(n_walkers, walk_length, true, TRW_RNG_GLIBC).total, 256);
+    return walk_bytes + trw_to_windows_workspace_bytes(n_walkers, (int64_t)walk_length + 1, window_size);
+}
+
+int trw_walk_windows_csr_prepared_hip(const void *prepared, size_t prepared_bytes, int32_t what, const int64_t *row_ptr,
+                                      int64_t n_nodes, const int64_t *col_idx, int64_t nnz, const int64_t *targets,
+                                      int64_t n_walkers, int64_t walker_base, int32_t walk_length, int32_t seed,
+                                      int32_t window_size, int64_t num_nodes, int32_t window_seed, int64_t *walks,
+                                      int64_t *target_nodes, int64_t *pos_windows, int64_t *neg_windows, void *workspace,
+                                      size_t workspace_bytes, void *hip_stream)
+{
+    t_last_error.clear();
+    const int64_t cols = (int64_t)walk_length + 1;
+    if (walk_length < 1 || window_size < 1 || window_size > cols)
+        return fail(TRW_E_ARG, "window_size must be between 1 and walk_length + 1");
+    if (num_nodes < 1) return fail(TRW_E_ARG, "num_nodes must be >= 1 (the reference computes rand() % num_nodes)");
+    if (n_walkers < 0 || walker_base < 0) return fail(TRW_E_ARG, "negative size argument");
+    if (!workspace || workspace_bytes < trw_walk_windows_workspace_bytes(n_walkers, walk_length, window_size))
+        return fail(TRW_E_WORKSPACE, "workspace too small for this call shape");
+    const int64_t step_end = cols - window_size + 1, width = window_size - 1;
+    const int64_t total_windows = n_walkers * step_end, draws = total_windows * width;
+    if (total_windows > 0 && (!target_nodes || (width > 0 && (!pos_windows || !neg_windows))))
+        return fail(TRW_E_ARG, "output pointer is null");
+    const bool fused = walk_windows_fusable(n_nodes, nnz, n_walkers, walk_length, window_size, what);
+    if (!fused && !walks && n_walkers > 0)
+        return fail(TRW_E_ARG, "this call shape is not fused (trw_walk_windows_fused): it needs the walks buffer");
+    const unsigned __int128 last = ((unsigned __int128)walker_base + n_walkers) * step_end * width;
+    if (last >= ((unsigned __int128)1 << 48)) return fail(TRW_E_RANGE, "glibc stream position beyond 2^48 draws");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const size_t walk_bytes = align_up(make_call_layout(n_walkers, walk_length, true, TRW_RNG_GLIBC).total, 256);
+    // The negatives do not depend on the walks (glibc's stream modulo num_nodes, as trw_to_windows_hip fills it): they are
+    // written on the side stream, beside the walk.  The fork point is here, in front of the walk, but the walk is queued
+    // FIRST: a walk that is already resident leaves the fill the CU share it needs (one workgroup per CU beside the
+    // walk's five), a fill that starts first takes the LDS of every CU and the walk waits for it to finish.
+    SideStream *side = nullptr;
+    if (draws > 0) {
+        if (int rc = ensure_jump_table()) return rc;
+        side = side_stream();
+        if (side && hipEventRecord(side->fork_ev, stream) != hipSuccess) side = nullptr;
+    }
+    FusedWindows fw;
+    fw.window_size = window_size;
+    fw.centre = target_nodes;
+    fw.pos = pos_windows;
+    // the walk (its status block is the call's), with or without the windows coming out of the same kernel
+    const int rc_walk = walk_prepared(prepared, prepared_bytes, what, row_ptr, n_nodes, col_idx, nnz, targets, n_walkers,
+                                      walker_base, 1.0, 1.0, walk_length, seed, TRW_RNG_GLIBC, walks, workspace, walk_bytes,
+                                      hip_stream, true, fused ? &fw : nullptr);
+    if (draws > 0 && rc_walk == TRW_OK) {
+        hipStream_t ss = stream;
+        if (side && hipStreamWaitEvent(side->stream, side->fork_ev, 0) == hipSuccess)
+            ss = side->stream;
+        else
+            side = nullptr;
+        uint32_t *win = (uint32_t *)((char *)workspace + walk_bytes + kStatusBytes);
+        const int64_t nlanes = (draws + fill_run(draws) - 1) / fill_run(draws);
+        SeedWindow sw;
+        trw::seed_window(window_seed, sw.w);
+        glibc_windows_kernel<<<(unsigned)((nlanes + kBlock - 1) / kBlock), kBlock, 0, ss>>>(
+            sw, (uint64_t)walker_base * (uint64_t)step_end * (uint64_t)width, (uint64_t)fill_run(draws), nlanes, win);
+        glibc_fill_mod_kernel<false><<<(unsigned)((nlanes + kBlock - 1) / kBlock), kBlock, 0, ss>>>(
+            win, nlanes, draws, num_nodes, nullptr, neg_windows);
+    } else {
+        side = nullptr;
+    }
+    if (rc_walk == TRW_OK && total_windows > 0 && !fused)
+        launch_windows_gather(walks, n_walkers, cols, window_size, target_nodes, pos_windows, stream);
+    side_join(stream, side);
+    if (rc_walk != TRW_OK) return rc_walk;
+    if (total_windows == 0) return TRW_OK;
+    prof_mark(3, stream);  // (the profile's "finish" phase: everything after the walk kernel)
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "kernel launch");
+    return TRW_OK;
+}
+
 static int windows_check(const int64_t *walks, int64_t num_walks, int64_t walk_cols, int32_t window_size,
                          int64_t num_nodes, int64_t base, void *workspace, size_t workspace_bytes)
 {
@@ -1145,18 +1322,21 @@ int trw_to_windows_hip(const int64_t *walks, int64_t num_walks, int64_t walk_col
     prof_mark(0, stream);
     uint32_t *win = (uint32_t *)((char *)workspace + kStatusBytes);
     const int64_t nlanes = (draws + fill_run(draws) - 1) / fill_run(draws);
+    prof_mark(1, stream);
+    // two independent store streams, side by side: the negatives (the stream modulo num_nodes) on the side stream, the
+    // windows' own nodes on the caller's
+    SideStream *side = nullptr;
     if (draws > 0) {
+        hipStream_t ss = side_fork(stream, side);
         SeedWindow sw;
         trw::seed_window(seed, sw.w);
-        glibc_windows_kernel<<<(unsigned)((nlanes + kBlock - 1) / kBlock), kBlock, 0, stream>>>(
+        glibc_windows_kernel<<<(unsigned)((nlanes + kBlock - 1) / kBlock), kBlock, 0, ss>>>(
             sw, (uint64_t)walk_base * (uint64_t)step_end * (uint64_t)width, (uint64_t)fill_run(draws), nlanes, win);
-    }
-    prof_mark(1, stream);
-    windows_gather_kernel<<<stream_grid(total_windows), kBlock, 0, stream>>>(walks, num_walks, walk_cols, window_size,
-                                                                           target_nodes, pos_windows);
-    if (draws > 0)
-        glibc_fill_mod_kernel<false><<<(unsigned)((nlanes + kBlock - 1) / kBlock), kBlock, 0, stream>>>(
+        glibc_fill_mod_kernel<false><<<(unsigned)((nlanes + kBlock - 1) / kBlock), kBlock, 0, ss>>>(
             win, nlanes, draws, num_nodes, nullptr, neg_windows);
+    }
+    launch_windows_gather(walks, num_walks, walk_cols, window_size, target_nodes, pos_windows, stream);
+    side_join(stream, side);
     prof_mark(2, stream);
     prof_mark(3, stream);
     e = hipGetLastError();
@@ -1189,8 +1369,7 @@ int trw_to_windows_cbow_hip(const int64_t *walks, int64_t num_walks, int64_t wal
 
     prof_mark(0, stream);
     prof_mark(1, stream);
-    windows_gather_kernel<<<stream_grid(total_windows), kBlock, 0, stream>>>(walks, num_walks, walk_cols, window_size,
-                                                                           pos_nodes, windows);
+    launch_windows_gather(walks, num_walks, walk_cols, window_size, pos_nodes, windows, stream);
     if (mode == TRW_RNG_GLIBC) {
         SeedWindow sw;
         trw::seed_window(seed, sw.w);

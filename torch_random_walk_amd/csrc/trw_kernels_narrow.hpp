@@ -168,6 +168,82 @@ struct WaveRows {
     }
 };
 
+// The skip-gram windows of the wave's rows, straight from the tile (rw.walk_windows: the walk fused with
+// to_windows, windows_cpu.cpp:5-77, so that the [N, L+1] rows need not make the round trip through HBM).
+// Call right after flush() for the same column c: the windows that column c (and the columns since the previous
+// flush) completed -- at most 8 per row -- go out: centre[w] = middle node, pos[w][0..ws-2] = the others.  A row's
+// new windows are ONE contiguous piece of `pos` (up to 8 * (ws-1) values), written by `lpr` adjacent lanes.
+// The ring holds 16 columns and a window started up to ws + 6 columns ago: window_size <= 9.
+struct WaveWindows {
+    int32_t ws, mid, width, step_end;
+    uint32_t lpr_shift;   // lanes per row = 1 << lpr_shift >= 8 * width
+    uint32_t inv_width;   // ceil(65536 / width): f / width == (f * inv_width) >> 16 for f < 64
+    int64_t *centre, *pos;
+    __device__ __forceinline__ void init(int32_t window_size, int32_t cols, int64_t *centre_, int64_t *pos_)
+    {
+        ws = window_size;
+        mid = window_size / 2;
+        width = window_size - 1;
+        step_end = cols - window_size + 1;
+        lpr_shift = width <= 1 ? 3u : (width <= 2 ? 4u : (width <= 4 ? 5u : 6u));
+        inv_width = width > 0 ? (65536u + (uint32_t)width - 1u) / (uint32_t)width : 0u;
+        centre = centre_;
+        pos = pos_;
+    }
+    // the windows [w_lo, w_hi) that became complete with column c
+    __device__ __forceinline__ void range(int32_t cols, int32_t c, int32_t &w_lo, int32_t &w_hi) const
+    {
+        const bool last = c == cols - 1;
+        const int32_t c_prev = (last && (c & 7) != 7) ? (c & ~7) - 1 : c - 8;  // the flush before this one (< 0: none)
+        w_lo = c_prev - ws + 2;
+        w_lo = w_lo < 0 ? 0 : w_lo;
+        w_hi = c - ws + 2;
+        w_hi = w_hi < 0 ? 0 : w_hi;
+    }
+    __device__ __forceinline__ void flush(const WaveRows &rows, int64_t walker0, int32_t walker_stride, int64_t n_walkers,
+                                          int32_t cols, int32_t c) const
+    {
+        int32_t w_lo, w_hi;
+        range(cols, c, w_lo, w_hi);
+        const int32_t nwin = w_hi - w_lo;
+        if (nwin <= 0) return;
+        int64_t left = n_walkers - walker0;
+        left = left < 0 ? 0 : (left + walker_stride - 1) / walker_stride;
+        const int nrows = left > 64 ? 64 : (int)left;
+        int ln = rows.lane;
+        asm volatile("" : "+v"(ln));
+        const uint32_t row_windows = (uint32_t)walker_stride * (uint32_t)step_end;  // windows between the wave's rows
+        // ---- centres: 8 lanes per row, 8 rows per pass
+        int64_t *cbase = centre + walker0 * step_end + w_lo;
+        {
+            const int k = ln & 7;
+#pragma unroll 2
+            for (int pass = 0; pass < 8; ++pass) {
+                const int row = 8 * pass + (ln >> 3);
+                if (k < nwin && row < nrows) {
+                    const uint32_t v = rows.t[row * kTileStride + ((w_lo + k + mid) & (kTileCols - 1))];
+                    if (v != kTileSkip) cbase[(uint32_t)row * row_windows + (uint32_t)k] = (int64_t)v;
+                }
+            }
+        }
+        if (width == 0) return;
+        // ---- the rest of each window: a row's piece is nwin * width consecutive values
+        int64_t *pbase = pos + (walker0 * step_end + w_lo) * width;
+        const uint32_t lpr = 1u << lpr_shift, rows_per_pass = 64u >> lpr_shift;
+        const uint32_t f = (uint32_t)ln & (lpr - 1u), sub = (uint32_t)ln >> lpr_shift;
+        const uint32_t k = (f * inv_width) >> 16, i = f - k * (uint32_t)width;
+        const uint32_t col = (uint32_t)w_lo + k + i + (i >= (uint32_t)mid ? 1u : 0u);
+        const bool mine = f < (uint32_t)nwin * (uint32_t)width;
+        for (uint32_t pass = 0; pass < lpr; ++pass) {
+            const uint32_t row = pass * rows_per_pass + sub;
+            if (mine && row < (uint32_t)nrows) {
+                const uint32_t v = rows.t[row * kTileStride + (col & (kTileCols - 1))];
+                if (v != kTileSkip) pbase[row * row_windows * (uint32_t)width + f] = (int64_t)v;
+            }
+        }
+    }
+};
+
 // For kernels whose lanes advance at their own pace (the biased walks): the last (up to) four columns of
 // the lane's row wait in registers until they fill a 32-byte-aligned group of the caller's row, the
 // granule a partial HBM write costs anyway (one write request per four columns instead of one per column).
@@ -224,12 +300,14 @@ struct RowCombiner {
 // Register budget: the fat-entry walk is bound by the memory system's request rate and runs faster with 5
 // waves per SIMD than with 8 (measured 16.3 vs 17.3 ms on R-MAT 10M/110M, and no better with 2-4; the compact walk
 // does not care).
-template <bool kFat>
+// kWin: the fused walk + to_windows (WaveWindows above); `out` may then be null (the rows themselves are not wanted).
+template <bool kFat, bool kWin>
 __global__ void __launch_bounds__(kBlock, kFat ? 4 : 8)
 uniform_glibc_rows_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32,
                           const u32x4_a16 *__restrict__ ext, const int64_t *__restrict__ targets, int64_t n_nodes,
                           int64_t n_walkers, int32_t L, int32_t G, int64_t nlanes, const uint32_t *__restrict__ win,
-                          int64_t *__restrict__ out, int64_t *__restrict__ status)
+                          int64_t *__restrict__ out, int64_t *__restrict__ status, int32_t window_size,
+                          int64_t *__restrict__ centre, int64_t *__restrict__ pos)
 {
     __shared__ uint32_t tiles[(kBlock / 64) * 64 * kTileStride];
     const int64_t lane = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -239,6 +317,8 @@ uniform_glibc_rows_kernel(const uint32_t *__restrict__ row32, const uint32_t *__
     }
     const bool in_range = lane < nlanes;  // the whole wave stays: every lane helps writing the wave's rows
     WaveRows rows = {tiles + (threadIdx.x >> 6) * 64 * kTileStride, (int)(threadIdx.x & 63)};
+    WaveWindows wins;
+    if (kWin) wins.init(window_size, L + 1, centre, pos);
     // first walker of the wave's lane 0: wave-uniform, kept in scalar registers
     const int64_t wave_walker0 = ((int64_t)blockIdx.x * kBlock + (__builtin_amdgcn_readfirstlane(threadIdx.x) & ~63u)) * G;
 
@@ -262,7 +342,14 @@ uniform_glibc_rows_kernel(const uint32_t *__restrict__ row32, const uint32_t *__
                 if ((uint64_t)tg >= (uint64_t)n_nodes) {  // reported; the row is filled with the bad id
                     st |= TRW_ST_NODE_RANGE;
                     live = false;
-                    for (int32_t c = 0; c <= L; ++c) out[walker * (int64_t)(L + 1) + c] = tg;
+                    if (out)
+                        for (int32_t c = 0; c <= L; ++c) out[walker * (int64_t)(L + 1) + c] = tg;
+                    if (kWin) {  // ... and so are its windows
+                        for (int64_t k = walker * wins.step_end; k < (walker + 1) * wins.step_end; ++k) {
+                            centre[k] = tg;
+                            for (int32_t i = 0; i < wins.width; ++i) pos[k * wins.width + i] = tg;
+                        }
+                    }
                 }
                 cur = (uint32_t)tg;
                 if (kFat && live) load_row32(row32, cur, start, deg);  // the only row32 gather of the walk
@@ -284,7 +371,18 @@ uniform_glibc_rows_kernel(const uint32_t *__restrict__ row32, const uint32_t *__
             }
         }
         rows.put(s, live ? cur : kTileSkip);
-        if ((s & 7) == 7 || s == L) rows.flush(wave_walker0 + g, G, n_walkers, L + 1, s, out);
+        if ((s & 7) == 7 || s == L) {
+            if (!kWin || out) rows.flush(wave_walker0 + g, G, n_walkers, L + 1, s, out);
+            if (kWin) {
+                if (!out) {  // (flush() fences the tile on both sides; without it, do so here)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                wins.flush(rows, wave_walker0 + g, G, n_walkers, L + 1, s);
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
         if (++s > L) {
             s = 0;
             ++walker;
@@ -1658,8 +1756,10 @@ constexpr int kPoolWaves = kBlock / 64;
 #ifndef TRW_POOL_PRIO
 #define TRW_POOL_PRIO 1
 #endif
+// The burst's pairs as straight-line code (no "does any lane still run" vote between them): the loop's exits cost
+// about 40 scalar instructions per pair in lane-mask merges; 42.7 -> 41.8 ms.
 #ifndef TRW_POOL_UNROLL
-#define TRW_POOL_UNROLL 0
+#define TRW_POOL_UNROLL 1
 #endif
 #ifndef TRW_POOL_ISSUE_MIN
 #define TRW_POOL_ISSUE_MIN 48

@@ -14,21 +14,111 @@
 
 namespace {
 
+typedef int64_t i64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));  // two values, stored as one 16-byte piece
+
 // Draws per lane of glibc_fill_mod_kernel: a multiple of the generator order, 4 turns for small jobs and up
-// to 32 for large ones (every lane costs one jump-ahead, ~6 31x31 polynomial products; ~1M lanes fill the chip).
+// to 64 for large ones (every lane costs one jump-ahead, ~6 31x31 polynomial products; 2^18 lanes fill the chip
+// -- at 1 M lanes the jump-ahead pass was 135 us in front of a 730 us fill).
 __host__ __device__ inline int64_t fill_run(int64_t draws)
 {
-    int64_t turns = draws / ((int64_t)kGlDeg << 20);
-    turns = turns < 4 ? 4 : (turns > 32 ? 32 : turns);
+    int64_t turns = draws / ((int64_t)kGlDeg << 18);   // about 2^18 lanes: every lane costs one jump-ahead
+    turns = turns < 4 ? 4 : (turns > 64 ? 64 : turns);
+    turns += turns & 1;  // even: the fill leaves two turns of a lane (62 draws, 496 bytes) as one contiguous piece
     return turns * kGlDeg;
 }
 
+// n / d and n % d for n < 2^22 and one small d: one multiply by the rounded reciprocal, one correction.
+struct SmallDiv {
+    float rcp;
+    uint32_t d;
+    __device__ __forceinline__ void init(uint32_t den)
+    {
+        d = den;
+        rcp = 1.0f / (float)den;
+    }
+    __device__ __forceinline__ void divmod(uint32_t n, uint32_t &q, uint32_t &r) const
+    {
+        q = (uint32_t)((float)n * rcp);
+        r = n - q * d;
+        if ((int32_t)r < 0) {
+            --q;
+            r += d;
+        } else if (r >= d) {
+            ++q;
+            r -= d;
+        }
+    }
+};
+
 // centre[w] = middle node of window w; pos[w][*] = the window without its middle.
-// One thread per OUTPUT element, so that both outputs are written fully coalesced (512 bytes per wave
-// store); the walk entries are re-read ~window_size times each, from L1/L2.
+// A block owns `walks_per_block` whole walks: their rows come into LDS with one coalesced read, their windows are
+// one contiguous piece of both outputs, written 16 bytes per thread (two consecutive values) -- a write-only
+// stream reaches 6.9 TB/s on this part that way, 6.1 with 8 bytes per thread, and a grid of one trip per thread
+// runs a third faster than a persistent grid-stride one (scripts/machine_probe.hip).  All index arithmetic is
+// 32-bit with reciprocal multiplies (the round-1 form divided 64-bit indices twice per element).
+// (Host: walks_per_block * cols <= kWinTileWords, walks_per_block * step_end * width < 2^22.)
+constexpr int kWinTileWords = 4096;  // int64 walk entries a block keeps in LDS (32 KB)
+
 __global__ void __launch_bounds__(kBlock)
 windows_gather_kernel(const int64_t *__restrict__ walks, int64_t num_walks, int64_t cols, int32_t window_size,
-                      int64_t *__restrict__ centre, int64_t *__restrict__ pos)
+                      int32_t walks_per_block, int64_t *__restrict__ centre, int64_t *__restrict__ pos)
+{
+    __shared__ int64_t tile[kWinTileWords];
+    const uint32_t step_end = (uint32_t)(cols - window_size + 1);
+    const uint32_t mid = (uint32_t)window_size / 2u, width = (uint32_t)window_size - 1u;
+    const int64_t walk0 = (int64_t)blockIdx.x * walks_per_block;
+    const int64_t left = num_walks - walk0;
+    const uint32_t nw = left < walks_per_block ? (uint32_t)left : (uint32_t)walks_per_block;
+    const uint32_t n_in = nw * (uint32_t)cols;
+    const int64_t *src = walks + walk0 * cols;
+    for (uint32_t i = threadIdx.x; i < n_in; i += kBlock) tile[i] = src[i];
+    __syncthreads();
+    SmallDiv by_walk_c, by_walk_p, by_width;
+    by_walk_c.init(step_end);
+    // ---- centres: nw * step_end consecutive values
+    {
+        int64_t *dst = centre + walk0 * step_end;
+        const uint32_t n = nw * step_end;
+        for (uint32_t o = 2u * threadIdx.x; o < n; o += 2u * kBlock) {
+            int64_t v[2];
+#pragma unroll
+            for (uint32_t e = 0; e < 2u; ++e) {
+                uint32_t wl, st;
+                by_walk_c.divmod(o + e < n ? o + e : o, wl, st);
+                v[e] = tile[wl * (uint32_t)cols + st + mid];
+            }
+            if (o + 1u < n)
+                *reinterpret_cast<i64x2_a8 *>(dst + o) = i64x2_a8{v[0], v[1]};
+            else
+                dst[o] = v[0];
+        }
+    }
+    if (width == 0u) return;
+    // ---- the rest of each window: nw * step_end * width consecutive values
+    by_walk_p.init(step_end * width);
+    by_width.init(width);
+    int64_t *dst = pos + walk0 * step_end * width;
+    const uint32_t n = nw * step_end * width;
+    for (uint32_t o = 2u * threadIdx.x; o < n; o += 2u * kBlock) {
+        int64_t v[2];
+#pragma unroll
+        for (uint32_t e = 0; e < 2u; ++e) {
+            uint32_t wl, rem, st, i;
+            by_walk_p.divmod(o + e < n ? o + e : o, wl, rem);
+            by_width.divmod(rem, st, i);
+            v[e] = tile[wl * (uint32_t)cols + st + i + (i >= mid ? 1u : 0u)];
+        }
+        if (o + 1u < n)
+            *reinterpret_cast<i64x2_a8 *>(dst + o) = i64x2_a8{v[0], v[1]};
+        else
+            dst[o] = v[0];
+    }
+}
+
+// The same, one thread per output element over the caller's rows in place: walks too long for the tile above.
+__global__ void __launch_bounds__(kBlock)
+windows_gather_long_kernel(const int64_t *__restrict__ walks, int64_t num_walks, int64_t cols, int32_t window_size,
+                           int64_t *__restrict__ centre, int64_t *__restrict__ pos)
 {
     const int64_t step_end = cols - window_size + 1;
     const int64_t total = num_walks * step_end;
@@ -54,14 +144,15 @@ windows_gather_kernel(const int64_t *__restrict__ walks, int64_t num_walks, int6
 // With `rows` set, draw k selects a row of that [num_nodes][3] table instead and out[k][0..2] gets the row
 // (the negatives of to_windows_triples, windows_cpu.cpp:279-290).
 // A lane's draws are consecutive outputs, so lanes writing their own values would scatter 8-byte stores
-// 992 bytes apart: every turn of the generator (31 draws per lane) goes through a per-wave LDS tile
-// instead and leaves as 248-byte contiguous runs, two per wave store.
+// ~2 KB apart: two turns of the generator (62 draws per lane) go through a per-wave LDS tile instead and
+// leave as 496-byte contiguous pieces, two per wave store, 16 bytes per thread.
 template <bool kRows>
 __global__ void __launch_bounds__(kBlock)
 glibc_fill_mod_kernel(const uint32_t *__restrict__ win, int64_t nlanes, int64_t total, int64_t num_nodes,
                       const int64_t *__restrict__ rows, int64_t *__restrict__ out)
 {
-    constexpr int kStride = kGlDeg + 2;  // 33: odd, conflict-free lane-per-row writes
+    constexpr int kPiece = 2 * kGlDeg;   // draws of one lane per trip through the tile: two turns of the generator
+    constexpr int kStride = kPiece + 1;  // 63: odd, conflict-free lane-per-row writes
     __shared__ uint32_t tiles[(kBlock / 64) * 64 * kStride];
     uint32_t *t = tiles + (threadIdx.x >> 6) * 64 * kStride;
     const int ln = threadIdx.x & 63;
@@ -74,33 +165,49 @@ glibc_fill_mod_kernel(const uint32_t *__restrict__ win, int64_t nlanes, int64_t 
     const bool small = num_nodes < ((int64_t)1 << 32);
     FastMod fm;
     fm.init(small ? (uint32_t)num_nodes : 1u);
-    const int64_t run = fill_run(total);
-    for (int rep = 0; rep < (int)(run / kGlDeg); ++rep) {
+    const int64_t run = fill_run(total);  // (an even number of turns)
+    for (int rep = 0; rep < (int)(run / kPiece); ++rep) {
 #pragma unroll
-        for (int j = 0; j < kGlDeg; ++j) {
-            const uint32_t v = w[j] + w[(j + kGlDeg - kGlSep) % kGlDeg];
-            w[j] = v;
-            const uint32_t r = v >> 1;
-            t[ln * kStride + j] = small ? fm.mod(r) : r;  // r < 2^31 <= num_nodes otherwise
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int j = 0; j < kGlDeg; ++j) {
+                const uint32_t v = w[j] + w[(j + kGlDeg - kGlSep) % kGlDeg];
+                w[j] = v;
+                const uint32_t r = v >> 1;
+                t[ln * kStride + half * kGlDeg + j] = small ? fm.mod(r) : r;  // r < 2^31 <= num_nodes otherwise
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // half a wave per producing lane: 31 of its 32 threads carry one draw each
-        const int j = ln & 31;
+        if (kRows) {
+            // half a wave per producing lane and turn: 31 of its 32 threads carry one draw (a 24-byte row) each
+            const int j = ln & 31;
 #pragma unroll 4
-        for (int pass = 0; pass < 32; ++pass) {
-            const int src = 2 * pass + (ln >> 5);
-            const int64_t k = (wave_lane0 + src) * run + rep * kGlDeg + j;
-            if (j < kGlDeg && k < total) {
-                const int64_t idx = (int64_t)t[src * kStride + j];
-                if (kRows) {
-                    const int64_t *row = rows + idx * 3;
+            for (int pass = 0; pass < 64; ++pass) {
+                const int src = pass & 63, half = ln >> 5;
+                const int64_t k = (wave_lane0 + src) * run + (int64_t)rep * kPiece + half * kGlDeg + j;
+                if (j < kGlDeg && k < total) {
+                    const int64_t *row = rows + (int64_t)t[src * kStride + half * kGlDeg + j] * 3;
                     int64_t *dst = out + k * 3;
                     dst[0] = row[0];
                     dst[1] = row[1];
                     dst[2] = row[2];
-                } else {
-                    out[k] = idx;
+                }
+            }
+        } else {
+            // half a wave per producing lane: 31 of its 32 threads carry two draws, 16 bytes, each -- the lane's 496
+            // bytes leave as one contiguous piece (8-byte aligned: the store is split by the hardware where it must)
+            const int j2 = 2 * (ln & 31);
+#pragma unroll 4
+            for (int pass = 0; pass < 32; ++pass) {
+                const int src = 2 * pass + (ln >> 5);
+                const int64_t k = (wave_lane0 + src) * run + (int64_t)rep * kPiece + j2;
+                if (j2 < kPiece && k < total) {
+                    const int64_t a = (int64_t)t[src * kStride + j2], b = (int64_t)t[src * kStride + j2 + 1];
+                    if (k + 1 < total)
+                        *reinterpret_cast<i64x2_a8 *>(out + k) = i64x2_a8{a, b};
+                    else
+                        out[k] = a;
                 }
             }
         }
@@ -108,29 +215,6 @@ glibc_fill_mod_kernel(const uint32_t *__restrict__ win, int64_t nlanes, int64_t 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
-
-// n / d and n % d for n < 2^22 and one small d: one multiply by the rounded reciprocal, one correction.
-struct SmallDiv {
-    float rcp;
-    uint32_t d;
-    __device__ __forceinline__ void init(uint32_t den)
-    {
-        d = den;
-        rcp = 1.0f / (float)den;
-    }
-    __device__ __forceinline__ void divmod(uint32_t n, uint32_t &q, uint32_t &r) const
-    {
-        q = (uint32_t)((float)n * rcp);
-        r = n - q * d;
-        if ((int32_t)r < 0) {
-            --q;
-            r += d;
-        } else if (r >= d) {
-            ++q;
-            r -= d;
-        }
-    }
-};
 
 // Triples windows (windows_cpu.cpp:160-474): the target triple and the 2*window_size positive rows around
 // it, with the reference's off-by-one left half and its walk[rel] in the head slot of left rows kept as

@@ -181,6 +181,23 @@ def to_windows(walks, window_size, num_nodes, seed):
     return torch_rw_native.to_windows(walks, window_size, num_nodes, seed)
 
 
+def walk_windows(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, window_size, num_nodes, window_seed=None,
+                 walker_base=0, return_walks=False, check=None):
+    """``to_windows(walk(...), window_size, num_nodes, seed)`` as one call (torch_rw/rw.py:3-4 then :29-30).
+
+    Returns ``(target_nodes, pos_windows, neg_windows)`` -- plus the ``[N, walk_length+1]`` walks as a fourth item
+    with ``return_walks=True`` -- bit for bit what the two calls give (``window_seed``: the seed of the negatives,
+    default ``seed`` as in the usual two-call use; ``walker_base``: global index of ``target_nodes[0]``, numbers both
+    the walkers and their windows for a shard).  For the reference-exact uniform walk (``p == q == 1``) on the GPU the
+    walk kernel writes the windows straight from its on-chip tile: the walks never travel to HBM and back (no
+    reference counterpart; csrc/cpu/windows_cpu.cpp:5-77 consumes the [N, L+1] tensor).  node2vec walks, CPU
+    tensors and ``window_size > 9`` run as the two calls."""
+    out = torch_rw_native.walk_windows(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, window_size, num_nodes,
+                                       seed if window_seed is None else window_seed, walker_base, return_walks,
+                                       _check_code(check))
+    return out if return_walks else out[:3]
+
+
 def to_windows_cbow(walks, window_size, num_nodes, seed):
     """CBOW windows: ``(pos_nodes [W], neg_nodes [W], windows [W, ws-1])``; the negative is redrawn while it
     equals the positive node.  Same surface as the reference (torch_rw/rw.py:32-33)."""
