@@ -151,16 +151,26 @@ struct EdgeListView {
 };
 
 // The walker's own draw stream: draw k is the k-th draw it actually consumes.
+// (The block's words are four named registers, not an array: indexed by d & 3 an array is turned into a lookup
+// in scratch memory -- 40 bytes per lane and a scratch_load per draw in three instantiations of elist_walk_kernel.)
 struct WalkerDraws {
     uint64_t gw;
     uint32_t seed, d;
-    uint32_t blk[4];
+    uint32_t b0, b1, b2, b3;
     __device__ __forceinline__ uint32_t next()
     {
-        if ((d & 3u) == 0) walker_block(gw, d >> 2, seed, blk);
+        if ((d & 3u) == 0) {
+            uint32_t blk[4];
+            walker_block(gw, d >> 2, seed, blk);
+            b0 = blk[0];
+            b1 = blk[1];
+            b2 = blk[2];
+            b3 = blk[3];
+        }
         const uint32_t k = d & 3u;
         ++d;
-        return (k == 0 ? blk[0] : k == 1 ? blk[1] : k == 2 ? blk[2] : blk[3]) >> 1;
+        const uint32_t lo = (k & 1u) ? b1 : b0, hi = (k & 1u) ? b3 : b2;
+        return ((k & 2u) ? hi : lo) >> 1;
     }
 };
 
@@ -215,6 +225,7 @@ elist_walk_kernel(EdgeListView<kNarrow> g, const int64_t *__restrict__ targets, 
     rng.gw = (uint64_t)walker_base + (uint64_t)i;
     rng.seed = seed;
     rng.d = 0;
+    rng.b0 = rng.b1 = rng.b2 = rng.b3 = 0u;
 
     // the (first, last) edge range of a node the way the reference's accessors would see it; a walker
     // standing on the padding id has a range only if the padding id is itself a row of the index

@@ -302,7 +302,7 @@ struct RowCombiner {
 // does not care).
 // kWin: the fused walk + to_windows (WaveWindows above); `out` may then be null (the rows themselves are not wanted).
 template <bool kFat, bool kWin>
-__global__ void __launch_bounds__(kBlock, kFat ? 4 : 8)
+__global__ void __launch_bounds__(kBlock, (kFat || kWin) ? 4 : 8)
 uniform_glibc_rows_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32,
                           const u32x4_a16 *__restrict__ ext, const int64_t *__restrict__ targets, int64_t n_nodes,
                           int64_t n_walkers, int32_t L, int32_t G, int64_t nlanes, const uint32_t *__restrict__ win,
@@ -2298,15 +2298,29 @@ biased_glibc_wave_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__
     if (lane < kGlDeg) R[(uint32_t)(kGlRing - kGlDeg + lane) & M] = sw.w[lane];  // calls -31 .. -1
     pool_fence();
     uint64_t pos = 0, gen = 0;  // next draw to consume / to generate (wave-uniform)
+    // The generator, 31 words per turn: r[k] = r[k-3] + r[k-31] makes the new words three running sums (one per residue
+    // of k mod 3) over the 31 words before them,
+    //     r[n+j] = r[n + j%3 - 3] + sum of r[n + i - 31] over i = j, j-3, j-6, ... >= 0,
+    // i.e. a strided prefix sum across 31 lanes (four shuffle-and-add steps: strides 3, 6, 12, 24) instead of eleven
+    // dependent trips through LDS three words at a time -- 10 cycles a word instead of 40, and off the critical path:
+    // the loop below runs it while the step's entry is on its way from memory.
     auto need = [&](uint64_t upto) {
         while (gen < upto) {
-            if (lane < kGlSep) {
-                const uint32_t i = (uint32_t)gen + (uint32_t)lane;
-                R[i & M] = R[(i - kGlDeg) & M] + R[(i - kGlSep) & M];
+            const uint32_t n = (uint32_t)gen, j = (uint32_t)lane;
+            uint32_t x = 0u, base = 0u;
+            if (j < (uint32_t)kGlDeg) {
+                x = R[(n + j - (uint32_t)kGlDeg) & M];
+                base = R[(n + j % 3u - 3u) & M];
             }
-            gen += kGlSep;
+#pragma unroll
+            for (int d = kGlSep; d < kGlDeg; d *= 2) {
+                const uint32_t y = (uint32_t)__shfl_up((int)x, d);
+                if (j >= (uint32_t)d) x += y;
+            }
+            if (j < (uint32_t)kGlDeg) R[(n + j) & M] = x + base;
+            gen += kGlDeg;
+            pool_fence();
         }
-        pool_fence();
     };
     auto draw = [&](uint64_t at) { return R[(uint32_t)at & M] >> 1; };
     const bool band_takes_near = bp.t1 > bp.t2;
@@ -2326,9 +2340,8 @@ biased_glibc_wave_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__
         uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
         bool exact = false;
         FastMod fm;
-        // every lane loads the SAME entry (one request) and steps the replicated state
-        auto step_onto = [&](uint32_t entry, int32_t s) {
-            const u32x4_a16 e0 = ext[2 * (size_t)entry], e1 = ext[2 * (size_t)entry + 1];
+        // the replicated state of the step onto entry {e0, e1} (the same values in every lane)
+        auto step_from = [&](const u32x4_a16 &e0, const u32x4_a16 &e1, int32_t s) {
             if (lane == 0) row[s] = (int64_t)e0.x;
             t = prev;
             prev = e0.x;
@@ -2342,7 +2355,7 @@ biased_glibc_wave_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__
             pos_lo = e0.w & 0x0FFFFFFFu;
             pos_cnt = e0.w >> 28;
             if (p_deg == 0) return;
-            fm.init(p_deg);
+            fm.init_exact(p_deg);
             if (e0.w == kRposLookup) {  // where t sits in prev's row: ask the table
                 uint32_t lo = 0, cnt = 0;
                 const bool found = edge_table_find(table, mask, prev, t, lo, cnt);
@@ -2361,18 +2374,30 @@ biased_glibc_wave_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__
             need(pos + 1);
             const uint32_t r0 = draw(pos);
             pos += 1;
-            step_onto(start + r0 % deg, 1);
+            const uint32_t entry = start + r0 % deg;
+            const u32x4_a16 e0 = ext[2 * (size_t)entry], e1 = ext[2 * (size_t)entry + 1];
+            need(pos + 320);  // (while the entry is on its way)
+            step_from(e0, e1, 1);
         }
         for (int32_t s = 2; s <= L && !st; ++s) {
             if (p_deg == 0) {
                 st |= TRW_ST_DEGREE0;
                 break;
             }
-            uint32_t rejected = 0, take = 0;
+            uint32_t rejected = 0;
+            u32x4_a16 c0, c1;
+            int f = 0;
             while (true) {  // 64 trials at a time
-                need(pos + 128);
+                need(pos + 128);  // (generated ahead of time, below: nothing to do here but for the first round)
                 const uint32_t rc = draw(pos + 2 * (uint64_t)lane), ru = draw(pos + 2 * (uint64_t)lane + 1);
-                const uint32_t idx = fm.mod(rc);
+                const uint32_t idx = fm.mod31(rc);
+                // Every lane fetches the entry of ITS candidate at once: the winner's entry is then in registers when
+                // the verdicts are in (the gather overlaps their evaluation instead of following it), a candidate the
+                // masks cannot decide has its node for the table, and the draws of the next round are generated while
+                // all of that is on its way.  64 gathers for one step: a single wave has the memory system to itself.
+                c0 = ext[2 * (size_t)(p_start + idx)];
+                c1 = ext[2 * (size_t)(p_start + idx) + 1];
+                need(pos + 128 + 192);
                 const uint32_t k = (idx >> 5) & 3u;
                 const uint32_t word = k == 0u ? m0 : (k == 1u ? m1 : (k == 2u ? m2 : m3));
                 const bool bit = (word >> (idx & 31u)) & 1u;
@@ -2387,16 +2412,14 @@ biased_glibc_wave_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__
                     if (pend == 0) break;
                     bool ok = false;
                     if ((pend >> lane) & 1ull) {
-                        const uint32_t x = ext[2 * (size_t)(p_start + idx)].x;
                         uint32_t lo, cnt;
-                        ok = edge_table_find(table, mask, t, x, lo, cnt) == band_takes_near;
+                        ok = edge_table_find(table, mask, t, c0.x, lo, cnt) == band_takes_near;
                     }
                     accepts |= __ballot(ok);
                     tests &= ~pend;
                 }
                 if (accepts) {
-                    const int f = (int)__ffsll((long long)accepts) - 1;
-                    take = p_start + (uint32_t)__shfl((int)idx, f);
+                    f = (int)__ffsll((long long)accepts) - 1;
                     pos += 2 * (uint64_t)(f + 1);
                     break;
                 }
@@ -2404,11 +2427,21 @@ biased_glibc_wave_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__
                 rejected += 64;
                 if (rejected >= kTrialCap) {
                     st |= (uint32_t)kStTrialCap;
-                    take = p_start + (uint32_t)__shfl((int)idx, 63);
+                    f = 63;
                     break;
                 }
             }
-            step_onto(take, s);
+            // the winning lane's entry, to every lane
+            u32x4_a16 e0, e1;
+            e0.x = (uint32_t)__shfl((int)c0.x, f);
+            e0.y = (uint32_t)__shfl((int)c0.y, f);
+            e0.z = (uint32_t)__shfl((int)c0.z, f);
+            e0.w = (uint32_t)__shfl((int)c0.w, f);
+            e1.x = (uint32_t)__shfl((int)c1.x, f);
+            e1.y = (uint32_t)__shfl((int)c1.y, f);
+            e1.z = (uint32_t)__shfl((int)c1.z, f);
+            e1.w = (uint32_t)__shfl((int)c1.w, f);
+            step_from(e0, e1, s);
         }
     }
     if (st && lane == 0) atomicOr((unsigned long long *)&status[0], (unsigned long long)st);
