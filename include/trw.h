@@ -75,7 +75,8 @@ extern "C" {
 #define TRW_ST_DEGREE0    1    /* a walker stood on a node with no out-edges (the
                                   reference divides by zero there, rw_cpu.cpp:20)  */
 #define TRW_ST_NODE_RANGE 2    /* a start node or a col_idx entry outside [0,n)    */
-#define TRW_ST_BAD_CSR    4    /* row_ptr not monotone within [0, nnz]             */
+#define TRW_ST_BAD_CSR    4    /* row_ptr not monotone within [0, nnz] (or, graphs
+                                  on the uint32 layout: one row of >= 2^31 entries) */
 #define TRW_ST_TRIAL_CAP  8    /* 2^20 consecutive rejections at one step; the
                                   candidate was force-accepted (the reference
                                   would still be spinning, rw_cpu.cpp:166)         */

@@ -26,7 +26,8 @@ DOMINANT = {"elist_rmat1m_biased": ("elist_pool_kernel", "elist_walk_kernel"), "
             "rmat10m_uniform": ("uniform_glibc_rows_kernel", "uniform_glibc_ext_kernel", "uniform_glibc_kernel"),
             "er100k_uniform": ("uniform_glibc_rows_kernel", "uniform_glibc_kernel", "uniform_glibc_ext_kernel"),
             "kg5m_triples": ("triples_walker_kernel",), 
-            "elist_rmat1m_uniform": ("elist_walk_kernel",), "windows_1m": ("glibc_fill_mod_kernel",)}
+            "elist_rmat1m_uniform": ("elist_walk_kernel",), "windows_1m": ("glibc_fill_mod_kernel",),
+            "walk_windows_1m": ("uniform_glibc_rows_kernel",)}
 
 
 def sources_sha():

@@ -2,8 +2,11 @@
 # Runs ON THE GPU BOX: rocprofv3 stats + PMC passes for every bench workload, condensed into
 # gpurun_out/collected/ (the raw traces are too big to travel back), then the bench lines themselves with CPU
 # baselines.  Afterwards, here: cp gpurun_out/collected/* profiles/
-TAG=${1:-r02}
-WLS=${2:-"rmat10m_biased rmat10m_uniform er100k_uniform kg5m_triples elist_rmat1m_uniform elist_rmat1m_biased windows_1m"}
+# usage: scripts/regen_all.sh [tag] ["workloads to profile" (may be "")] [profiles-only]   (a gpurun call lasts 20 minutes
+# at most: profile the workloads in two or three calls with `profiles-only`, copying pmc_traffic.json into profiles/
+# between them, then run the bench lines and probes with an empty workload list)
+TAG=${1:-r03}
+WLS=${2:-"rmat10m_biased rmat10m_uniform er100k_uniform kg5m_triples elist_rmat1m_uniform elist_rmat1m_biased windows_1m walk_windows_1m"}
 mkdir -p gpurun_out/collected
 for w in $WLS; do
   bash scripts/profile_gpu.sh $w $TAG > gpurun_out/collected/prof_log_$w.txt 2>&1
@@ -12,10 +15,17 @@ for w in $WLS; do
   echo "profiled $w"
 done
 cp gpurun_out/collected/pmc_traffic.json profiles/pmc_traffic.json   # bench.py reads traffic / misses from here
-for w in default rmat10m_uniform er100k_uniform papers100m_uniform papers100m_biased kg5m_triples elist_rmat1m_uniform elist_rmat1m_biased windows_1m; do
+if [ "${3:-}" = "profiles-only" ]; then du -sh gpurun_out; exit 0; fi
+for w in default rmat10m_uniform er100k_uniform papers100m_uniform papers100m_biased kg5m_triples elist_rmat1m_uniform elist_rmat1m_biased windows_1m walk_windows_1m; do
   if [ $w = default ]; then ARG=""; else ARG="--workload $w"; fi
   timeout -k 10 300 python3 bench.py $ARG > gpurun_out/collected/${TAG}_bench_$w.json 2> gpurun_out/collected/bench_$w.err || echo "bench $w failed"
   echo "bench $w done"
 done
 rm -f gpurun_out/collected/prof_log_*.txt
+# the machine's yardsticks and the side measurements DESIGN.md quotes
+hipcc --offload-arch=gfx950 -O3 -o /tmp/machine_probe scripts/machine_probe.hip && timeout -k 5 300 /tmp/machine_probe 4096 > gpurun_out/collected/${TAG}_machine_probe.txt 2>&1
+hipcc --offload-arch=gfx950 -O3 -o /tmp/alu_probe2 scripts/alu_probe2.hip && timeout -k 5 300 /tmp/alu_probe2 > gpurun_out/collected/${TAG}_alu_probe2.txt 2>&1
+timeout -k 10 300 python3 scripts/time_small_batch.py 2>&1 | grep -v amdgpu.ids > gpurun_out/collected/${TAG}_small_batches.txt
+timeout -k 10 300 python3 scripts/time_windows.py 2>&1 | grep -v amdgpu.ids > gpurun_out/collected/${TAG}_time_windows.txt
+timeout -k 10 300 python3 scripts/tune_biased.py --what 14 --runs 5 --count 2>&1 | grep -v amdgpu.ids > gpurun_out/collected/${TAG}_pool_phases.txt
 du -sh gpurun_out

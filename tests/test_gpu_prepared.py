@@ -351,3 +351,51 @@ def test_prepared_edge_list_is_cached_per_padding_id_and_invalidated_by_writes(r
     both(n)
     u = rw.walk_edge_list_ex(d_e, d_i, d_t, 1.0, 1.0, 25, 5, n, rng_mode=rw.RNG_WALKER).cpu().numpy()
     assert (u == O.walk_edge_list(d_e.cpu().numpy(), d_i.cpu().numpy(), tg, 1.0, 1.0, 25, 5, n, rng_mode=O.RNG_WALKER)).all()
+
+
+def test_a_rewritten_graph_leaves_no_stale_entry_behind(rw):
+    """an entry whose tensors are alive but were written in place can never match again -- it is dropped
+    when the same tensors come back (pinned or not), not kept beside its successor until LRU gets to it."""
+    rp, ci = hub_graph(2000, 5)
+    rp2, ci2 = random_graph(2000, 4, 5)   # same entry count (5 per node), other edges
+    assert len(ci2) == len(ci)
+    tg = np.arange(2000)
+    d_rp, d_ci, d_tg = _dev(rp, ci, tg)
+    rw.walk(d_rp, d_ci, d_tg, 0.25, 4.0, 20, 3)
+    assert len(rw.cache_info()) == 1
+    d_rp.copy_(torch.as_tensor(rp2))
+    d_ci.copy_(torch.as_tensor(ci2))
+    got = rw.walk(d_rp, d_ci, d_tg, 0.25, 4.0, 20, 3)
+    assert len(rw.cache_info()) == 1
+    assert (got.cpu().numpy() == O.walk(rp2, ci2, tg, 0.25, 4.0, 20, 3, rng_mode=O.RNG_WALKER)).all()
+    # prepare() -> write -> prepare(): the pinned stale blob goes too
+    rw.prepare(d_rp, d_ci, marks=True)
+    assert len(rw.cache_info()) == 1
+    d_ci.copy_(torch.as_tensor(ci2))          # (same values: the version counter moves all the same)
+    rw.prepare(d_rp, d_ci, marks=True)
+    assert len(rw.cache_info()) == 1
+    # a write torch cannot see (through .data) leaves the entry in place: rw.invalidate() is the way to say so
+    d_ci.data.copy_(torch.as_tensor(ci))
+    d_rp.data.copy_(torch.as_tensor(rp))
+    assert rw.invalidate(d_rp, d_ci) == 1 and rw.cache_info() == []
+    got = rw.walk(d_rp, d_ci, d_tg, 0.25, 4.0, 20, 3)
+    assert (got.cpu().numpy() == O.walk(rp, ci, tg, 0.25, 4.0, 20, 3, rng_mode=O.RNG_WALKER)).all()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs in one process")
+def test_two_devices_in_one_process(rw):
+    """One process, two cards: each device keeps its own prepared graphs (capacity counts per device) and the deferred
+    status read-back of a call on cuda:1 uses an event of cuda:1 (the slots were shared across devices)."""
+    rp, ci = hub_graph(2000, 5)
+    tg = np.arange(2000)
+    ref = O.walk(rp, ci, tg, 0.25, 4.0, 20, 3, rng_mode=O.RNG_WALKER)
+    graphs = []
+    for dev in ("cuda:0", "cuda:1"):
+        for k in range(2):
+            t = [torch.as_tensor(np.asarray(a), dtype=torch.int64).to(dev) for a in (rp, ci, tg)]
+            graphs.append(t)
+            for _ in range(3):                       # deferred checks: slots freed on one device, reused on the other
+                got = rw.walk(t[0], t[1], t[2], 0.25, 4.0, 20, 3)
+            assert (got.cpu().numpy() == ref).all()
+    assert len(rw.cache_info()) == 4                 # two graphs on each of the two devices
+    rw.check_status(wait=True)

@@ -995,6 +995,21 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("_cache_victims", &cache_victims,
           "the prepared-graph cache's eviction rule (positions to drop; capacity counts per device)",
           pybind11::arg("device_of"), pybind11::arg("pinned"), pybind11::arg("capacity"));
+    m.def("invalidate", [](const torch::Tensor &a, const torch::Tensor &b) {
+        // Drop what is cached for these tensors' memory, whatever their version counters say: for writes torch cannot
+        // see (through `.data`, DLPack, another extension's kernels), which leave the counters where they were.
+        std::lock_guard<std::mutex> lock(g_cache_mu);
+        int64_t dropped = 0;
+        for (auto it = g_cache.begin(); it != g_cache.end();) {
+            if (a.has_storage() && b.has_storage() && entry_same_memory(**it, a, b, (*it)->kind, (*it)->pad)) {
+                it = g_cache.erase(it);
+                ++dropped;
+            } else {
+                ++it;
+            }
+        }
+        return dropped;
+    }, "forget the prepared graph cached for (row_ptr, col_idx) / (edge_list_indexed, node_edge_index)");
     m.def("clear_cache", []() {
         std::lock_guard<std::mutex> lock(g_cache_mu);
         g_cache.clear();

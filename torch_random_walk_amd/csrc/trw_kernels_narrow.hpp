@@ -56,6 +56,9 @@ csr_shadow_kernel(const int64_t *__restrict__ row_ptr, const int64_t *__restrict
         int64_t r = row_ptr[v];
         bool bad = r < 0 || r > nnz;
         if (v < n_nodes && row_ptr[v + 1] < r) bad = true;
+        // a single row of 2^31 entries or more (17 GB of parallel edges) would alias the flag bit the 32-byte entries
+        // keep in the top of their degree word (kMaskIsFilter): outside what the uint32 layout describes, reported
+        if (v < n_nodes && row_ptr[v + 1] - r >= ((int64_t)1 << 31)) bad = true;
         if (bad) st |= TRW_ST_BAD_CSR;
         r = r < 0 ? 0 : (r > nnz ? nnz : r);
         row32[v] = (uint32_t)r;

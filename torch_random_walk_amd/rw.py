@@ -96,6 +96,14 @@ def set_cache(on=True, capacity=0):
     torch_rw_native.set_cache(bool(on), int(capacity))
 
 
+def invalidate(row_ptr, col_idx):
+    """Forget what is cached for these two tensors (``(edge_list_indexed, node_edge_index)`` for the edge-list walk).
+    The cache notices in-place writes through the tensors' version counters; a write torch cannot see -- through
+    ``tensor.data``, DLPack / cupy views, another extension's kernels -- leaves them unchanged: call this after such a
+    write (the reference re-reads the CSR on every call and needs nothing of the kind).  Returns the entries dropped."""
+    return torch_rw_native.invalidate(row_ptr, col_idx)
+
+
 def clear_cache():
     """Drop every cached prepared graph (their device memory goes back to the allocator)."""
     torch_rw_native.clear_cache()
@@ -137,6 +145,25 @@ def check_status(wait=True):
     """Raise ``RuntimeError`` for device-side faults of earlier deferred-check calls.  ``wait=True``
     first waits for every outstanding read-back; returns the number still in flight otherwise."""
     return torch_rw_native.check_status(wait)
+
+
+def _report_pending_at_exit():
+    """A deferred check nobody collected: the fault of a script's LAST torch_rw call (or of one in front of a long
+    stretch without torch_rw calls) would otherwise never surface.  Non-blocking: only read-backs that
+    have landed are looked at; the interpreter is going down, so a warning instead of an exception."""
+    try:
+        torch_rw_native.check_status(False)
+    except RuntimeError as e:
+        import warnings
+        warnings.warn("torch_rw: a GPU call made under the deferred status check reported a data fault that no "
+                      "later call raised: %s" % e, RuntimeWarning)
+    except Exception:  # noqa: BLE001 -- never stand in the way of interpreter shutdown
+        pass
+
+
+import atexit as _atexit  # noqa: E402
+
+_atexit.register(_report_pending_at_exit)
 
 
 def walk_triples(triples_indexed, relation_tail_index, target_nodes, walk_length, padding_idx, seed, restart=True):
