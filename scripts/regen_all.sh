@@ -16,12 +16,13 @@ for w in $WLS; do
 done
 cp gpurun_out/collected/pmc_traffic.json profiles/pmc_traffic.json   # bench.py reads traffic / misses from here
 if [ "${3:-}" = "profiles-only" ]; then du -sh gpurun_out; exit 0; fi
-for w in default rmat10m_uniform er100k_uniform papers100m_uniform papers100m_biased kg5m_triples elist_rmat1m_uniform elist_rmat1m_biased windows_1m walk_windows_1m; do
+for w in ${BENCH_WLS:-default rmat10m_uniform er100k_uniform papers100m_uniform papers100m_biased kg5m_triples elist_rmat1m_uniform elist_rmat1m_biased windows_1m walk_windows_1m}; do
   if [ $w = default ]; then ARG=""; else ARG="--workload $w"; fi
   timeout -k 10 300 python3 bench.py $ARG > gpurun_out/collected/${TAG}_bench_$w.json 2> gpurun_out/collected/bench_$w.err || echo "bench $w failed"
   echo "bench $w done"
 done
 rm -f gpurun_out/collected/prof_log_*.txt
+if [ "${3:-}" = "bench-only" ]; then du -sh gpurun_out; exit 0; fi
 # the machine's yardsticks and the side measurements DESIGN.md quotes
 hipcc --offload-arch=gfx950 -O3 -o /tmp/machine_probe scripts/machine_probe.hip && timeout -k 5 300 /tmp/machine_probe 4096 > gpurun_out/collected/${TAG}_machine_probe.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 -o /tmp/alu_probe2 scripts/alu_probe2.hip && timeout -k 5 300 /tmp/alu_probe2 > gpurun_out/collected/${TAG}_alu_probe2.txt 2>&1

@@ -89,11 +89,21 @@ def walk_sharded(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, group=
     def walk_into(dst, c_lo, c_hi):
         """rows [c_lo, c_hi) of the batch, walked into `dst` (a [c_hi-c_lo, cols] slice of a result tensor)"""
         if walk_fn is None:
+            # (deferred status check: nothing holds the host back between a chunk's walk and its transfer; the
+            # read-backs are collected -- and a data fault raised, on the rank whose block is faulty -- before this
+            # function returns, see `settle` below)
             rw.walk_ex(row_ptr, col_idx, target_nodes[c_lo:c_hi], p, q, walk_length, seed, walker_base=c_lo,
-                       rng_mode=rng_mode, out=dst)
+                       rng_mode=rng_mode, check="deferred", out=dst)
         else:
             dst.copy_(walk_fn(row_ptr, col_idx, target_nodes[c_lo:c_hi], p, q, walk_length, seed, walker_base=c_lo,
                               rng_mode=rng_mode))
+
+    def settle(result):
+        """A block with a data fault (degree-0 node, id out of range) must not pass for a result: every rank waits for
+        the status read-backs of its own walks and raises if one of them reported."""
+        if walk_fn is None and target_nodes.is_cuda:
+            rw.check_status(wait=True)
+        return result
 
     def to_wire(rows):
         """what travels for a block of rows: the rows themselves, or their uint32 form; on the host under gloo"""
@@ -112,7 +122,7 @@ def walk_sharded(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, group=
     if not root_gather:
         walk_into(mine, lo, hi)
         if world == 1 or gather == "none":
-            return mine
+            return settle(mine)
         # gather == "all": equal-sized pieces for the collective; the pad rows are dropped below
         w = to_wire(mine)
         if hi - lo < block:
@@ -124,7 +134,7 @@ def walk_sharded(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, group=
         got = got[:n]
         if staged:
             got = got.to(dev)
-        return rw.widen_rows(got.contiguous()) if narrow else got
+        return settle(rw.widen_rows(got.contiguous()) if narrow else got)
 
     # gather == "root": a gather on xGMI is world-1 independent peer -> root transfers; issued as groups of
     # point-to-point operations they land directly in the root's buffers, chunk by chunk
@@ -141,7 +151,7 @@ def walk_sharded(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, group=
             works += dist.batch_isend_irecv([dist.P2POp(dist.isend, w, dst, group)])
         for w in works:
             w.wait()
-        return mine
+        return settle(mine)
 
     wire_dtype = torch.int32 if narrow else torch.int64
     land = None
@@ -175,4 +185,4 @@ def walk_sharded(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, group=
                 rw.widen_rows(got, out=full[c_lo:c_hi])
             else:
                 full[c_lo:c_hi].copy_(got)
-    return full[:n]
+    return settle(full[:n])
