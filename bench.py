@@ -760,6 +760,20 @@ def main():
                 note="SURVEY 8(d) formula with the reference's access pattern; NOT used for roofline.achieved, "
                      "which counts only what this kernel's algorithm has to read")
 
+    # What the prepared graph costs a caller who does not walk it for ever: after how many epochs
+    # the one-off full prepare has paid for itself against walking over what the first call builds by itself, and the
+    # rate over 10 epochs with the prepare call inside.
+    amortised = None
+    if cold and all(k in cold for k in ("first_call_prepare_ms", "first_call_walk_kernel_ms", "prepare_call_ms")):
+        steady = elapsed / args.steps * 1e3
+        gain = cold["first_call_walk_kernel_ms"] - steady
+        extra = cold["prepare_call_ms"] - cold["first_call_prepare_ms"]
+        amortised = dict(
+            epochs_to_break_even=(extra / gain) if gain > 0 else None,
+            value_incl_prepare_at_10_epochs=10 * world * B * L / ((cold["prepare_call_ms"] + 10 * steady) * 1e-3),
+            value_one_shot_call=world * B * L / (cold["first_call_ms"] * 1e-3),
+            note="break-even: (full prepare - the first call's own prepare) / (first call's walk - steady-state step); "
+                 "one_shot = a single call over a graph nobody prepared, everything included")
     if rank == 0:
         total_steps = world * B * L * args.steps
         line = {
@@ -809,6 +823,7 @@ def main():
                 "finish_ms": sum(finish_ms) / max(1, len(finish_ms)),
                 "cold_prepare_ms": cold_prepare_ms,   # prepare passes of the warm-up calls, if any
                 "cold": cold,                         # CSR biased walk: first call over an unprepared graph; the one-off full prepare
+                "amortised": amortised,
                 "kernel_steps_per_s": steps_per_launch / (k_ms * 1e-3) if k_ms > 0 else None,
                 "counters": counters,
                 "request_rate": request_rate,
