@@ -599,6 +599,18 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
     u32x4_a4 e0 = {0u, 0u, 0u, 0u}, e1 = {0u, 0u, 0u, 0u}, e2 = {0u, 0u, 0u, 0u};
     bool more_walkers = true;
 
+    // counting variant only: shader-clock cycles per phase, burst passes / lanes / trial repetitions (status[20..27])
+    uint64_t w_cycles[4] = {0, 0, 0, 0}, w_bursts = 0, w_burst_lanes = 0, w_reps = 0, w_rep_lanes = 0;
+    uint64_t w_kind[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (kept in registers: an atomic per pass made the counting run 17x slower)
+    uint64_t t_mark = kCount ? clock64() : 0;
+    auto lap = [&](int phase) {
+        if (kCount) {
+            const uint64_t now = clock64();
+            w_cycles[phase] += now - t_mark;
+            t_mark = now;
+        }
+    };
+
     auto row_of = [&](uint32_t slot) { return out + (int64_t)P[EF_WALKER][slot] * cols; };
     // new low flag bits and gather kind for a slot; the rejection count stays, the probe count restarts
     auto set_kind = [&](uint32_t slot, uint32_t low, uint32_t kind) {
@@ -745,11 +757,9 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
         {
             bool to_trial = false, to_issue = false, to_free = false;
             if (kCount) {  // how many gathers of each kind were consumed (status[12 + kind]) and in how many passes ([19])
-                for (uint32_t k = 0; k < 7u; ++k) {
-                    const unsigned long long b = __ballot(hold && hkind == k);
-                    if (b && lane == 0) atomicAdd((unsigned long long *)&status[12 + k], (unsigned long long)__popcll(b));
-                }
-                if (lane == 0) atomicAdd((unsigned long long *)&status[19], 1ull);
+#pragma unroll
+                for (uint32_t k = 0; k < 7u; ++k) w_kind[k] += (uint64_t)__popcll(__ballot(hold && hkind == k));
+                ++w_kind[7];
             }
             if (hold) {
                 const uint32_t slot = hs;
@@ -884,6 +894,7 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
             hold = false;
             pool_fence();
         }
+        lap(0);
 
         // ================= refill =================
         if (more_walkers && (free_q.count >= 32u || trial_q.count + issue_q.count < 64u) && free_q.count > 0u) {
@@ -938,6 +949,7 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
             free_q.push(back, slot);
             pool_fence();
         }
+        lap(1);
         if (!more_walkers && free_q.count == (uint32_t)kElSlots) break;
 
         // ================= issue =================
@@ -966,6 +978,7 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
             }
         }
 
+        lap(2);
         // ================= burst =================
 #if TRW_POOL_PRIO
         __builtin_amdgcn_s_setprio(TRW_POOL_PRIO == 1 ? 0 : 3);
@@ -973,6 +986,10 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
         if (trial_q.count >= kPoolTrialMin || (trial_q.count > 0u && issue_q.count < kPoolIssueMin)) {
             uint32_t n, slot;
             trial_q.pop(lane, n, slot);
+            if (kCount) {
+                ++w_bursts;
+                w_burst_lanes += n;
+            }
             const bool busy = (uint32_t)lane < n;
             const uint32_t first = P[EF_FIRST][slot], cnt = P[EF_CNT][slot];
             FastMod fm;
@@ -1022,6 +1039,10 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
             for (int rep = 0; rep < 4; ++rep) {
                 running = running && pos + need <= (uint32_t)kElWin;
                 if (__ballot(running) == 0) break;
+                if (kCount) {
+                    ++w_reps;
+                    w_rep_lanes += (uint64_t)__popcll(__ballot(running));
+                }
                 if (running) {
                     if (kCount) ++n_trials;
                     uint32_t v;
@@ -1091,12 +1112,16 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
             free_q.push(to_free, slot);
             pool_fence();
         }
+        lap(3);
     }
 
     if (st) atomicOr((unsigned long long *)&status[0], (unsigned long long)st);
     if (kCount) {
         const uint64_t a = wave_sum(n_trials), b = wave_sum(n_fetch), c = wave_sum(n_tests), d = wave_sum(n_probes);
         if (lane == 0) {
+            const uint64_t w[8] = {w_cycles[0], w_cycles[1], w_cycles[2], w_cycles[3], w_bursts, w_burst_lanes, w_reps, w_rep_lanes};
+            for (int k = 0; k < 8; ++k) atomicAdd((unsigned long long *)&status[20 + k], (unsigned long long)w[k]);
+            for (int k = 0; k < 8; ++k) atomicAdd((unsigned long long *)&status[12 + k], (unsigned long long)w_kind[k]);
             atomicAdd((unsigned long long *)&status[4], (unsigned long long)a);
             atomicAdd((unsigned long long *)&status[5], (unsigned long long)b);
             atomicAdd((unsigned long long *)&status[6], (unsigned long long)c);
