@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: the whole GPU tier, then bench lines given as arguments (workload names).
 set -o pipefail
-O=gpurun_out/r03full; mkdir -p $O
+O=gpurun_out/tier; mkdir -p $O
 timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest.log
 for WL in "$@"; do
   timeout -k 10 300 python bench.py --workload $WL > $O/bench_$WL.json 2> $O/bench_$WL.err; echo "bench $WL rc=$?"

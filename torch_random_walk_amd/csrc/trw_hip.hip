@@ -1117,44 +1117,63 @@ int trw_walk_edge_list_hip(const int64_t *edges, int64_t n_edges, const int64_t 
 // caller's stream so far, join() makes the caller's stream wait for the side work.  Event-based fork / join is what a
 // stream capture records as graph dependencies, so a captured call replays with the same overlap.
 struct SideStream {
-    hipStream_t stream = nullptr;
-    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    hipStream_t stream = nullptr;  // one per device, made on first use, shared by every call on that device
+    hipEvent_t fork_ev = nullptr;  // THIS call's fork point (events are per call: two host threads may be in here at once)
     bool ok = false;
 };
 
-static SideStream *side_stream()
+static hipStream_t side_stream_of_device()
 {
     static std::mutex mu;
-    static SideStream per_device[64];
+    static hipStream_t per_device[64] = {nullptr};
     static bool tried[64] = {false};
     int dev = 0;
     if (env_long("TRW_SIDE_STREAM", 0, 1, 1) == 0 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     std::lock_guard<std::mutex> lock(mu);
-    SideStream &s = per_device[dev];
     if (!tried[dev]) {
         tried[dev] = true;
-        s.ok = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
-               hipEventCreateWithFlags(&s.fork_ev, hipEventDisableTiming) == hipSuccess &&
-               hipEventCreateWithFlags(&s.join_ev, hipEventDisableTiming) == hipSuccess;
+        if (hipStreamCreateWithFlags(&per_device[dev], hipStreamNonBlocking) != hipSuccess) per_device[dev] = nullptr;
     }
-    return s.ok ? &s : nullptr;
+    return per_device[dev];
 }
 
-// fork: the stream side work goes to (the caller's own stream when there is no side stream); join: back
-static hipStream_t side_fork(hipStream_t main, SideStream *&side)
+// Marks the fork point on the caller's stream (everything queued so far); !ok: no side stream, the work stays in line.
+static SideStream side_mark(hipStream_t main)
 {
-    side = side_stream();
-    if (side && hipEventRecord(side->fork_ev, main) == hipSuccess && hipStreamWaitEvent(side->stream, side->fork_ev, 0) == hipSuccess)
-        return side->stream;
-    side = nullptr;
+    SideStream s;
+    s.stream = side_stream_of_device();
+    if (!s.stream) return s;
+    if (hipEventCreateWithFlags(&s.fork_ev, hipEventDisableTiming) != hipSuccess) return s;
+    if (hipEventRecord(s.fork_ev, main) != hipSuccess) {
+        (void)hipEventDestroy(s.fork_ev);
+        s.fork_ev = nullptr;
+        return s;
+    }
+    s.ok = true;
+    return s;
+}
+
+// The stream the side work goes to: the side stream, made to wait for the fork point -- or the caller's own.
+static hipStream_t side_begin(hipStream_t main, SideStream &s)
+{
+    if (s.ok && hipStreamWaitEvent(s.stream, s.fork_ev, 0) == hipSuccess) return s.stream;
+    s.ok = false;
     return main;
 }
 
-static void side_join(hipStream_t main, SideStream *side)
+// The caller's stream waits for the side work; the call's events are released (they live until they have fired).
+static void side_join(hipStream_t main, SideStream &s)
 {
-    if (!side) return;
-    if (hipEventRecord(side->join_ev, side->stream) != hipSuccess || hipStreamWaitEvent(main, side->join_ev, 0) != hipSuccess)
-        (void)hipStreamSynchronize(side->stream);  // (never expected; keeps the ordering the caller relies on)
+    if (s.ok) {
+        hipEvent_t join_ev = nullptr;
+        if (hipEventCreateWithFlags(&join_ev, hipEventDisableTiming) != hipSuccess ||
+            hipEventRecord(join_ev, s.stream) != hipSuccess || hipStreamWaitEvent(main, join_ev, 0) != hipSuccess)
+            (void)hipStreamSynchronize(s.stream);  // (never expected; keeps the ordering the caller relies on)
+        if (join_ev) (void)hipEventDestroy(join_ev);
+    }
+    if (s.fork_ev) (void)hipEventDestroy(s.fork_ev);
+    s.fork_ev = nullptr;
+    s.ok = false;
 }
 
 // centre / pos of every window: blocks of whole walks through LDS, or -- walks too long for the tile -- in place
@@ -1229,11 +1248,10 @@ int trw_walk_windows_csr_prepared_hip(const void *prepared, size_t prepared_byte
     // written on the side stream, beside the walk.  The fork point is here, in front of the walk, but the walk is queued
     // FIRST: a walk that is already resident leaves the fill the CU share it needs (one workgroup per CU beside the
     // walk's five), a fill that starts first takes the LDS of every CU and the walk waits for it to finish.
-    SideStream *side = nullptr;
+    SideStream side;
     if (draws > 0) {
         if (int rc = ensure_jump_table()) return rc;
-        side = side_stream();
-        if (side && hipEventRecord(side->fork_ev, stream) != hipSuccess) side = nullptr;
+        side = side_mark(stream);
     }
     FusedWindows fw;
     fw.window_size = window_size;
@@ -1244,11 +1262,7 @@ int trw_walk_windows_csr_prepared_hip(const void *prepared, size_t prepared_byte
                                       walker_base, 1.0, 1.0, walk_length, seed, TRW_RNG_GLIBC, walks, workspace, walk_bytes,
                                       hip_stream, true, fused ? &fw : nullptr);
     if (draws > 0 && rc_walk == TRW_OK) {
-        hipStream_t ss = stream;
-        if (side && hipStreamWaitEvent(side->stream, side->fork_ev, 0) == hipSuccess)
-            ss = side->stream;
-        else
-            side = nullptr;
+        hipStream_t ss = side_begin(stream, side);
         uint32_t *win = (uint32_t *)((char *)workspace + walk_bytes + kStatusBytes);
         const int64_t nlanes = (draws + fill_run(draws) - 1) / fill_run(draws);
         SeedWindow sw;
@@ -1257,8 +1271,6 @@ int trw_walk_windows_csr_prepared_hip(const void *prepared, size_t prepared_byte
             sw, (uint64_t)walker_base * (uint64_t)step_end * (uint64_t)width, (uint64_t)fill_run(draws), nlanes, win);
         glibc_fill_mod_kernel<false><<<(unsigned)((nlanes + kBlock - 1) / kBlock), kBlock, 0, ss>>>(
             win, nlanes, draws, num_nodes, nullptr, neg_windows);
-    } else {
-        side = nullptr;
     }
     if (rc_walk == TRW_OK && total_windows > 0 && !fused)
         launch_windows_gather(walks, n_walkers, cols, window_size, target_nodes, pos_windows, stream);
@@ -1325,9 +1337,10 @@ int trw_to_windows_hip(const int64_t *walks, int64_t num_walks, int64_t walk_col
     prof_mark(1, stream);
     // two independent store streams, side by side: the negatives (the stream modulo num_nodes) on the side stream, the
     // windows' own nodes on the caller's
-    SideStream *side = nullptr;
+    SideStream side;
     if (draws > 0) {
-        hipStream_t ss = side_fork(stream, side);
+        side = side_mark(stream);
+        hipStream_t ss = side_begin(stream, side);
         SeedWindow sw;
         trw::seed_window(seed, sw.w);
         glibc_windows_kernel<<<(unsigned)((nlanes + kBlock - 1) / kBlock), kBlock, 0, ss>>>(
