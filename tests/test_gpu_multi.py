@@ -206,6 +206,10 @@ def test_bench_line_carries_the_contract_fields():
         assert key in roof, key
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and roof["kernel"] == "biased_pool_kernel"
+    # what the prepared graph costs a caller who does not walk it for ever
+    am = roof["amortised"]
+    assert am["value_one_shot_call"] > 0 and am["value_incl_prepare_at_10_epochs"] > 0
+    assert am["value_incl_prepare_at_10_epochs"] < line["value"] and "epochs_to_break_even" in am
     cpu = line["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cpu, key
