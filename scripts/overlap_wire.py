@@ -23,7 +23,8 @@ rw.prepare(rp, ci, marks="full")
 out = torch.empty((n, L + 1), dtype=torch.int64, device=dev)
 land = torch.randint(0, n, (peers * n, L + 1), dtype=torch.int32, device=dev)     # what the peers sent
 full = torch.empty((peers * n, L + 1), dtype=torch.int64, device=dev)
-s_walk, s_wire = torch.cuda.Stream(), torch.cuda.Stream()
+prio = int(os.environ.get("WIRE_PRIORITY", "0"))     # -1: the widening on a high-priority stream
+s_walk, s_wire = torch.cuda.Stream(), torch.cuda.Stream(priority=prio)
 
 
 def walk():
@@ -63,6 +64,6 @@ for spare in ("0", "64"):
     (w_both, x_both), whole = timed([(s_walk, walk), (s_wire, widen)])
     (x_both2, w_both2), whole2 = timed([(s_wire, widen), (s_walk, walk)])
     gb = peers * n * (L + 1) * 12 / 1e9
-    print("spare slots %2s: walk alone %.1f ms, widening %d blocks (%.0f GB moved) alone %.1f ms; together, walk queued first: "
+    print("wire stream priority %d, spare slots %2s: walk alone %.1f ms, widening %d blocks (%.0f GB moved) alone %.1f ms; together, walk queued first: "
           "walk %.1f widen %.1f whole %.1f ms; widening queued first: walk %.1f widen %.1f whole %.1f ms" % (
-              spare, w_alone, peers, gb, x_alone, w_both, x_both, whole, w_both2, x_both2, whole2), flush=True)
+              prio, spare, w_alone, peers, gb, x_alone, w_both, x_both, whole, w_both2, x_both2, whole2), flush=True)

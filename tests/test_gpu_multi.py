@@ -315,3 +315,25 @@ def test_config4_graph_node2vec_shard_keeps_the_table_path():
     del w
     rw.clear_cache()
     torch.cuda.empty_cache()
+
+
+def test_wire_format_kernels_round_trip():
+    """trw_rows_narrow_hip / trw_rows_widen_hip through the extension: any size (the last count % 4 values, blocks that
+    start at an odd element of a larger tensor take the scalar kernels), the whole uint32 range, overflow only reported
+    in strict mode; equal to the host legs."""
+    from torch_rw import rw
+    g = torch.Generator(device=DEV).manual_seed(5)
+    for shape in [(0, 81), (1, 1), (3,), (1023, 81), (4096, 81), (100_003, 7)]:
+        x = torch.randint(0, 2**32, shape, generator=g, dtype=torch.int64, device=DEV)
+        if x.numel():
+            x.view(-1)[-1] = 2**32 - 1
+        w = rw.narrow_rows(x, strict=True)
+        assert w.dtype == torch.int32 and w.shape == x.shape and torch.equal(rw.widen_rows(w), x)
+        assert torch.equal(w.cpu(), rw.narrow_rows(x.cpu()))
+    big = torch.arange(1000, dtype=torch.int64, device=DEV) * 7
+    src, dst = big[3:], torch.empty(1000, dtype=torch.int32, device=DEV)[1:998]      # both unaligned windows
+    assert torch.equal(rw.widen_rows(rw.narrow_rows(src, out=dst)), src)
+    bad = torch.tensor([1, 2**32, 3, 4, 5], device=DEV)
+    assert rw.narrow_rows(bad).tolist() == [1, 0, 3, 4, 5]
+    with pytest.raises(RuntimeError, match="does not fit"):
+        rw.narrow_rows(bad, strict=True)

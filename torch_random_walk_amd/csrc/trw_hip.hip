@@ -1739,12 +1739,13 @@ int trw_rows_narrow_hip(const int64_t *rows, int64_t count, uint32_t *wire, int6
     if (count < 0 || (count > 0 && (!rows || !wire))) return fail(TRW_E_ARG, "null pointer or negative count");
     if (count == 0) return TRW_OK;
     hipStream_t stream = (hipStream_t)hip_stream;
-    const bool aligned = (((uintptr_t)rows | (uintptr_t)wire) & 15u) == 0;
-    const unsigned grid = stream_grid(aligned ? (count + 3) / 4 : count);
-    if (aligned)
-        rows_narrow_kernel<<<grid, 256, 0, stream>>>(rows, count, wire, (unsigned long long *)overflow);
+    const bool aligned = (((uintptr_t)rows | (uintptr_t)wire) & 15u) == 0 && count / 4 / 256 < ((int64_t)1 << 31) - 1;
+    if (aligned)  // one trip per thread: a grid of count / 4 threads (+1 block: the last count % 4 values)
+        rows_narrow_kernel<<<(unsigned)(count / 4 / 256 + 1), 256, 0, stream>>>(rows, count, wire,
+                                                                               (unsigned long long *)overflow);
     else
-        rows_narrow_scalar_kernel<<<grid, 256, 0, stream>>>(rows, count, wire, (unsigned long long *)overflow);
+        rows_narrow_scalar_kernel<<<stream_grid(count), 256, 0, stream>>>(rows, count, wire,
+                                                                          (unsigned long long *)overflow);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? TRW_OK : fail_hip(e, "rows_narrow_kernel");
 }
@@ -1755,12 +1756,11 @@ int trw_rows_widen_hip(const uint32_t *wire, int64_t count, int64_t *rows, void 
     if (count < 0 || (count > 0 && (!rows || !wire))) return fail(TRW_E_ARG, "null pointer or negative count");
     if (count == 0) return TRW_OK;
     hipStream_t stream = (hipStream_t)hip_stream;
-    const bool aligned = (((uintptr_t)rows | (uintptr_t)wire) & 15u) == 0;
-    const unsigned grid = stream_grid(aligned ? (count + 3) / 4 : count);
+    const bool aligned = (((uintptr_t)rows | (uintptr_t)wire) & 15u) == 0 && count / 4 / 256 < ((int64_t)1 << 31) - 1;
     if (aligned)
-        rows_widen_kernel<<<grid, 256, 0, stream>>>(wire, count, rows);
+        rows_widen_kernel<<<(unsigned)(count / 4 / 256 + 1), 256, 0, stream>>>(wire, count, rows);
     else
-        rows_widen_scalar_kernel<<<grid, 256, 0, stream>>>(wire, count, rows);
+        rows_widen_scalar_kernel<<<stream_grid(count), 256, 0, stream>>>(wire, count, rows);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? TRW_OK : fail_hip(e, "rows_widen_kernel");
 }
