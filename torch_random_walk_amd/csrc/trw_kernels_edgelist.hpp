@@ -49,13 +49,18 @@ elist_shadow_kernel(const int64_t *__restrict__ edges, int64_t n_edges, const in
     if (st) atomicOr((unsigned long long *)&status[0], (unsigned long long)st);
 }
 
-// The edge table of the edge-list walk: one slot {u, v, ~posmask, ~flags} per distinct (head, tail) pair, every
-// edge included (all bytes 0xFF when empty).  Words 2 and 3 are kept INVERTED so that the fill value means
-// "nothing yet" and concurrent inserts of the same pair only ever clear bits (atomicAnd):
-//   posmask bit b   some occurrence of v sits at an offset == b (mod 32) of u's edge range -- tails are in input
-//                   order there, not sorted, so "where is v in u's range" is a set of offsets, kept modulo 32
-//   flags bit 0     some occurrence is not u's last edge: is_neighbor(x, t) looks at t's edges [first, last) --
+// The edge table of the edge-list walk: one slot {u, v, ~posmask, where} per distinct (head, tail) pair, every edge
+// included (all bytes 0xFF when empty).  Tails are in input order inside a head's range, not sorted, so "where is v in
+// u's range" is a set of offsets:
+//   posmask bit b   (kept inverted: inserts only clear bits) some occurrence sits at an offset == b (mod 32)
+//   where >> 2      the FIRST such offset (atomicMin over the occurrences' (offset << 2 | last << 1))
+//   where bit 1     0 when some occurrence is not u's last edge: is_neighbor(x, t) looks at t's edges [first, last) --
 //                   never the last one (rw_cpu_edge_list.cpp:51) -- so THIS bit is the reference's membership test
+//                   (the minimum is the first occurrence, which is the last edge only when it is the only one)
+//   where bit 0     1 when the pair occurs more than once: every occurrence that finds the slot taken sets it AFTER its
+//                   atomicMin, so whichever minimum stands last carries it
+// With one occurrence the first offset is where the pair is, exactly: a filter over a hub's range then has 128
+// distinct bits instead of the 32 of the modulo mask (which round 2 used alone: half of all steps looked a candidate up).
 __global__ void __launch_bounds__(kBlock)
 elist_table_build_kernel(const int64_t *__restrict__ edges, int64_t n_edges, int64_t n_nodes,
                          const uint32_t *__restrict__ tail32, const u32x2_a8 *__restrict__ ix32,
@@ -74,8 +79,10 @@ elist_table_build_kernel(const int64_t *__restrict__ edges, int64_t n_edges, int
             uint32_t *ent = table + 4 * (size_t)slot;
             const unsigned long long old = atomicCAS((unsigned long long *)ent, ~0ull, key);
             if (old == ~0ull || old == key) {
-                atomicAnd(ent + 2, ~(1u << (((uint32_t)e - ix.x) & 31u)));
-                if ((uint32_t)e != ix.y) atomicAnd(ent + 3, ~1u);
+                const uint32_t off = (uint32_t)e - ix.x;
+                atomicAnd(ent + 2, ~(1u << (off & 31u)));
+                const uint32_t before = atomicMin(ent + 3, (off << 2) | ((uint32_t)e == ix.y ? 2u : 0u));
+                if (before != 0xFFFFFFFFu) atomicOr(ent + 3, 1u);  // not the first to arrive: the pair is a multi-edge
                 break;
             }
             slot = (slot + 1) & mask;
@@ -83,17 +90,19 @@ elist_table_build_kernel(const int64_t *__restrict__ edges, int64_t n_edges, int
     }
 }
 
-// the slot of pair (u, v): false when absent; posmask / in_range as described above
+// the slot of pair (u, v): false when absent; `first` = first offset of v in u's range (where it is, when `posmask`
+// comes back 0: a single occurrence), `posmask` = the offsets modulo 32 of a pair that occurs more than once
 __device__ __forceinline__ bool elist_table_find(const uint32_t *__restrict__ table, uint32_t mask, uint32_t u,
-                                                 uint32_t v, uint32_t &posmask, bool &in_range)
+                                                 uint32_t v, uint32_t &first, uint32_t &posmask, bool &in_range)
 {
     uint32_t slot = edge_hash(u, v) & mask;
     while (true) {
         const u32x4_a16 kv = *reinterpret_cast<const u32x4_a16 *>(table + 4 * (size_t)slot);
         if (kv.x == 0xFFFFFFFFu && kv.y == 0xFFFFFFFFu) return false;
         if (kv.x == u && kv.y == v) {
-            posmask = ~kv.z;
-            in_range = (kv.w & 1u) == 0u;
+            first = kv.w >> 2;
+            posmask = (kv.w & 1u) ? ~kv.z : 0u;
+            in_range = (kv.w & 2u) == 0u;
             return true;
         }
         slot = (slot + 1) & mask;
@@ -104,9 +113,9 @@ __device__ __forceinline__ bool elist_table_find(const uint32_t *__restrict__ ta
 __device__ __forceinline__ bool elist_table_contains(const uint32_t *__restrict__ table, uint32_t mask, uint32_t u,
                                                      uint32_t v)
 {
-    uint32_t pm;
+    uint32_t first, pm;
     bool in_range = false;
-    return elist_table_find(table, mask, u, v, pm, in_range) && in_range;
+    return elist_table_find(table, mask, u, v, first, pm, in_range) && in_range;
 }
 
 // Uniform views of the two layouts: node ids as int64, "no edges" as first < 0.
@@ -449,9 +458,9 @@ elist_node_kernel(int64_t n_nodes, uint32_t pad, const uint32_t *__restrict__ ta
                 for (uint32_t j = 0; j < cnt; ++j)
                     if (tail32[ix.x + j] == pad) flags |= kElHasPad;
             } else {
-                uint32_t pm;
+                uint32_t at0, pm;
                 bool in_range;
-                if (elist_table_find(table, mask, (uint32_t)v, pad, pm, in_range)) flags |= kElHasPad;
+                if (elist_table_find(table, mask, (uint32_t)v, pad, at0, pm, in_range)) flags |= kElHasPad;
             }
         }
         u32x4_a16 o = {ix.x, ix.y, flags, only};
@@ -479,7 +488,7 @@ elist_ext_kernel(const int64_t *__restrict__ edges, int64_t n_edges, int64_t n_n
                 cnt = ix.y - ix.x + 1u;
             }
             if (cnt == 1u) only = tail32[first];
-            uint32_t pm;
+            uint32_t at0, pm;
             bool in_range;
             if (cnt >= 1u && cnt <= 128u) {
                 uint32_t occ = 0, at = 0xFFFFFFFFu, m32 = 0;
@@ -502,19 +511,34 @@ elist_ext_kernel(const int64_t *__restrict__ edges, int64_t n_edges, int64_t n_n
                     flags |= kElTmLook;
                 }
             } else if (cnt > 128u) {
+                // a range too long to scan: the masks are FILTERS over offsets modulo 128, built from the table -- the
+                // offset itself for a pair that occurs once, its offsets modulo 32 (in all four words) for a multi-edge
                 flags |= kElFilter;
-                if (elist_table_find(table, mask, v, pad, pm, in_range)) flags |= kElHasPad;
-                uint32_t t32 = 0u, n32 = 0xFFFFFFFFu;
-                if (elist_table_find(table, mask, v, u, pm, in_range)) t32 = pm;
+                if (elist_table_find(table, mask, v, pad, at0, pm, in_range)) flags |= kElHasPad;
+                if (elist_table_find(table, mask, v, u, at0, pm, in_range)) {  // t is in v's range
+                    if (pm == 0u) {
+                        tm = at0;
+                        flags |= kElTmOffset;  // ... once: that offset, exactly
+                    } else {
+                        tm = pm;
+                        flags |= kElTmLook;
+                    }
+                } else {
+                    tm = 0u;
+                    flags |= kElTmLook;  // (a plain mask with no bit set: no offset holds t)
+                }
+                nb.fill();
                 const u32x2_a8 ux = ix32[u];
                 if (ux.x != kNoEdge && ux.y - ux.x <= kElFilterWalk) {
-                    n32 = 0u;
-                    for (uint32_t k = ux.x; k < ux.y; ++k)  // u's edges [first, last): the last one never counts
-                        if (elist_table_find(table, mask, v, tail32[k], pm, in_range)) n32 |= pm;
+                    nb.clear();
+                    for (uint32_t k = ux.x; k < ux.y; ++k) {  // u's edges [first, last): the last one never counts
+                        if (elist_table_find(table, mask, v, tail32[k], at0, pm, in_range)) {
+                            if (pm == 0u) nb.set(at0);
+                            else
+                                for (int w = 0; w < 4; ++w) nb.w[w] |= pm;
+                        }
+                    }
                 }
-                tm = t32;
-                flags |= kElTmLook;
-                for (int k = 0; k < 4; ++k) nb.w[k] = n32;
             }
             if (flags & kElHasPad) {  // any candidate may be the padding id: every trial looks
                 flags = (flags & ~kElTmOffset) | kElFilter | kElTmLook;
@@ -866,7 +890,7 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
                         P[EF_FLAGS][slot] = flags + (1u << kEfProbeShift);  // next slot of the probe chain
                         where = 1;
                     } else {
-                        const bool nb = match && (e0.w & 1u) == 0u;
+                        const bool nb = match && (e0.w & 2u) == 0u;  // (the slot's "some occurrence is not t's last edge" bit)
                         if (hkind == EK_FIXNB) {
                             P[EF_AUX][slot] = fixed_threshold(x, t, nb);
                             set_kind(slot, flags, 0u);
