@@ -725,11 +725,11 @@ static int walk_prepared(const void *prepared, size_t prepared_bytes, int32_t wh
             if (pblocks > president) pblocks = president;
             if (g_prof.count)
                 biased_pool_kernel<true><<<(unsigned)pblocks, kBlock, 0, stream>>>(
-                    row32, ext32, table, pl.hash_mask, targets, n_nodes, n_walkers, walker_base, walk_length,
+                    row32, col32, ext32, table, pl.hash_mask, targets, n_nodes, n_walkers, walker_base, walk_length,
                     (uint32_t)seed, bp, out, status);
             else
                 biased_pool_kernel<false><<<(unsigned)pblocks, kBlock, 0, stream>>>(
-                    row32, ext32, table, pl.hash_mask, targets, n_nodes, n_walkers, walker_base, walk_length,
+                    row32, col32, ext32, table, pl.hash_mask, targets, n_nodes, n_walkers, walker_base, walk_length,
                     (uint32_t)seed, bp, out, status);
         } else if (mask_kernel) {
             if (g_prof.count)

@@ -1734,7 +1734,8 @@ biased_mask_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
 //     adopt   the lanes that issued a gather in the previous iteration consume it for their slot: step onto the
 //             entry (emit the column, write the next step's row / rpos / mask into the slot) -> trial queue;
 //             first-step row, edge-table probes likewise
-//     refill  free slots take new walkers from the device counter -> issue queue
+//     refill  free slots take new walkers from the wave's reserve (64 claimed from the device counter at a time,
+//             start rows and first steps prefetched) -> issue queue
 //     issue   pop up to 64 slots that want a gather, form the address, load; the data is collected by `adopt`
 //             in the NEXT iteration, after the burst below -- the wave hides its own memory latency
 //     burst   pop up to 64 slots that are between gathers, load their trial state, run up to 2*kPoolPairs
@@ -1770,7 +1771,15 @@ constexpr int kPoolWaves = kBlock / 64;
 #ifndef TRW_POOL_TRIAL_MIN
 #define TRW_POOL_TRIAL_MIN 48
 #endif
-constexpr uint32_t kPoolIssueMin = TRW_POOL_ISSUE_MIN, kPoolTrialMin = TRW_POOL_TRIAL_MIN;
+// Free slots are refilled when this many have gathered (a refill pass is an atomic on the device counter and one Philox
+// block for the pass).
+#ifndef TRW_POOL_PAIR_STORES
+#define TRW_POOL_PAIR_STORES 1
+#endif
+#ifndef TRW_POOL_REFILL_MIN
+#define TRW_POOL_REFILL_MIN 8
+#endif
+constexpr uint32_t kPoolIssueMin = TRW_POOL_ISSUE_MIN, kPoolTrialMin = TRW_POOL_TRIAL_MIN, kPoolRefillMin = TRW_POOL_REFILL_MIN;
 enum : uint32_t { PK_ROW = 0, PK_ENTRY = 1, PK_TEST = 2, PK_MEMBER = 3, PK_POS = 4 };  // what a slot's gather is for
 // kPfExact: the slot's mask bits are exact answers (a filter otherwise); kPfOdd: the stream stands at word 3 of the
 // current block; kPfWide: t's run in prev's row does not fit PF_RPOS
@@ -1822,8 +1831,8 @@ __device__ __forceinline__ void pool_fence()
 //     mask, one v_bfi per threshold, one select for the run of t;
 //   * the 128-bit mask of a slot is 16 contiguous bytes, the word is read at base + ((idx >> 3) & 12); a slot whose
 //     run of t does not fit RPOS ("wide") points its base at sixteen 0xFF bytes instead of testing a flag per trial;
-//   * the first step's draw is worked out where new walkers are taken on, a full pass of lanes at a time (it was a
-//     special case inside every trial), and goes straight to the issue queue when the start row arrives;
+//   * the first step is worked out where new walkers are taken on -- 64 at a time, in the wave's reserve (see `refill`) --
+//     and a new walker enters the pool with its first entry gather queued (it was a special case inside every trial);
 //   * rejections are counted per pair, the runaway cap is looked at once per pair;
 //   * the Philox key schedule lives in vector registers (philox4x32_10_keyed).
 // 19 words per walker (15 + the 4 mask words): with 128 walkers per wave that is 9.9 KB of LDS, 39.6 KB per workgroup,
@@ -1835,17 +1844,17 @@ enum : int {
                 // bits 29..31 how far the probe chain of the current table lookup has gone
     PF_S, PF_WALKER,
     PF_W1, PF_W2, PF_W3, PF_BLK,  // words 1..3 of the walker's current Philox block, and its number
-    PF_X,       // the candidate node a table probe asks about (before the start row has arrived: the first step's draw)
+    PF_X,       // the candidate node a table probe asks about
     PF_AT,      // fat entry index to gather
     PF_COUNT
 };
 
 template <bool kCount>
 __global__ void __launch_bounds__(kBlock)
-biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restrict__ ext,
-                    const uint32_t *__restrict__ table, uint64_t mask, const int64_t *__restrict__ targets,
-                    int64_t n_nodes, int64_t n_walkers, int64_t walker_base, int32_t L, uint32_t seed, BiasedParams bp,
-                    int64_t *__restrict__ out, int64_t *__restrict__ status)
+biased_pool_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32,
+                   const u32x4_a16 *__restrict__ ext, const uint32_t *__restrict__ table, uint64_t mask,
+                   const int64_t *__restrict__ targets, int64_t n_nodes, int64_t n_walkers, int64_t walker_base, int32_t L,
+                   uint32_t seed, BiasedParams bp, int64_t *__restrict__ out, int64_t *__restrict__ status)
 {
     if (status[kStDescents] != status[kStBoundary]) return;  // unsorted rows: biased_hash_kernel's job
     __shared__ uint32_t pool_mem[kPoolWaves][PF_COUNT][kPoolSlots];
@@ -1882,6 +1891,14 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
     uint32_t hs = 0, hkind = 0;
     u32x4_a4 e0 = {0u, 0u, 0u, 0u}, e1 = {0u, 0u, 0u, 0u};
     bool more_walkers = true;
+    // the reserve of new walkers (see `refill`): state 0 empty / 1 claimed / 2 start nodes asked for / 3 rows asked for / 4 ready
+    int rs_state = 0;
+    uint32_t rs_cnt = 0, rs_next = 0, rs_have = 0, rs_at = 0, rs_tg_lo = 0, rs_tg_hi = 0;
+    long long rs_base = 0;
+    int64_t rs_walker0 = 0, rs_target = 0;
+    u32x2_a4 rs_row = {0u, 0u};
+    uint32_t rs_blk[4] = {0u, 0u, 0u, 0u};
+    bool rs_bad = false, rs_dead = false;
     uint64_t w_iters = 0, w_pass[3] = {0, 0, 0}, w_lanes[3] = {0, 0, 0}, w_cycles[4] = {0, 0, 0, 0}, w_trial_passes = 0;
     uint64_t t_mark = kCount ? clock64() : 0;
     auto lap = [&](int phase) {
@@ -1910,35 +1927,31 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
             }
             if (hold) {
                 const uint32_t slot = hs;
-                if (hkind == PK_ROW) {  // e0 = row32[start node], row32[start node + 1]
-                    const uint32_t start = e0.x, deg = e0.y >= e0.x ? e0.y - e0.x : 0u;
-                    const uint32_t prev = P[PF_PREV][slot];
-                    if (deg == 0) {  // dead end at the start node: reported, the walker stays
-                        st |= TRW_ST_DEGREE0;
-                        int64_t *r = row_of(slot);
-                        for (int32_t s = 1; s <= L; ++s) r[s] = (int64_t)prev;
-                        to_free = true;
-                    } else {  // first step: plain uniform neighbour, draw 0 (rw_cpu.cpp:159), drawn at refill (PF_X)
-                        FastMod fm;
-                        fm.init_exact(deg);
-                        P[PF_AT][slot] = start + fm.mod31(P[PF_X][slot] >> 1);
-                        P[PF_FLAGS][slot] = PK_ENTRY << 4;
-                        if (kCount) ++n_fetch;
-                        to_issue = true;
-                    }
-                } else if (hkind == PK_ENTRY) {  // e0, e1 = the accepted entry: step onto it
+                if (hkind == PK_ENTRY) {  // e0, e1 = the accepted entry: step onto it
                     const uint32_t x = e0.x;
                     int32_t s = (int32_t)P[PF_S][slot];
                     const uint32_t prev = P[PF_PREV][slot];
                     int64_t *r = row_of(slot);
+#if TRW_POOL_PAIR_STORES
+                    // Columns leave in 16-byte ALIGNED pairs: column s together with column s-1 (the node being left, in
+                    // the slot anyway) when its address is the upper half of a pair, not at all when it is the lower half
+                    // (the next step stores it) -- half the store requests of a kernel that runs at the memory system's
+                    // request rate.  (Round 2 paired by step parity: rows are 8-byte aligned, every other walker's pairs
+                    // straddled and were split again.)
+                    if (((uintptr_t)(r + s) >> 3) & 1u)
+                        *reinterpret_cast<i64x2_a16 *>(r + s - 1) = i64x2_a16{(int64_t)prev, (int64_t)x};
+                    else if (s == L)
+                        r[s] = (int64_t)x;  // (the last column has no partner to wait for)
+#else
                     r[s] = (int64_t)x;
+#endif
                     ++s;
                     const uint32_t deg = e0.z & ~kMaskIsFilter;
                     if (s > L) {
                         to_free = true;
                     } else if (deg == 0) {  // dead end: reported, the walker stays
                         st |= TRW_ST_DEGREE0;
-                        for (; s <= L; ++s) r[s] = (int64_t)x;
+                        for (int32_t c = s - 1; c <= L; ++c) r[c] = (int64_t)x;
                         to_free = true;
                     } else {
                         FastMod fm;
@@ -2044,57 +2057,98 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
         lap(0);
 
         // ================= refill: new walkers into free slots =================
-        if (more_walkers && (free_q.count >= 32u || trial_q.count + issue_q.count < 64u) && free_q.count > 0u) {
-            uint32_t n, slot;
-            const uint32_t avail = free_q.count < 64u ? free_q.count : 64u;
-            long long base = 0;
-            if (lane == 0) base = (long long)atomicAdd((unsigned long long *)&status[kStNextWalker], (unsigned long long)avail);
-            base = __shfl(base, 0);
+        // New walkers come out of a RESERVE of up to 64 that the wave keeps in registers, one per lane: claimed from the
+        // device counter 64 at a time, their start nodes, start rows, first Philox block and first step worked out a
+        // stage per iteration, every load long on its way before it is used.  (Claiming them when slots fell free made
+        // the wave sit through an atomic and a load, ~20 000 cycles a pass, so a pass was only worth it for 32 free
+        // slots at once and 16 slots of a pool stood empty on average: bursts of 58.7 lanes instead of 62.)
+        if (rs_state == 1) {  // the claim has returned: which walkers, if any
+            const long long base = __shfl(rs_base, 0);
             int64_t left = n_walkers - (int64_t)base;
-            left = left < 0 ? 0 : left;
-            const uint32_t take = left < (int64_t)avail ? (uint32_t)left : avail;
-            if (take < avail) more_walkers = false;
+            left = left < 0 ? 0 : (left > 64 ? 64 : left);
+            if (left < 64) more_walkers = false;  // the counter has run out: no further claim
+            rs_cnt = (uint32_t)left;
+            rs_walker0 = (int64_t)base;
+            if ((uint32_t)lane < rs_cnt) rs_target = targets[base + lane];
+            rs_state = rs_cnt ? 2 : 0;
+        } else if (rs_state == 2) {  // the start nodes have arrived: their rows
+            rs_bad = (uint32_t)lane < rs_cnt && (uint64_t)rs_target >= (uint64_t)n_nodes;
+            rs_row = u32x2_a4{0u, 0u};
+            if ((uint32_t)lane < rs_cnt && !rs_bad) rs_row = *reinterpret_cast<const u32x2_a4 *>(row32 + (uint32_t)rs_target);
+            // block 0 of every reserved walker's stream, 64 lanes at once: word 0 is the first step's draw
+            const uint64_t gw0 = (uint64_t)walker_base + (uint64_t)rs_walker0 + (uint64_t)lane;
+            philox4x32_10_keyed((uint32_t)gw0, (uint32_t)(gw0 >> 32), 0u, 0u, key_r, rs_blk);
+            rs_state = 3;
+        } else if (rs_state == 3) {  // the rows have arrived: the first step (a plain uniform neighbour, rw_cpu.cpp:159)
+            const uint32_t deg = rs_row.y >= rs_row.x ? rs_row.y - rs_row.x : 0u;
+            FastMod fm;
+            fm.init_exact(deg ? deg : 1u);
+            rs_at = rs_row.x + fm.mod31(rs_blk[0] >> 1);
+            rs_dead = deg == 0u;
+            // The hand-out below must not look at a register a LOAD wrote: the compiler cannot know that load finished
+            // many iterations ago and would wait for every memory operation in flight (this iteration's column stores
+            // included, ~20 000 cycles) in front of the first use.  Real moves, here, where the loads have been waited for.
+            asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
+                         : "=&v"(rs_tg_lo), "=&v"(rs_tg_hi)
+                         : "v"((uint32_t)rs_target), "v"((uint32_t)((uint64_t)rs_target >> 32)));
+            rs_next = 0u;
+            rs_have = rs_cnt;
+            rs_state = 4;
+        }
+        if (rs_state == 4 && free_q.count > 0u && (free_q.count >= kPoolRefillMin || trial_q.count + issue_q.count < 64u)) {
+            uint32_t n, slot;
+            uint32_t take = free_q.count < rs_have ? free_q.count : rs_have;  // (rs_have <= 64)
             const uint32_t keep_count = free_q.count;
             free_q.pop(lane, n, slot);
             if (take < n) {  // hand the unused ones back (they are the last ones popped)
                 free_q.head = (free_q.head + (uint32_t)kQueueCap - (n - take)) & (uint32_t)(kQueueCap - 1);
                 free_q.count = keep_count - take;
             }
+            // lane i < take serves reserve entry rs_next + i
+            const int src = (int)((rs_next + (uint32_t)lane) & 63u);
+            const int64_t tg = (int64_t)(((uint64_t)(uint32_t)__shfl((int)rs_tg_hi, src) << 32) |
+                                         (uint64_t)(uint32_t)__shfl((int)rs_tg_lo, src));
+            const uint32_t b1 = (uint32_t)__shfl((int)rs_blk[1], src), b2 = (uint32_t)__shfl((int)rs_blk[2], src),
+                           b3 = (uint32_t)__shfl((int)rs_blk[3], src), at0 = (uint32_t)__shfl((int)rs_at, src);
+            const uint32_t why = (uint32_t)__shfl((int)((rs_bad ? 1u : 0u) | (rs_dead ? 2u : 0u)), src);
             bool to_issue = false, back = false;
             if ((uint32_t)lane < take) {
-                const int64_t walker = (int64_t)base + lane;
-                const int64_t tg = targets[walker];
-                if ((uint64_t)tg >= (uint64_t)n_nodes) {
-                    st |= TRW_ST_NODE_RANGE;  // reported; the row is filled with the bad id
-                    int64_t *rowp = out + walker * cols;
+                const int64_t walker = rs_walker0 + (int64_t)src;
+                int64_t *rowp = out + walker * cols;
+                if (why) {  // reported; a bad id fills its row, a dead end at the start node stays there
+                    st |= (why & 1u) ? TRW_ST_NODE_RANGE : TRW_ST_DEGREE0;
                     for (int32_t c = 0; c <= L; ++c) rowp[c] = tg;
                     back = true;
                 } else {
-                    // block 0 of the walker's stream, for the whole pass of new walkers at once: word 0 is the first
-                    // step's draw (kept in PF_X until the start row has arrived), words 1..3 the first trials'
-                    uint32_t nb[4];
-                    const uint64_t gw0 = (uint64_t)walker_base + (uint64_t)walker;
-                    philox4x32_10_keyed((uint32_t)gw0, (uint32_t)(gw0 >> 32), 0u, 0u, key_r, nb);
                     P[PF_WALKER][slot] = (uint32_t)walker;
-                    out[walker * cols] = tg;  // column 0
+                    rowp[0] = tg;  // column 0
                     P[PF_PREV][slot] = (uint32_t)tg;  // step 1 leaves the start node
                     P[PF_T][slot] = (uint32_t)tg;
                     P[PF_S][slot] = 1u;
-                    P[PF_X][slot] = nb[0];
-                    P[PF_W1][slot] = nb[1];
-                    P[PF_W2][slot] = nb[2];
-                    P[PF_W3][slot] = nb[3];
+                    P[PF_AT][slot] = at0;
+                    P[PF_W1][slot] = b1;
+                    P[PF_W2][slot] = b2;
+                    P[PF_W3][slot] = b3;
                     P[PF_BLK][slot] = 0u;
-                    P[PF_FLAGS][slot] = PK_ROW << 4;
+                    P[PF_FLAGS][slot] = PK_ENTRY << 4;
+                    if (kCount) ++n_fetch;
                     to_issue = true;
                 }
             }
+            rs_next += take;
+            rs_have -= take;
+            if (rs_have == 0u) rs_state = 0;
             issue_q.push(to_issue, slot);
             free_q.push(back, slot);
             pool_fence();
         }
+        if (rs_state == 0 && more_walkers) {  // the reserve is used up: claim the next 64 (looked at next time round)
+            if (lane == 0) rs_base = (long long)atomicAdd((unsigned long long *)&status[kStNextWalker], 64ull);
+            rs_state = 1;
+        }
         lap(1);
-        if (!more_walkers && free_q.count == (uint32_t)kPoolSlots) break;  // every walker of this wave is done
+        // every walker of this wave is done: none in the pool, none in the reserve, none to claim
+        if (!more_walkers && rs_state == 0 && free_q.count == (uint32_t)kPoolSlots) break;
 
         // ================= issue: gathers for the slots that want one =================
         if (issue_q.count >= kPoolIssueMin || (issue_q.count > 0u && trial_q.count < kPoolTrialMin)) {
@@ -2107,19 +2161,23 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
             if ((uint32_t)lane < n) {
                 const uint32_t flags = P[PF_FLAGS][slot];
                 const uint32_t kind = (flags & kPfKind) >> 4;
-                const uint32_t *addr;
-                if (kind == PK_ENTRY || kind == PK_TEST) {
-                    addr = reinterpret_cast<const uint32_t *>(ext + 2 * (size_t)P[PF_AT][slot]);
-                } else if (kind == PK_ROW) {
-                    addr = row32 + P[PF_PREV][slot];
+                if (kind == PK_TEST) {
+                    // only the candidate's node is wanted: from the compact shadow (4 bytes of a 0.4 GB array that the
+                    // L2s and the Infinity Cache hold a good part of) instead of its 32-byte entry (3.5 GB: a miss)
+                    e0.x = col32[P[PF_AT][slot]];
                 } else {
-                    const uint32_t t = P[PF_T][slot], prev = P[PF_PREV][slot];
-                    const uint64_t s0 = kind == PK_MEMBER ? edge_slot(t, P[PF_X][slot], mask) : edge_slot(prev, t, mask);
-                    addr = table + 4 * ((((s0 >> 1) + (flags >> kPfProbeShift)) << 1) & mask);  // an aligned pair of slots
-                    if ((flags & kPfProbe) == 0u && (s0 & 1u) != 0u) P[PF_FLAGS][slot] = flags | kPfSkip;
+                    const uint32_t *addr;
+                    if (kind == PK_ENTRY) {
+                        addr = reinterpret_cast<const uint32_t *>(ext + 2 * (size_t)P[PF_AT][slot]);
+                    } else {
+                        const uint32_t t = P[PF_T][slot], prev = P[PF_PREV][slot];
+                        const uint64_t s0 = kind == PK_MEMBER ? edge_slot(t, P[PF_X][slot], mask) : edge_slot(prev, t, mask);
+                        addr = table + 4 * ((((s0 >> 1) + (flags >> kPfProbeShift)) << 1) & mask);  // an aligned pair of slots
+                        if ((flags & kPfProbe) == 0u && (s0 & 1u) != 0u) P[PF_FLAGS][slot] = flags | kPfSkip;
+                    }
+                    e0 = *reinterpret_cast<const u32x4_a4 *>(addr);
+                    e1 = *reinterpret_cast<const u32x4_a4 *>(addr + 4);
                 }
-                e0 = *reinterpret_cast<const u32x4_a4 *>(addr);
-                if (kind != PK_ROW && kind != PK_TEST) e1 = *reinterpret_cast<const u32x4_a4 *>(addr + 4);
                 hold = true;
                 hs = slot;
                 hkind = kind;
