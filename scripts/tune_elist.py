@@ -78,8 +78,8 @@ if args.count:
         " ".join("%s %.3f" % (nm, raw[12 + k] / steps) for k, nm in enumerate(names)), raw[19]))
     cyc = max(1, sum(raw[20:24]))
     print("   phases: wall cycles adopt %.1f%% refill %.1f%% issue %.1f%% burst %.1f%% (%.0f cycles / iteration); burst passes/iter %.2f, "
-          "%.1f lanes in, %.2f trial repetitions per burst at %.1f lanes" % (
+          "%.1f lanes in, %.2f trial repetitions per burst at %.1f lanes; adopt waited for its gathers %.1f%% of the wall cycles" % (
               100.0 * raw[20] / cyc, 100.0 * raw[21] / cyc, 100.0 * raw[22] / cyc, 100.0 * raw[23] / cyc, cyc / max(1, raw[19]),
-              raw[24] / max(1, raw[19]), raw[25] / max(1, raw[24]), raw[26] / max(1, raw[24]), raw[27] / max(1, raw[26])))
+              raw[24] / max(1, raw[19]), raw[25] / max(1, raw[24]), raw[26] / max(1, raw[24]), raw[27] / max(1, raw[26]), 100.0 * raw[28] / cyc))
 print("%-40s prepare %.2f  walk %s  best %.2f  family %d status %d checksum %x" % (
     args.tag or os.path.basename(args.lib), min(pre), " ".join("%.2f" % t for t in wk), min(wk), st[3], st[0], chk & 0xffffffff), flush=True)

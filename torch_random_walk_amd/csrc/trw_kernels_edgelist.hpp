@@ -597,7 +597,20 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
 #ifndef TRW_EL_WIN12
 #define TRW_EL_WIN12 0
 #endif
+#ifndef TRW_EL_BURST2
+#define TRW_EL_BURST2 1
+#endif
+#ifndef TRW_EL_REFILL_MIN
+#define TRW_EL_REFILL_MIN 32  // free slots that trigger a claim of new walkers
+#endif
+#ifndef TRW_EL_ISSUE_MIN
+#define TRW_EL_ISSUE_MIN TRW_POOL_ISSUE_MIN
+#endif
+#ifndef TRW_EL_TRIAL_MIN
+#define TRW_EL_TRIAL_MIN TRW_POOL_TRIAL_MIN
+#endif
     constexpr int kWinOff = TRW_EL_WIN12 ? 0 : 4;  // window positions below this are read from the slot's C0..C3
+    static_assert(!(TRW_EL_BURST2 && TRW_EL_WIN12), "the straight-line burst reads positions 0..3 from the slot");
     __shared__ uint32_t win_mem[kPoolWaves][kElWin - kWinOff][64];
     __shared__ uint8_t queue_mem[kPoolWaves][3][kQueueCap];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -615,16 +628,27 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
     const bool band_takes_near = bp.t1 > bp.t2;
     const uint32_t v_clear = band_takes_near ? 0u : 1u, v_set = band_takes_near ? 1u : 0u;
     const int32_t cols = L + 1;
+    // the Philox key schedule in vector registers (see philox4x32_10_keyed)
+    uint32_t key_r[10];
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        key_r[r] = seed + (uint32_t)r * 0x9E3779B9u;
+        asm volatile("" : "+v"(key_r[r]));
+    }
 
     uint32_t st = 0;
     uint32_t n_trials = 0, n_fetch = 0, n_tests = 0, n_probes = 0;
     bool hold = false;
     uint32_t hs = 0, hkind = 0;
-    u32x4_a4 e0 = {0u, 0u, 0u, 0u}, e1 = {0u, 0u, 0u, 0u}, e2 = {0u, 0u, 0u, 0u};
+    u32x4_a4 e0 = {0u, 0u, 0u, 0u}, e1 = {0u, 0u, 0u, 0u};
+    // (only the words of an entry that are used are loaded: a load's unused destination registers get other values
+    // assigned to them, and the first write to one waits for the load -- a memory latency at the head of the burst)
+    u32x2_a4 e2 = {0u, 0u};
     bool more_walkers = true;
 
     // counting variant only: shader-clock cycles per phase, burst passes / lanes / trial repetitions (status[20..27])
     uint64_t w_cycles[4] = {0, 0, 0, 0}, w_bursts = 0, w_burst_lanes = 0, w_reps = 0, w_rep_lanes = 0;
+    uint64_t w_wait = 0;  // cycles the adopt pass waited for its gathers (status[28])
     uint64_t w_kind[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (kept in registers: an atomic per pass made the counting run 17x slower)
     uint64_t t_mark = kCount ? clock64() : 0;
     auto lap = [&](int phase) {
@@ -725,8 +749,11 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
         set_kind(slot, fbits, 0u);
         return 0;
     };
-    // the walker of `slot` takes `node` as column S without an entry for it
-    auto step_bare = [&](uint32_t slot, uint32_t node, bool &to_free) -> int {
+    // The walker of `slot` takes `node` as column S: onto the entry in e0..e2 (`with_entry`) or without one (padding id,
+    // jump, restart).  Returns -1 freed, 0 trial queue, 1 issue queue, 2 "classify(slot, only_tail) is still to be done"
+    // -- the callers run ONE copy of classify for every way a walker can arrive (the lambdas are inlined where they are
+    // called: the adopt pass used to execute three copies of this and two of classify in every pass).
+    auto step_to = [&](uint32_t slot, uint32_t node, bool with_entry, bool &to_free, uint32_t &only_tail) -> int {
         int32_t s = (int32_t)P[EF_S][slot];
         row_of(slot)[s] = (int64_t)node;
         ++s;
@@ -734,32 +761,14 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
         const uint32_t left = P[EF_PREV][slot];
         // the node being left becomes t: does is_neighbor(., t) have anything to look at?  (edges [first, last))
         const bool tnonb = left == pad ? pad >= (uint32_t)n_nodes : P[EF_CNT][slot] <= 1u;
-        P[EF_FLAGS][slot] = tnonb ? kEfTNoNb : 0u;  // (no rejections yet at the new step)
         P[EF_T][slot] = left;
         P[EF_PREV][slot] = node;
         if (s > L) {
             to_free = true;
             return -1;
         }
-        return arrive_bare(slot);
-    };
-    // ... onto the entry in e0..e2
-    auto step_entry = [&](uint32_t slot, bool &to_free) -> int {
-        const uint32_t x = e0.x;
-        int32_t s = (int32_t)P[EF_S][slot];
-        row_of(slot)[s] = (int64_t)x;
-        ++s;
-        P[EF_S][slot] = (uint32_t)s;
-        const uint32_t left = P[EF_PREV][slot];
-        const bool tnonb = left == pad ? pad >= (uint32_t)n_nodes : P[EF_CNT][slot] <= 1u;
-        P[EF_T][slot] = left;
-        P[EF_PREV][slot] = x;
-        if (s > L) {
-            to_free = true;
-            return -1;
-        }
-        if (x == pad) {
-            P[EF_FLAGS][slot] = tnonb ? kEfTNoNb : 0u;
+        if (!with_entry || node == pad) {
+            P[EF_FLAGS][slot] = tnonb ? kEfTNoNb : 0u;  // (no rejections yet at the new step)
             return arrive_bare(slot);
         }
         P[EF_FIRST][slot] = e0.y;
@@ -770,7 +779,8 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
         P[EF_NB3][slot] = e1.w;
         P[EF_TM][slot] = e2.x;
         P[EF_FLAGS][slot] = (e0.w & kEfFromEntry) | (tnonb ? kEfTNoNb : 0u);
-        return classify(slot, e2.y, true);
+        only_tail = e2.y;
+        return 2;
     };
 
     while (true) {
@@ -780,21 +790,31 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
 #endif
         {
             bool to_trial = false, to_issue = false, to_free = false;
+            // The gathers are waited for HERE, once: left to the compiler, every branch below that reads e0..e2 got its
+            // own `s_waitcnt vmcnt(0)`, behind the column stores of the branches before it -- a store's round trip
+            // exposed two or three times per pass.  (An s_waitcnt the compiler can see: it knows e0..e2 are there.)
+            const uint64_t t_wait = kCount ? clock64() : 0;
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
             if (kCount) {  // how many gathers of each kind were consumed (status[12 + kind]) and in how many passes ([19])
+                w_wait += clock64() - t_wait;
 #pragma unroll
                 for (uint32_t k = 0; k < 7u; ++k) w_kind[k] += (uint64_t)__popcll(__ballot(hold && hkind == k));
                 ++w_kind[7];
             }
             if (hold) {
                 const uint32_t slot = hs;
-                int where = -1;  // 0 trial queue, 1 issue queue, -1 neither (freed)
+                int where = -1;  // 0 trial queue, 1 issue queue, -1 neither (freed), 2 classify pending
+                // what the kind's branch decided: 0 nothing more, 1 step onto the entry in e0..e2, 2 step to `bare` without one
+                int act = 0;
+                uint32_t bare = 0u, only_tail = 0u;
                 const uint32_t flags = P[EF_FLAGS][slot];
                 if (hkind == EK_RANGE) {  // e0 = {first, last, flags, only tail} of PREV
                     const uint32_t first = e0.x, cnt = first == kNoEdge ? 0u : e0.y - e0.x + 1u;
                     if (P[EF_S][slot] == 1u) {  // the first step samples a neighbour of the start node outright (:188)
                         P[EF_CNT][slot] = cnt;  // (the start node becomes t: step_* looks at this)
                         if (cnt == 0u) {
-                            where = step_bare(slot, pad, to_free);
+                            act = 2;
+                            bare = pad;
                         } else {
                             uint32_t idx = 0u;
                             if (cnt > 1u) {  // draw 0 (a single edge is taken without a draw, cpu_utils.cpp:4-5)
@@ -818,12 +838,14 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
                         P[EF_NB0][slot] = P[EF_NB1][slot] = P[EF_NB2][slot] = P[EF_NB3][slot] = fill;
                         P[EF_TM][slot] = fill;
                         P[EF_FLAGS][slot] = (flags & (kEfRej | kEfTNoNb)) | (plain ? 0u : (kEfFilter | kEfTmLook));
-                        where = classify(slot, e0.w, true);
+                        only_tail = e0.w;
+                        where = 2;
                     }
                 } else if (hkind == EK_ENTRY) {
-                    where = step_entry(slot, to_free);
+                    act = 1;
                 } else if (hkind == EK_NOENTRY) {
-                    where = step_bare(slot, P[EF_X][slot], to_free);
+                    act = 2;
+                    bare = P[EF_X][slot];
                 } else if (hkind == EK_PEEK) {  // e0.x = the only tail of PREV
                     const uint32_t x = e0.x, t = P[EF_T][slot];
                     if (x == pad) {
@@ -852,16 +874,17 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
                     else if (!nb_bit || (flags & kEfTNoNb)) verdict = band_takes_near ? 0 : 1;
                     else verdict = 3;
                     if (verdict == 1) {
-                        where = step_entry(slot, to_free);
+                        act = 1;
                     } else if (verdict == 2) {
-                        where = step_bare(slot, P[EF_JUMP][slot], to_free);
+                        act = 2;
+                        bare = P[EF_JUMP][slot];
                     } else if (verdict == 3) {
                         P[EF_X][slot] = x;
                         set_kind(slot, flags, EK_MEMBER);
                         where = 1;
                     } else if (reject(slot)) {
                         st |= (uint32_t)kStTrialCap;
-                        where = step_entry(slot, to_free);
+                        act = 1;
                     } else {
                         set_kind(slot, flags, 0u);
                         where = 0;
@@ -909,6 +932,8 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
                         }
                     }
                 }
+                if (act) where = step_to(slot, act == 1 ? e0.x : bare, act == 1, to_free, only_tail);
+                if (where == 2) where = classify(slot, only_tail, true);
                 to_trial = where == 0;
                 to_issue = where == 1;
             }
@@ -921,7 +946,7 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
         lap(0);
 
         // ================= refill =================
-        if (more_walkers && (free_q.count >= 32u || trial_q.count + issue_q.count < 64u) && free_q.count > 0u) {
+        if (more_walkers && (free_q.count >= (uint32_t)TRW_EL_REFILL_MIN || trial_q.count + issue_q.count < 64u) && free_q.count > 0u) {
             uint32_t n, slot;
             const uint32_t avail = free_q.count < 64u ? free_q.count : 64u;
             long long base = 0;
@@ -977,25 +1002,28 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
         if (!more_walkers && free_q.count == (uint32_t)kElSlots) break;
 
         // ================= issue =================
-        if (issue_q.count >= kPoolIssueMin || (issue_q.count > 0u && trial_q.count < kPoolTrialMin)) {
+        if (issue_q.count >= (uint32_t)TRW_EL_ISSUE_MIN || (issue_q.count > 0u && trial_q.count < (uint32_t)TRW_EL_TRIAL_MIN)) {
             uint32_t n, slot;
             issue_q.pop(lane, n, slot);
             if ((uint32_t)lane < n) {
                 const uint32_t flags = P[EF_FLAGS][slot];
                 const uint32_t kind = (flags & kEfKind) >> kEfKindShift;
-                if (kind == EK_ENTRY || kind == EK_TEST || kind == EK_PEEK) {
-                    const uint32_t *addr = reinterpret_cast<const uint32_t *>(ent + 4 * (size_t)P[EF_AT][slot]);
-                    e0 = *reinterpret_cast<const u32x4_a4 *>(addr);
-                    if (kind != EK_PEEK) {
-                        e1 = *reinterpret_cast<const u32x4_a4 *>(addr + 4);
-                        e2 = *reinterpret_cast<const u32x4_a4 *>(addr + 8);
-                    }
-                } else if (kind == EK_RANGE) {
-                    e0 = *reinterpret_cast<const u32x4_a4 *>(nd + P[EF_PREV][slot]);
-                } else if (kind == EK_MEMBER || kind == EK_FIXNB) {
-                    const uint32_t s0 = edge_hash(P[EF_T][slot], P[EF_X][slot]);
-                    e0 = *reinterpret_cast<const u32x4_a4 *>(table + 4 * (size_t)((s0 + (flags >> kEfProbeShift)) & mask));
-                }  // EK_NOENTRY: nothing to load
+                // ONE address and ONE load instruction for all kinds of gather: loads of the three kinds issued from three
+                // branches wrote the same registers under different lane masks, and the compiler put a full
+                // `s_waitcnt vmcnt(0)` between them -- two memory latencies exposed in every iteration.
+                const uint32_t at = P[EF_AT][slot], prev = P[EF_PREV][slot], t = P[EF_T][slot], x = P[EF_X][slot];
+                const bool from_ent = kind == EK_ENTRY || kind == EK_TEST || kind == EK_PEEK;
+                const bool from_tab = kind == EK_MEMBER || kind == EK_FIXNB;
+                const uint32_t tslot = (edge_hash(t, x) + (flags >> kEfProbeShift)) & mask;
+                const char *base = from_ent ? reinterpret_cast<const char *>(ent)
+                                            : (from_tab ? reinterpret_cast<const char *>(table) : reinterpret_cast<const char *>(nd));
+                const uint64_t off = from_ent ? (uint64_t)at << 6 : (uint64_t)(from_tab ? tslot : prev) << 4;
+                const uint32_t *addr = reinterpret_cast<const uint32_t *>(base + off);
+                if (kind != EK_NOENTRY) e0 = *reinterpret_cast<const u32x4_a4 *>(addr);
+                if (kind == EK_ENTRY || kind == EK_TEST) {
+                    e1 = *reinterpret_cast<const u32x4_a4 *>(addr + 4);
+                    e2 = *reinterpret_cast<const u32x2_a4 *>(addr + 8);
+                }
                 hold = true;
                 hs = slot;
                 hkind = kind;
@@ -1007,7 +1035,7 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
 #if TRW_POOL_PRIO
         __builtin_amdgcn_s_setprio(TRW_POOL_PRIO == 1 ? 0 : 3);
 #endif
-        if (trial_q.count >= kPoolTrialMin || (trial_q.count > 0u && issue_q.count < kPoolIssueMin)) {
+        if (trial_q.count >= (uint32_t)TRW_EL_TRIAL_MIN || (trial_q.count > 0u && issue_q.count < (uint32_t)TRW_EL_ISSUE_MIN)) {
             uint32_t n, slot;
             trial_q.pop(lane, n, slot);
             if (kCount) {
@@ -1015,6 +1043,92 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
                 w_burst_lanes += n;
             }
             const bool busy = (uint32_t)lane < n;
+#if TRW_EL_BURST2
+            // Straight-line form (round 3, cf. the burst of biased_pool_kernel): the slot's state, the eight draws the four
+            // trials of a visit can consume and the four mask words they index are each read from LDS in ONE batch, the four
+            // trials are evaluated side by side, and the first one that ends the visit is picked afterwards -- three LDS round
+            // trips per visit where the loop made three per TRIAL, and no exec-mask regions.
+            const uint32_t first = P[EF_FIRST][slot], cnt = P[EF_CNT][slot];
+            FastMod fm;
+            fm.d = busy && cnt ? cnt : 1u;
+            fm.z = P[EF_Z][slot];
+            const uint32_t tm = P[EF_TM][slot];
+            const uint32_t flags = P[EF_FLAGS][slot];
+            const bool fixed = (flags & kEfFixed) != 0u, filter = (flags & kEfFilter) != 0u;
+            const bool tm_offset = (flags & kEfTmOffset) != 0u, tm_look = (flags & kEfTmLook) != 0u;
+            const bool tnonb = (flags & kEfTNoNb) != 0u;  // nothing is a neighbour of t: every nb bit reads as clear
+            const uint32_t aux = P[EF_AUX][slot];
+            uint32_t rejected = (flags & kEfRej) >> kEfRejShift;
+            const uint32_t d0 = busy ? P[EF_D][slot] : 0u;
+            const uint64_t gw = (uint64_t)walker_base + (uint64_t)P[EF_WALKER][slot];
+            // the window of draws: positions 0..3 are the slot's block (C0..C3, the block of the last draw consumed),
+            // 4..11 the next two blocks, worked out here
+            const uint32_t cb = d0 ? (d0 - 1u) >> 2 : 0u;
+            {
+                uint32_t nbk[4];
+                philox4x32_10_keyed((uint32_t)gw, (uint32_t)(gw >> 32), cb + 1u, 0u, key_r, nbk);
+                W[0][lane] = nbk[0];
+                W[1][lane] = nbk[1];
+                W[2][lane] = nbk[2];
+                W[3][lane] = nbk[3];
+                philox4x32_10_keyed((uint32_t)gw, (uint32_t)(gw >> 32), cb + 2u, 0u, key_r, nbk);
+                W[4][lane] = nbk[0];
+                W[5][lane] = nbk[1];
+                W[6][lane] = nbk[2];
+                W[7][lane] = nbk[3];
+            }
+            const uint32_t pos0 = d0 - 4u * cb;  // next draw inside the window (0..4)
+            uint32_t dr[8];  // draws pos0 .. pos0 + 7 of the window
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t w = pos0 + (uint32_t)j;
+                const uint32_t *src = (j >= 4 || w >= 4u) ? &W[w - 4u][lane] : &P[EF_C0 + (int)w][slot];
+                dr[j] = *src >> 1;
+            }
+            const uint32_t need = fixed ? 1u : 2u;
+            uint32_t vk[4], idxk[4], nbwk[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                idxk[k] = fm.mod31(dr[2 * k]);
+                nbwk[k] = P[EF_NB0 + (int)((idxk[k] >> 5) & 3u)][slot];  // (by address: cf. biased_pool_kernel)
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t ru = dr[2 * k + 1], idx = idxk[k], sh = idx & 31u;
+                const bool nbb = !tnonb && ((nbwk[k] >> sh) & 1u);
+                const bool tmb = tm_offset ? idx == tm : ((tm >> sh) & 1u) != 0u;  // (a plain mask only describes ranges <= 32)
+                const uint32_t v_band = nbb ? (filter ? 2u : v_set) : v_clear;
+                const uint32_t v_cls = ru < bp.lo ? 1u : (ru >= bp.hi ? 0u : v_band);
+                // the offset may hold t: exact -> the reference's first test, then its class; otherwise look
+                const uint32_t v_t = tm_look ? 2u : ((ru < bp.t0) ? 1u : v_cls);
+                const uint32_t v_free = tmb ? v_t : v_cls;
+                const uint32_t v_fixed = dr[k] < aux ? 1u : 0u;  // a fixed candidate consumes ONE draw per trial
+                vk[k] = fixed ? v_fixed : v_free;
+            }
+            uint32_t verdict = 0u, at = 0u, ru_keep = 0u, used = 0u;
+            bool done = !busy;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool take = !done;
+                const uint32_t rj = vk[k] == 0u ? rejected + 1u : rejected;
+                const bool capped = rj >= kTrialCap;
+                if (take && capped) st |= (uint32_t)kStTrialCap;
+                const uint32_t v = capped ? 1u : vk[k];
+                rejected = take ? rj : rejected;
+                verdict = take ? v : verdict;
+                at = take ? first + idxk[k] : at;
+                ru_keep = take ? dr[2 * k + 1] : ru_keep;
+                used = take ? (uint32_t)(k + 1) : used;
+                done = done || v != 0u;
+                if (kCount) {
+                    const unsigned long long ran = __ballot(take);
+                    w_reps += ran != 0ull ? 1u : 0u;
+                    w_rep_lanes += (uint64_t)__popcll(ran);
+                    if (take) ++n_trials;
+                }
+            }
+            const uint32_t pos = pos0 + need * used;
+#else
             const uint32_t first = P[EF_FIRST][slot], cnt = P[EF_CNT][slot];
             FastMod fm;
             fm.d = busy && cnt ? cnt : 1u;
@@ -1099,6 +1213,7 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
                     running = v == 0u;
                 }
             }
+#endif
             bool to_issue = false, to_trial = false, to_free = false;
             if (busy) {
                 // the block of the last draw consumed becomes the slot's block
@@ -1116,7 +1231,8 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
                 if (verdict == 0u) {
                     to_trial = true;
                 } else if (fixed && P[EF_AT][slot] == kNoEdge) {  // taken without an entry (padding / jump): no gather, step now
-                    const int where = step_bare(slot, P[EF_X][slot], to_free);
+                    uint32_t unused_tail = 0u;
+                    const int where = step_to(slot, P[EF_X][slot], false, to_free, unused_tail);
                     to_trial = where == 0;
                     to_issue = where == 1;
                 } else if (fixed) {  // the fixed candidate is taken through its entry
@@ -1146,6 +1262,7 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
             const uint64_t w[8] = {w_cycles[0], w_cycles[1], w_cycles[2], w_cycles[3], w_bursts, w_burst_lanes, w_reps, w_rep_lanes};
             for (int k = 0; k < 8; ++k) atomicAdd((unsigned long long *)&status[20 + k], (unsigned long long)w[k]);
             for (int k = 0; k < 8; ++k) atomicAdd((unsigned long long *)&status[12 + k], (unsigned long long)w_kind[k]);
+            atomicAdd((unsigned long long *)&status[28], (unsigned long long)w_wait);
             atomicAdd((unsigned long long *)&status[4], (unsigned long long)a);
             atomicAdd((unsigned long long *)&status[5], (unsigned long long)b);
             atomicAdd((unsigned long long *)&status[6], (unsigned long long)c);
