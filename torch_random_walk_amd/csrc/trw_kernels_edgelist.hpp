@@ -1230,7 +1230,7 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
                 P[EF_FLAGS][slot] = low | (rejected << kEfRejShift);
                 if (verdict == 0u) {
                     to_trial = true;
-                } else if (fixed && P[EF_AT][slot] == kNoEdge) {  // taken without an entry (padding / jump): no gather, step now
+                } else if (fixed && P[EF_AT][slot] == kNoEdge) {  // taken without an entry (padding / jump): no gather
                     uint32_t unused_tail = 0u;
                     const int where = step_to(slot, P[EF_X][slot], false, to_free, unused_tail);
                     to_trial = where == 0;
