@@ -2468,6 +2468,9 @@ biased_glibc_wave_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__
                 const uint32_t v_other = ru < bp.lo ? 1u : (ru >= bp.hi ? 0u : v_band);
                 const uint32_t verdict = (idx - pos_lo < pos_cnt) ? (ru < bp.t0 ? 1u : 0u) : v_other;
                 unsigned long long accepts = __ballot(verdict == 1u), tests = __ballot(verdict == 2u);
+                // (a use of the entry's second half HERE: it is only needed once the winner is known, and the compiler had
+                // moved its load down there -- a second, dependent round trip per step, if only to the L1)
+                asm volatile("" ::"v"(c1.x), "v"(c1.y), "v"(c1.z), "v"(c1.w));
                 while (true) {  // settle the filter-only trials that come before the first definite accept
                     const int fa = accepts ? (int)__ffsll((long long)accepts) - 1 : 64;
                     const unsigned long long before = fa >= 64 ? ~0ull : ((1ull << fa) - 1ull);
