@@ -29,4 +29,7 @@ hipcc --offload-arch=gfx950 -O3 -o /tmp/alu_probe2 scripts/alu_probe2.hip && tim
 timeout -k 10 300 python3 scripts/time_small_batch.py 2>&1 | grep -v amdgpu.ids > gpurun_out/collected/${TAG}_small_batches.txt
 timeout -k 10 300 python3 scripts/time_windows.py 2>&1 | grep -v amdgpu.ids > gpurun_out/collected/${TAG}_time_windows.txt
 timeout -k 10 300 python3 scripts/tune_biased.py --what 14 --runs 5 --count 2>&1 | grep -v amdgpu.ids > gpurun_out/collected/${TAG}_pool_phases.txt
+# the edge-list pool: phases of the bench batch (one walker per node), and of a batch four times as long (the drain of the
+# pools at the end of a batch is a quarter as heavy there)
+{ timeout -k 10 300 python3 scripts/tune_elist.py --runs 5 --count --tag "1 walker per node" 2>&1; timeout -k 10 300 python3 scripts/tune_elist.py --runs 4 --count --walkers-mult 4 --tag "4 walkers per node" 2>&1; } | grep -v amdgpu.ids > gpurun_out/collected/${TAG}_elist_pool_phases.txt
 du -sh gpurun_out

@@ -15,6 +15,7 @@ ap.add_argument("--L", type=int, default=80)
 ap.add_argument("--env", nargs="*", default=[])
 ap.add_argument("--tag", default="")
 ap.add_argument("--count", action="store_true")
+ap.add_argument("--walkers-mult", type=int, default=1, help="walkers per node (the drain of the pools at the end of a batch weighs less in a longer one)")
 args = ap.parse_args()
 for kv in args.env:
     k, v = kv.split("=", 1)
@@ -46,18 +47,19 @@ heads = torch.repeat_interleave(torch.arange(n, device=dev), rp[1:] - rp[:-1])
 keep = ci != (heads + 1) % n
 index, edges = utils.build_node_edge_index(torch.stack([heads[keep], ci[keep]], 1), torch.arange(n, device=dev))
 E_ = edges.shape[0]
-tg = torch.arange(n, device=dev)
+tg = torch.arange(n, device=dev).repeat(args.walkers_mult)
+nw = int(tg.numel())
 stream = torch.cuda.current_stream().cuda_stream
-nb = L.trw_walk_edge_list_workspace_bytes(E_, n, n, args.L, n, 2)
+nb = L.trw_walk_edge_list_workspace_bytes(E_, n, nw, args.L, n, 2)
 ws = torch.empty(nb, dtype=torch.uint8, device=dev)
-out = torch.empty((n, args.L + 1), dtype=torch.int64, device=dev)
+out = torch.empty((nw, args.L + 1), dtype=torch.int64, device=dev)
 L.trw_profile_enable(1)
 pre, wk = [], []
 chk = None
 for r in range(args.runs):
     if args.count and r == args.runs - 1:
         L.trw_profile_enable(3)
-    rc = L.trw_walk_edge_list_hip(edges.data_ptr(), E_, index.data_ptr(), n, tg.data_ptr(), n, 0, 0.25, 4.0, args.L, 10, n, 1, 2,
+    rc = L.trw_walk_edge_list_hip(edges.data_ptr(), E_, index.data_ptr(), n, tg.data_ptr(), nw, 0, 0.25, 4.0, args.L, 10, n, 1, 2,
                                   out.data_ptr(), ws.data_ptr(), nb, stream)
     assert rc == 0, L.trw_last_error()
     a, b, c = dbl(), dbl(), dbl()
@@ -71,7 +73,7 @@ st = (i64 * 4)()
 L.trw_walk_status(ws.data_ptr(), stream, st)
 if args.count:
     raw = ws[:256].view(torch.int64).cpu().tolist()
-    steps = n * args.L
+    steps = nw * args.L
     names = ["RANGE", "ENTRY", "TEST", "MEMBER", "FIXNB", "PEEK", "NOENTRY"]
     print("   per step: trials %.2f fetch %.3f tests %.3f probes %.3f | gathers consumed by kind: %s | wave iterations %.3e" % (
         raw[4] / steps, raw[5] / steps, raw[6] / steps, raw[7] / steps,
