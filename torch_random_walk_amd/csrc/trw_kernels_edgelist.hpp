@@ -585,6 +585,33 @@ static_assert(kTrialCap <= (kEfRej >> kEfRejShift), "the rejection count must fi
 // what of an entry's flag word a slot keeps
 constexpr uint32_t kEfFromEntry = kElFilter | kElTmOffset | kElTmLook;
 
+// (a macro, not a lambda: called from two places a lambda was not inlined and its captures went to scratch memory)
+#define TRW_EL_ISSUE_PASS() \
+    do { \
+                uint32_t n, slot; \
+                issue_q.pop(lane, n, slot); \
+                if ((uint32_t)lane < n) { \
+                    const uint32_t flags = P[EF_FLAGS][slot]; \
+                    const uint32_t kind = (flags & kEfKind) >> kEfKindShift; \
+                    const uint32_t at = P[EF_AT][slot], prev = P[EF_PREV][slot], t = P[EF_T][slot], x = P[EF_X][slot]; \
+                    const bool from_ent = kind == EK_ENTRY || kind == EK_TEST || kind == EK_PEEK; \
+                    const bool from_tab = kind == EK_MEMBER || kind == EK_FIXNB; \
+                    const uint32_t tslot = (edge_hash(t, x) + (flags >> kEfProbeShift)) & mask; \
+                    const char *base = from_ent ? reinterpret_cast<const char *>(ent) \
+                                                : (from_tab ? reinterpret_cast<const char *>(table) : reinterpret_cast<const char *>(nd)); \
+                    const uint64_t off = from_ent ? (uint64_t)at << 6 : (uint64_t)(from_tab ? tslot : prev) << 4; \
+                    const uint32_t *addr = reinterpret_cast<const uint32_t *>(base + off); \
+                    if (kind != EK_NOENTRY) e0 = *reinterpret_cast<const u32x4_a4 *>(addr); \
+                    if (kind == EK_ENTRY || kind == EK_TEST) { \
+                        e1 = *reinterpret_cast<const u32x4_a4 *>(addr + 4); \
+                        e2 = *reinterpret_cast<const u32x2_a4 *>(addr + 8); \
+                    } \
+                    hold = true; \
+                    hs = slot; \
+                    hkind = kind; \
+                } \
+    } while (0)
+
 template <bool kCount>
 __global__ void __launch_bounds__(kBlock)
 elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict__ ent,
@@ -608,6 +635,13 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
 #endif
 #ifndef TRW_EL_TRIAL_MIN
 #define TRW_EL_TRIAL_MIN TRW_POOL_TRIAL_MIN
+#endif
+#ifndef TRW_EL_LATE_ISSUE
+#define TRW_EL_LATE_ISSUE 2  // 1: a second issue pass after the burst when no gather is held; 2: only once the batch has run
+                             // out (pools that drain: 6.83 -> 6.72 ms; always: 6.98)
+#endif
+#ifndef TRW_EL_SCALE_NUM
+#define TRW_EL_SCALE_NUM 0  // > 0: a pass waits for this many eighths of the RESIDENT walkers (a pool that drains)
 #endif
     constexpr int kWinOff = TRW_EL_WIN12 ? 0 : 4;  // window positions below this are read from the slot's C0..C3
     static_assert(!(TRW_EL_BURST2 && TRW_EL_WIN12), "the straight-line burst reads positions 0..3 from the slot");
@@ -1002,40 +1036,25 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
         if (!more_walkers && free_q.count == (uint32_t)kElSlots) break;
 
         // ================= issue =================
-        if (issue_q.count >= (uint32_t)TRW_EL_ISSUE_MIN || (issue_q.count > 0u && trial_q.count < (uint32_t)TRW_EL_TRIAL_MIN)) {
-            uint32_t n, slot;
-            issue_q.pop(lane, n, slot);
-            if ((uint32_t)lane < n) {
-                const uint32_t flags = P[EF_FLAGS][slot];
-                const uint32_t kind = (flags & kEfKind) >> kEfKindShift;
-                // ONE address and ONE load instruction for all kinds of gather: loads of the three kinds issued from three
-                // branches wrote the same registers under different lane masks, and the compiler put a full
-                // `s_waitcnt vmcnt(0)` between them -- two memory latencies exposed in every iteration.
-                const uint32_t at = P[EF_AT][slot], prev = P[EF_PREV][slot], t = P[EF_T][slot], x = P[EF_X][slot];
-                const bool from_ent = kind == EK_ENTRY || kind == EK_TEST || kind == EK_PEEK;
-                const bool from_tab = kind == EK_MEMBER || kind == EK_FIXNB;
-                const uint32_t tslot = (edge_hash(t, x) + (flags >> kEfProbeShift)) & mask;
-                const char *base = from_ent ? reinterpret_cast<const char *>(ent)
-                                            : (from_tab ? reinterpret_cast<const char *>(table) : reinterpret_cast<const char *>(nd));
-                const uint64_t off = from_ent ? (uint64_t)at << 6 : (uint64_t)(from_tab ? tslot : prev) << 4;
-                const uint32_t *addr = reinterpret_cast<const uint32_t *>(base + off);
-                if (kind != EK_NOENTRY) e0 = *reinterpret_cast<const u32x4_a4 *>(addr);
-                if (kind == EK_ENTRY || kind == EK_TEST) {
-                    e1 = *reinterpret_cast<const u32x4_a4 *>(addr + 4);
-                    e2 = *reinterpret_cast<const u32x2_a4 *>(addr + 8);
-                }
-                hold = true;
-                hs = slot;
-                hkind = kind;
-            }
+        uint32_t issue_min = (uint32_t)TRW_EL_ISSUE_MIN, trial_min = (uint32_t)TRW_EL_TRIAL_MIN;
+        if (TRW_EL_SCALE_NUM > 0) {
+            const uint32_t resident = (uint32_t)kElSlots - free_q.count;
+            uint32_t cap = (resident * (uint32_t)TRW_EL_SCALE_NUM) >> 3;
+            cap = cap < 4u ? 4u : cap;
+            issue_min = issue_min < cap ? issue_min : cap;
+            trial_min = trial_min < cap ? trial_min : cap;
         }
+        // ONE address and ONE load instruction for all kinds of gather: loads of the three kinds issued from three
+        // branches wrote the same registers under different lane masks, and the compiler put a full
+        // `s_waitcnt vmcnt(0)` between them -- two memory latencies exposed in every iteration.
+        if (issue_q.count >= issue_min || (issue_q.count > 0u && trial_q.count < trial_min)) TRW_EL_ISSUE_PASS();
 
         lap(2);
         // ================= burst =================
 #if TRW_POOL_PRIO
         __builtin_amdgcn_s_setprio(TRW_POOL_PRIO == 1 ? 0 : 3);
 #endif
-        if (trial_q.count >= (uint32_t)TRW_EL_TRIAL_MIN || (trial_q.count > 0u && issue_q.count < (uint32_t)TRW_EL_ISSUE_MIN)) {
+        if (trial_q.count >= trial_min || (trial_q.count > 0u && issue_q.count < issue_min)) {
             uint32_t n, slot;
             trial_q.pop(lane, n, slot);
             if (kCount) {
@@ -1252,6 +1271,11 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
             free_q.push(to_free, slot);
             pool_fence();
         }
+#if TRW_EL_LATE_ISSUE
+        // nothing in flight and walkers waiting for a gather (a pool that drains, or one whose issue queue was short
+        // before the burst filled it): they leave now instead of an iteration later
+        if (__ballot(hold) == 0ull && issue_q.count > 0u && (TRW_EL_LATE_ISSUE == 1 || !more_walkers)) TRW_EL_ISSUE_PASS();
+#endif
         lap(3);
     }
 
