@@ -1295,4 +1295,6 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
     }
 }
 
+#undef TRW_EL_ISSUE_PASS
+
 }  // namespace

@@ -96,6 +96,14 @@ triples_walker_kernel(const u32x2_a8 *__restrict__ rt32, const u32x2_a8 *__restr
     const uint64_t gw = (uint64_t)walker_base + (uint64_t)i;
     uint32_t blk[4] = {0, 0, 0, 0};
     uint32_t d = 0;  // draws this walker has consumed
+    // A walker that has reached the padding id stays there: every later column of its row is the padding id.  Left to
+    // the ring those columns leave as one 64-byte piece per row and flush, scattered over the wave's 64 rows -- on a
+    // graph with sinks (the bench's: 12 live hops of 80 on average) they are most of what the kernel writes, at the
+    // memory system's RANDOM-access rate.  Instead the wave writes the rest of such a row at once, 512 contiguous bytes
+    // per store instruction, and the ring skips the row from then on.
+    bool filled = !live;  // rows that take nothing more from the ring
+    int64_t *const row0 = out + wave_walker0 * (int64_t)cols;
+    const int ln = (int)(threadIdx.x & 63);
     for (int32_t h = 0; h < L; ++h) {
         uint32_t rel = pad, tail = pad;
         if (live && node != pad) {
@@ -115,11 +123,20 @@ triples_walker_kernel(const u32x2_a8 *__restrict__ rt32, const u32x2_a8 *__restr
             }
         }
         const int32_t c = 2 * h + 1;
-        rows.put(c, live ? rel : kTileSkip);
+        rows.put(c, !filled ? rel : kTileSkip);
         if ((c & 7) == 7) rows.flush(wave_walker0, 1, n_walkers, cols, c, out);
-        rows.put(c + 1, live ? tail : kTileSkip);
+        rows.put(c + 1, !filled ? tail : kTileSkip);
         if (((c + 1) & 7) == 7 || c + 1 == cols - 1) rows.flush(wave_walker0, 1, n_walkers, cols, c + 1, out);
         node = tail;
+        // rows whose walker has just arrived on the padding id: columns c + 2 .. cols - 1, by the whole wave
+        unsigned long long fresh = __ballot(!filled && tail == pad && c + 2 < cols);
+        filled = filled || tail == pad;
+        while (fresh) {
+            const int r = (int)__ffsll((long long)fresh) - 1;
+            fresh &= fresh - 1ull;
+            int64_t *rowp = row0 + (int64_t)r * cols;
+            for (int32_t k = c + 2 + ln; k < cols; k += 64) rowp[k] = (int64_t)pad;
+        }
     }
 }
 
