@@ -621,12 +621,6 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
 {
     static_assert(kElSlots >= 64 && kElSlots <= kQueueCap, "pool size must be 64..128 slots");
     __shared__ uint32_t pool_mem[kPoolWaves][EF_COUNT][kElSlots];
-#ifndef TRW_EL_WIN12
-#define TRW_EL_WIN12 0
-#endif
-#ifndef TRW_EL_BURST2
-#define TRW_EL_BURST2 1
-#endif
 #ifndef TRW_EL_REFILL_MIN
 #define TRW_EL_REFILL_MIN 32  // free slots that trigger a claim of new walkers
 #endif
@@ -643,8 +637,7 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
 #ifndef TRW_EL_SCALE_NUM
 #define TRW_EL_SCALE_NUM 0  // > 0: a pass waits for this many eighths of the RESIDENT walkers (a pool that drains)
 #endif
-    constexpr int kWinOff = TRW_EL_WIN12 ? 0 : 4;  // window positions below this are read from the slot's C0..C3
-    static_assert(!(TRW_EL_BURST2 && TRW_EL_WIN12), "the straight-line burst reads positions 0..3 from the slot");
+    constexpr int kWinOff = 4;  // window positions below this are read from the slot's C0..C3, not from win_mem
     __shared__ uint32_t win_mem[kPoolWaves][kElWin - kWinOff][64];
     __shared__ uint8_t queue_mem[kPoolWaves][3][kQueueCap];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1062,7 +1055,6 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
                 w_burst_lanes += n;
             }
             const bool busy = (uint32_t)lane < n;
-#if TRW_EL_BURST2
             // Straight-line form (round 3, cf. the burst of biased_pool_kernel): the slot's state, the eight draws the four
             // trials of a visit can consume and the four mask words they index are each read from LDS in ONE batch, the four
             // trials are evaluated side by side, and the first one that ends the visit is picked afterwards -- three LDS round
@@ -1147,92 +1139,6 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
                 }
             }
             const uint32_t pos = pos0 + need * used;
-#else
-            const uint32_t first = P[EF_FIRST][slot], cnt = P[EF_CNT][slot];
-            FastMod fm;
-            fm.d = busy && cnt ? cnt : 1u;
-            fm.z = P[EF_Z][slot];
-            const uint32_t tm = P[EF_TM][slot];
-            const uint32_t flags = P[EF_FLAGS][slot];
-            const bool fixed = (flags & kEfFixed) != 0u, filter = (flags & kEfFilter) != 0u;
-            const bool tm_offset = (flags & kEfTmOffset) != 0u, tm_look = (flags & kEfTmLook) != 0u;
-            const bool tnonb = (flags & kEfTNoNb) != 0u;  // nothing is a neighbour of t: every nb bit reads as clear
-            const uint32_t aux = P[EF_AUX][slot];
-            uint32_t rejected = (flags & kEfRej) >> kEfRejShift;
-            const uint32_t d0 = P[EF_D][slot];
-            const uint64_t gw = (uint64_t)walker_base + (uint64_t)P[EF_WALKER][slot];
-            // the window of draws: positions 0..3 are the slot's block (C0..C3, the block of the last draw consumed),
-            // 4..11 the next two blocks, worked out here
-            const uint32_t cb = d0 ? (d0 - 1u) >> 2 : 0u;
-            if (TRW_EL_WIN12) {
-                W[0][lane] = P[EF_C0][slot];
-                W[1][lane] = P[EF_C1][slot];
-                W[2][lane] = P[EF_C2][slot];
-                W[3][lane] = P[EF_C3][slot];
-            }
-            if (busy) {
-                uint32_t nbk[4];
-                walker_block(gw, cb + 1u, seed, nbk);
-                W[4 - kWinOff][lane] = nbk[0];
-                W[5 - kWinOff][lane] = nbk[1];
-                W[6 - kWinOff][lane] = nbk[2];
-                W[7 - kWinOff][lane] = nbk[3];
-                walker_block(gw, cb + 2u, seed, nbk);
-                W[8 - kWinOff][lane] = nbk[0];
-                W[9 - kWinOff][lane] = nbk[1];
-                W[10 - kWinOff][lane] = nbk[2];
-                W[11 - kWinOff][lane] = nbk[3];
-            }
-            auto draw = [&](uint32_t w) {
-                if (TRW_EL_WIN12) return W[w][lane] >> 1;
-                return (w < 4u ? P[EF_C0 + (int)w][slot] : W[w - 4u][lane]) >> 1;
-            };
-            const uint32_t pos0 = d0 - 4u * cb;  // next draw inside the window (0..4)
-            uint32_t pos = pos0;
-            const uint32_t need = fixed ? 1u : 2u;
-            uint32_t verdict = 0u, at = 0u, ru_keep = 0u;
-            bool running = busy;
-#pragma unroll 1
-            for (int rep = 0; rep < 4; ++rep) {
-                running = running && pos + need <= (uint32_t)kElWin;
-                if (__ballot(running) == 0) break;
-                if (kCount) {
-                    ++w_reps;
-                    w_rep_lanes += (uint64_t)__popcll(__ballot(running));
-                }
-                if (running) {
-                    if (kCount) ++n_trials;
-                    uint32_t v;
-                    if (fixed) {
-                        const uint32_t ru = draw(pos);
-                        pos += 1u;
-                        v = ru < aux ? 1u : 0u;
-                    } else {
-                        const uint32_t rc = draw(pos), ru = draw(pos + 1u);
-                        pos += 2u;
-                        const uint32_t idx = fm.mod31(rc);
-                        const uint32_t sh = idx & 31u;
-                        const uint32_t nbw = P[EF_NB0 + (int)((idx >> 5) & 3u)][slot];  // (by address: cf. biased_pool_kernel)
-                        const bool nbb = !tnonb && ((nbw >> sh) & 1u);
-                        const bool tmb = tm_offset ? idx == tm : ((tm >> sh) & 1u) != 0u;  // (a plain mask only describes ranges <= 32)
-                        const uint32_t v_band = nbb ? (filter ? 2u : v_set) : v_clear;
-                        const uint32_t v_cls = ru < bp.lo ? 1u : (ru >= bp.hi ? 0u : v_band);
-                        // the offset may hold t: exact -> the reference's first test, then its class; otherwise look
-                        const uint32_t v_t = tm_look ? 2u : ((ru < bp.t0) ? 1u : v_cls);
-                        v = tmb ? v_t : v_cls;
-                        at = first + idx;
-                        ru_keep = ru;
-                    }
-                    rejected = v == 0u ? rejected + 1u : rejected;
-                    if (rejected >= kTrialCap) {
-                        st |= (uint32_t)kStTrialCap;
-                        v = 1u;
-                    }
-                    verdict = v;
-                    running = v == 0u;
-                }
-            }
-#endif
             bool to_issue = false, to_trial = false, to_free = false;
             if (busy) {
                 // the block of the last draw consumed becomes the slot's block

@@ -177,6 +177,11 @@ struct WaveRows {
 // flush) completed -- at most 8 per row -- go out: centre[w] = middle node, pos[w][0..ws-2] = the others.  A row's
 // new windows are ONE contiguous piece of `pos` (up to 8 * (ws-1) values), written by `lpr` adjacent lanes.
 // The ring holds 16 columns and a window started up to ws + 6 columns ago: window_size <= 9.
+#ifndef TRW_WIN_STORE16
+#define TRW_WIN_STORE16 1
+#endif
+typedef int64_t i64x2_a16 __attribute__((ext_vector_type(2)));
+
 struct WaveWindows {
     int32_t ws, mid, width, step_end;
     uint32_t lpr_shift;   // lanes per row = 1 << lpr_shift >= 8 * width
@@ -232,7 +237,34 @@ struct WaveWindows {
         if (width == 0) return;
         // ---- the rest of each window: a row's piece is nwin * width consecutive values
         int64_t *pbase = pos + (walker0 * step_end + w_lo) * width;
-        const uint32_t lpr = 1u << lpr_shift, rows_per_pass = 64u >> lpr_shift;
+        const uint32_t lpr = 1u << lpr_shift;
+#if TRW_WIN_STORE16
+        // An even width: a row's piece starts on a 16-byte boundary and holds an even number of values, so a lane
+        // takes TWO of them and stores 16 bytes -- half the store instructions per flush (the stores are what the
+        // fused kernel adds to the walk).
+        if ((width & 1) == 0 && ((uintptr_t)pos & 15u) == 0u) {
+            const uint32_t lpr2 = lpr >> 1, rows_per_pass = 128u >> lpr_shift;
+            const uint32_t q = (uint32_t)ln & (lpr2 - 1u), sub = (uint32_t)ln >> (lpr_shift - 1u);
+            const uint32_t f0 = 2u * q, f1 = f0 + 1u;
+            const uint32_t k0 = (f0 * inv_width) >> 16, i0 = f0 - k0 * (uint32_t)width;
+            const uint32_t k1 = (f1 * inv_width) >> 16, i1 = f1 - k1 * (uint32_t)width;
+            const uint32_t col0 = (uint32_t)w_lo + k0 + i0 + (i0 >= (uint32_t)mid ? 1u : 0u);
+            const uint32_t col1 = (uint32_t)w_lo + k1 + i1 + (i1 >= (uint32_t)mid ? 1u : 0u);
+            const bool mine = f0 < (uint32_t)nwin * (uint32_t)width;
+            for (uint32_t pass = 0; pass < lpr2; ++pass) {
+                const uint32_t row = pass * rows_per_pass + sub;
+                if (mine && row < (uint32_t)nrows) {
+                    const uint32_t v0 = rows.t[row * kTileStride + (col0 & (kTileCols - 1))];
+                    const uint32_t v1 = rows.t[row * kTileStride + (col1 & (kTileCols - 1))];
+                    if (v0 != kTileSkip)  // (a row is skipped as a whole)
+                        *reinterpret_cast<i64x2_a16 *>(pbase + row * row_windows * (uint32_t)width + f0) =
+                            i64x2_a16{(int64_t)v0, (int64_t)v1};
+                }
+            }
+            return;
+        }
+#endif
+        const uint32_t rows_per_pass = 64u >> lpr_shift;
         const uint32_t f = (uint32_t)ln & (lpr - 1u), sub = (uint32_t)ln >> lpr_shift;
         const uint32_t k = (f * inv_width) >> 16, i = f - k * (uint32_t)width;
         const uint32_t col = (uint32_t)w_lo + k + i + (i >= (uint32_t)mid ? 1u : 0u);
@@ -250,8 +282,6 @@ struct WaveWindows {
 // For kernels whose lanes advance at their own pace (the biased walks): the last (up to) four columns of
 // the lane's row wait in registers until they fill a 32-byte-aligned group of the caller's row, the
 // granule a partial HBM write costs anyway (one write request per four columns instead of one per column).
-typedef int64_t i64x2_a16 __attribute__((ext_vector_type(2)));
-
 struct RowCombiner {
     int64_t *sp;  // where the next column goes
     uint32_t wb0, wb1, wb2, wb3;
