@@ -1,8 +1,11 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: bench.py's N > 1 control flow with 2..4 gloo ranks on the one card (the numbers mean nothing; what
 # is checked is that every configuration prints its line and passes bench.py's own checks of the gathered blocks).
+# `--backend nccl` (on a node with as many GPUs as the largest --gpus below): the same matrix over RCCL, one rank per GPU.
+BACKEND=gloo
+if [ "$1" = "--backend" ]; then BACKEND=$2; fi
 run() {
-  timeout 300 python bench.py "$@" --backend gloo --steps 2 --warmup 1 --no-cpu-baseline > /tmp/o.json 2>/tmp/o.err; rc=$?
+  timeout 300 python bench.py "$@" --backend $BACKEND --steps 2 --warmup 1 --no-cpu-baseline > /tmp/o.json 2>/tmp/o.err; rc=$?
   python - "$*" $rc <<'PY'
 import json, sys
 lines = [ln for ln in open("/tmp/o.json") if ln.startswith("{")]

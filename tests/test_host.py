@@ -144,6 +144,48 @@ def test_sharded_walk_equals_single_shot_gloo(tmp_path, gather, wire, chunks, p,
         assert torch.equal(r1, full[259:])
 
 
+def _gloo_fault_worker(rank, world, port, gather, chunks, bad_rank, outdir):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from torch_random_walk_amd import graphs
+    from torch_random_walk_amd.dist import walk_sharded
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world,
+                            timeout=__import__("datetime").timedelta(seconds=60))
+    rp, ci = graphs.rmat(300, 2000, seed=4)
+    tg = torch.arange(300).repeat(2)[:517]
+    calls = [0]
+
+    def faulty_walk(row_ptr, col_idx, targets, p, q, walk_length, seed, walker_base=0, rng_mode=0):
+        calls[0] += 1
+        if rank == bad_rank and calls[0] == min(2, chunks):   # in the MIDDLE of the chunk loop when there is one
+            raise RuntimeError("node 7 has no neighbours (injected)")
+        return torch.from_numpy(O.walk(row_ptr.numpy(), col_idx.numpy(), targets.numpy(), p, q, walk_length, seed,
+                                       rng_mode=O.RNG_WALKER, walker_base=walker_base))
+
+    try:
+        walk_sharded(rp, ci, tg, 0.25, 4.0, 11, 42, gather=gather, walk_fn=faulty_walk, chunks=chunks)
+        verdict = "returned"
+    except RuntimeError as e:
+        verdict = "raised: %s" % e
+    with open(os.path.join(outdir, "r%d.txt" % rank), "w") as f:
+        f.write(verdict)
+    dist.barrier()   # both ranks are still in step: nobody is stranded in a receive
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("gather,chunks,bad_rank", [("root", 4, 1), ("root", 4, 0), ("root", 1, 1), ("all", 1, 1)])
+def test_sharded_walk_fault_reaches_every_rank_gloo(tmp_path, gather, chunks, bad_rank):
+    """a walk that raises in the middle of the chunk loop must neither strand the other rank in its
+    receives nor let the faulty block pass for a result anywhere: both ranks finish the transfers, both raise --
+    the owner its own error, the other one a RuntimeError naming the faulty rank."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_gloo_fault_worker, args=(2, port, gather, chunks, bad_rank, str(tmp_path)), nprocs=2, join=True)
+    got = [open(os.path.join(tmp_path, "r%d.txt" % r)).read() for r in range(2)]
+    assert "injected" in got[bad_rank], got
+    assert got[1 - bad_rank].startswith("raised") and "rank(s) %d" % bad_rank in got[1 - bad_rank], got
+
+
 def test_wire_format_round_trip_and_bounds():
     """uint32 wire format of the gather (include/trw.h trw_rows_narrow_cpu / _widen_cpu through the extension):
     round trip over the whole uint32 range, any shape / alignment, overflow reported in strict mode only."""

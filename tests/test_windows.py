@@ -325,6 +325,34 @@ def test_walk_windows_host_composition_equals_two_calls():
         rw.walk_windows(rp, ci, tg, 1.0, 1.0, 20, 7, 22, 300)
 
 
+def _walk_windows_follows_rng_mode(device):
+    """walk_windows resolves the walk's stream as rw.walk does -- under set_rng_mode(RNG_WALKER) a uniform
+    walk is the per-walker Philox stream in BOTH forms, and differs from the libc stream."""
+    from torch_rw import rw
+    rp, ci = _small_graph(300, 2000, 4, device)
+    tg = torch.arange(300, device=device).repeat(2)[:431]
+    glibc = rw.walk_windows(rp, ci, tg, 1.0, 1.0, 20, 7, 5, 300, return_walks=True)
+    old = rw.get_rng_mode()
+    rw.set_rng_mode(rw.RNG_WALKER)
+    try:
+        got = rw.walk_windows(rp, ci, tg, 1.0, 1.0, 20, 7, 5, 300, return_walks=True)
+        walks = rw.walk(rp, ci, tg, 1.0, 1.0, 20, 7)
+        ref = rw.to_windows(walks, 5, 300, 7)
+    finally:
+        rw.set_rng_mode(old)
+    assert torch.equal(got[3], walks) and all(torch.equal(a, b) for a, b in zip(got[:3], ref))
+    assert not torch.equal(got[3], glibc[3]) and torch.equal(got[2], glibc[2])   # other walks, same negatives
+
+
+def test_walk_windows_follows_the_process_rng_mode_host():
+    _walk_windows_follows_rng_mode("cpu")
+
+
+@pytest.mark.gpu
+def test_gpu_walk_windows_follows_the_process_rng_mode():
+    _walk_windows_follows_rng_mode(DEV)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("L,ws", [(80, 5), (80, 1), (80, 2), (80, 9), (80, 10), (7, 8), (8, 9), (6, 3), (15, 4), (16, 7),
                                   (1, 2), (23, 8), (3, 4), (9, 9)])
@@ -397,3 +425,56 @@ def test_gpu_walk_windows_full_size():
     for a, b in zip(got, ref):
         assert torch.equal(a, b)
     assert got[0].shape == (77 * n,) and got[1].shape == (77 * n, 4)
+
+
+@pytest.mark.gpu
+def test_gpu_side_stream_lanes_capture_beside_another_thread():
+    """the side stream of the window builders is a pool of lanes now -- while one thread captures a
+    to_windows call into a HIP graph (its lane's stream is part of that capture until it ends), another thread's
+    plain call gets ANOTHER lane: it neither fails with a capture-isolation error nor lands in the first thread's
+    graph, and the graph replays to the same windows afterwards."""
+    import threading
+    from torch_rw import rw
+    n = 3000
+    rp, ci = _small_graph(n, 24000, 9, DEV)
+    tg = torch.arange(n, device=DEV).repeat(4)
+    walks = rw.walk(rp, ci, tg, 1.0, 1.0, 40, 5)
+    ref = rw.to_windows(walks, 5, n, 5)                 # (also makes the first lane, outside any capture)
+    other_walks = rw.walk(rp, ci, tg[:5000], 1.0, 1.0, 30, 6)
+    other_ref = rw.to_windows(other_walks, 4, n, 6)
+    torch.cuda.synchronize()
+    errors, got_other = [], []
+
+    def plain_call():
+        try:
+            s2 = torch.cuda.Stream()
+            with torch.cuda.stream(s2):
+                for _ in range(3):
+                    got_other.append(rw.to_windows(other_walks, 4, n, 6))
+            s2.synchronize()
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        rw.to_windows(walks, 5, n, 5)                   # warm the allocator on the capture stream
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        cap = rw.to_windows(walks, 5, n, 5)
+        t = threading.Thread(target=plain_call)         # runs while the capture is still open
+        t.start()
+        t.join()
+        cap2 = rw.to_windows(walks, 5, n, 5)            # a second call of the SAME capture reuses the capture's lane
+    assert not errors, errors
+    for got in got_other:
+        assert all(torch.equal(a, b) for a, b in zip(got, other_ref))
+    for _ in range(3):
+        for x in cap + cap2:
+            x.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(cap, ref)) and all(torch.equal(a, b) for a, b in zip(cap2, ref))
+    again = rw.to_windows(walks, 5, n, 5)               # and the lanes are usable after the capture has ended
+    assert all(torch.equal(a, b) for a, b in zip(again, ref))

@@ -780,13 +780,17 @@ walk_windows(const torch::Tensor &row_ptr, const torch::Tensor &col_idx, const t
     TORCH_CHECK(seed >= INT32_MIN && seed <= INT32_MAX && window_seed >= INT32_MIN && window_seed <= INT32_MAX &&
                     walk_length < (int64_t(1) << 31), "walk_length/seed must fit the reference's int arguments");
     const bool uniform = p == 1.0 && q == 1.0;
-    const int64_t rng = uniform ? (int64_t)TRW_RNG_GLIBC : (int64_t)g_rng_mode.load();
+    // the walk's stream is resolved exactly as rw.walk resolves it (process-wide mode; AUTO -> the reference's libc
+    // stream for a uniform walk), so that "what the two calls give" holds under set_rng_mode(RNG_WALKER) too (ADVICE
+    // r03): the fused kernel IS the reference-exact uniform walk, any other stream runs as the two calls
+    const int64_t rng = (int64_t)g_rng_mode.load();
+    const bool glibc_uniform = uniform && (rng == TRW_RNG_AUTO || rng == TRW_RNG_GLIBC);
     auto composed = [&]() {
         auto walks = walk_ex(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, walker_base, rng, check, c10::nullopt);
         auto w = windows_impl(walks, window_size, num_nodes, window_seed, false, walker_base, TRW_RNG_GLIBC);
         return std::make_tuple(std::get<0>(w), std::get<1>(w), std::get<2>(w), return_walks ? walks : torch::Tensor());
     };
-    if (!row_ptr.is_cuda() || !uniform) return composed();
+    if (!row_ptr.is_cuda() || !glibc_uniform) return composed();
     check_index_tensor(row_ptr, "row_ptr");
     check_index_tensor(col_idx, "col_idx");
     check_index_tensor(target_nodes, "target_nodes");

@@ -1111,42 +1111,97 @@ int trw_walk_edge_list_hip(const int64_t *edges, int64_t n_edges, const int64_t 
 
 // ---- window builders, reference csrc/cpu/windows_cpu.cpp ------------------------------------------
 
-// A second stream per device for work that does not depend on the call's main kernel (the negatives of the window
-// builders: glibc's stream modulo num_nodes, write-bound) so that it runs BESIDE it (the walk: bound by gather
-// latency; the window gather: its own store stream): fork() makes the side stream wait for everything queued on the
-// caller's stream so far, join() makes the caller's stream wait for the side work.  Event-based fork / join is what a
-// stream capture records as graph dependencies, so a captured call replays with the same overlap.
+// A second stream for work that does not depend on the call's main kernel (the negatives of the window builders:
+// glibc's stream modulo num_nodes, write-bound) so that it runs BESIDE it (the walk: bound by gather latency; the window
+// gather: its own store stream): side_begin() makes the side stream wait for everything queued on the caller's stream up
+// to side_mark(), side_join() makes the caller's stream wait for the side work.  Event-based fork / join is what a stream
+// capture records as graph dependencies, so a captured call replays with the same overlap.
+//
+// Lanes.  A side stream, its fork event and its join event form a LANE; a device keeps a small pool of
+// them, made once and reused (no stream or event is created or destroyed per call).  A call holds its lane from
+// side_mark() to side_join(), so two host threads never share one.  A stream that a capture has pulled in stays in that
+// capture until it ends -- so a lane is only handed to a call whose own stream is in the SAME capture state (both not
+// capturing, or both in the capture with the same id): a thread that is not capturing never launches into somebody
+// else's graph.  A capturing call that finds no lane of its own capture and no idle one stays in line (the work is
+// queued on the caller's stream: same result, no overlap) rather than create a stream in the middle of a capture.
+struct SideLane {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    bool held = false;  // between side_mark and side_join of one call
+};
 struct SideStream {
-    hipStream_t stream = nullptr;  // one per device, made on first use, shared by every call on that device
-    hipEvent_t fork_ev = nullptr;  // THIS call's fork point (events are per call: two host threads may be in here at once)
+    SideLane *lane = nullptr;
+    hipStream_t stream = nullptr;
     bool ok = false;
 };
 
-static hipStream_t side_stream_of_device()
+static std::mutex g_side_mu;
+static std::vector<SideLane *> g_side_lanes[64];
+
+static unsigned long long capture_id_of(hipStream_t st, bool *capturing)
 {
-    static std::mutex mu;
-    static hipStream_t per_device[64] = {nullptr};
-    static bool tried[64] = {false};
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    if (hipStreamGetCaptureInfo(st, &cap, &id) != hipSuccess) {
+        (void)hipGetLastError();
+        *capturing = false;
+        return 0;
+    }
+    *capturing = cap != hipStreamCaptureStatusNone;
+    return *capturing ? id : 0;
+}
+
+static SideLane *side_lane_acquire(hipStream_t main)
+{
     int dev = 0;
     if (env_long("TRW_SIDE_STREAM", 0, 1, 1) == 0 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!tried[dev]) {
-        tried[dev] = true;
-        if (hipStreamCreateWithFlags(&per_device[dev], hipStreamNonBlocking) != hipSuccess) per_device[dev] = nullptr;
+    bool main_capturing = false;
+    const unsigned long long main_id = capture_id_of(main, &main_capturing);
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    for (SideLane *l : g_side_lanes[dev]) {
+        if (l->held) continue;
+        bool lane_capturing = false;
+        const unsigned long long lane_id = capture_id_of(l->stream, &lane_capturing);
+        if (lane_capturing == main_capturing && lane_id == main_id) {
+            l->held = true;
+            return l;
+        }
     }
-    return per_device[dev];
+    if (main_capturing || g_side_lanes[dev].size() >= 16) return nullptr;  // never make a stream inside a capture
+    SideLane *l = new SideLane;
+    if (hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&l->fork_ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&l->join_ev, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        if (l->join_ev) (void)hipEventDestroy(l->join_ev);
+        if (l->fork_ev) (void)hipEventDestroy(l->fork_ev);
+        if (l->stream) (void)hipStreamDestroy(l->stream);
+        delete l;
+        return nullptr;
+    }
+    l->held = true;
+    g_side_lanes[dev].push_back(l);
+    return l;
+}
+
+static void side_lane_release(SideLane *l)
+{
+    if (!l) return;
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    l->held = false;
 }
 
 // Marks the fork point on the caller's stream (everything queued so far); !ok: no side stream, the work stays in line.
 static SideStream side_mark(hipStream_t main)
 {
     SideStream s;
-    s.stream = side_stream_of_device();
-    if (!s.stream) return s;
-    if (hipEventCreateWithFlags(&s.fork_ev, hipEventDisableTiming) != hipSuccess) return s;
-    if (hipEventRecord(s.fork_ev, main) != hipSuccess) {
-        (void)hipEventDestroy(s.fork_ev);
-        s.fork_ev = nullptr;
+    s.lane = side_lane_acquire(main);
+    if (!s.lane) return s;
+    s.stream = s.lane->stream;
+    if (hipEventRecord(s.lane->fork_ev, main) != hipSuccess) {
+        (void)hipGetLastError();
+        side_lane_release(s.lane);
+        s.lane = nullptr;
         return s;
     }
     s.ok = true;
@@ -1156,23 +1211,20 @@ static SideStream side_mark(hipStream_t main)
 // The stream the side work goes to: the side stream, made to wait for the fork point -- or the caller's own.
 static hipStream_t side_begin(hipStream_t main, SideStream &s)
 {
-    if (s.ok && hipStreamWaitEvent(s.stream, s.fork_ev, 0) == hipSuccess) return s.stream;
+    if (s.ok && hipStreamWaitEvent(s.stream, s.lane->fork_ev, 0) == hipSuccess) return s.stream;
     s.ok = false;
     return main;
 }
 
-// The caller's stream waits for the side work; the call's events are released (they live until they have fired).
+// The caller's stream waits for the side work; the lane goes back to the pool.
 static void side_join(hipStream_t main, SideStream &s)
 {
     if (s.ok) {
-        hipEvent_t join_ev = nullptr;
-        if (hipEventCreateWithFlags(&join_ev, hipEventDisableTiming) != hipSuccess ||
-            hipEventRecord(join_ev, s.stream) != hipSuccess || hipStreamWaitEvent(main, join_ev, 0) != hipSuccess)
+        if (hipEventRecord(s.lane->join_ev, s.stream) != hipSuccess || hipStreamWaitEvent(main, s.lane->join_ev, 0) != hipSuccess)
             (void)hipStreamSynchronize(s.stream);  // (never expected; keeps the ordering the caller relies on)
-        if (join_ev) (void)hipEventDestroy(join_ev);
     }
-    if (s.fork_ev) (void)hipEventDestroy(s.fork_ev);
-    s.fork_ev = nullptr;
+    side_lane_release(s.lane);
+    s.lane = nullptr;
     s.ok = false;
 }
 

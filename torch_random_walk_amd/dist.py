@@ -86,23 +86,51 @@ def walk_sharded(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, group=
     dev = target_nodes.device
     staged = world > 1 and _host_staged(group, target_nodes)
 
-    def walk_into(dst, c_lo, c_hi):
-        """rows [c_lo, c_hi) of the batch, walked into `dst` (a [c_hi-c_lo, cols] slice of a result tensor)"""
-        if walk_fn is None:
-            # (deferred status check: nothing holds the host back between a chunk's walk and its transfer; the
-            # read-backs are collected -- and a data fault raised, on the rank whose block is faulty -- before this
-            # function returns, see `settle` below)
-            rw.walk_ex(row_ptr, col_idx, target_nodes[c_lo:c_hi], p, q, walk_length, seed, walker_base=c_lo,
-                       rng_mode=rng_mode, check="deferred", out=dst)
-        else:
-            dst.copy_(walk_fn(row_ptr, col_idx, target_nodes[c_lo:c_hi], p, q, walk_length, seed, walker_base=c_lo,
-                              rng_mode=rng_mode))
+    fault = []   # first exception of this rank's walks: remembered, raised only once every transfer is done
 
-    def settle(result):
-        """A block with a data fault (degree-0 node, id out of range) must not pass for a result: every rank waits for
-        the status read-backs of its own walks and raises if one of them reported."""
+    def walk_into(dst, c_lo, c_hi):
+        """rows [c_lo, c_hi) of the batch, walked into `dst` (a [c_hi-c_lo, cols] slice of a result tensor).
+        NEVER raises: a rank that left the chunk loop half way would strand its peers in their receives (the root in
+        irecv.wait() for the chunks that were never sent, or the peers' isends without a match) -- ADVICE r03.  An
+        exception -- an argument error, or a data fault of an earlier deferred-check call surfacing at this call's
+        entry -- is kept for `settle`; the rank goes on and ships whatever its buffer holds, and `settle` makes sure
+        nobody takes that for a result."""
+        try:
+            if walk_fn is None:
+                # (deferred status check: nothing holds the host back between a chunk's walk and its transfer)
+                rw.walk_ex(row_ptr, col_idx, target_nodes[c_lo:c_hi], p, q, walk_length, seed, walker_base=c_lo,
+                           rng_mode=rng_mode, check="deferred", out=dst)
+            else:
+                dst.copy_(walk_fn(row_ptr, col_idx, target_nodes[c_lo:c_hi], p, q, walk_length, seed,
+                                  walker_base=c_lo, rng_mode=rng_mode))
+        except Exception as e:  # noqa: BLE001 -- see above: kept, raised by settle()
+            if not fault:
+                fault.append(e)
+
+    def settle(result, collective=True):
+        """A block with a data fault (degree-0 node, id out of range) must not pass for a result -- on ANY rank: the
+        rows of a faulty block have already travelled when its owner finds out.  Every rank waits for the status
+        read-backs of its own walks, the ranks agree on "did anyone fault" (one MAX all_reduce of a flag; every rank
+        reaches it, whatever happened before), and all of them raise: the owner its own error, the others a
+        RuntimeError that names the faulty ranks.  ``gather="none"`` has no collective and stays
+        local."""
         if walk_fn is None and target_nodes.is_cuda:
-            rw.check_status(wait=True)
+            try:
+                rw.check_status(wait=True)
+            except RuntimeError as e:
+                if not fault:
+                    fault.append(e)
+        if world > 1 and collective:
+            flags = torch.zeros(world, dtype=torch.int32, device="cpu" if (staged or not target_nodes.is_cuda) else dev)
+            if fault:
+                flags[rank] = 1
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)
+            bad = [r for r, f in enumerate(flags.tolist()) if f]
+            if bad and not fault:
+                raise RuntimeError("torch_rw.walk_sharded: the walk of rank(s) %s reported a fault; the gathered rows "
+                                   "are not a result" % ", ".join(str(r) for r in bad))
+        if fault:
+            raise fault[0]
         return result
 
     def to_wire(rows):
@@ -122,7 +150,7 @@ def walk_sharded(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, group=
     if not root_gather:
         walk_into(mine, lo, hi)
         if world == 1 or gather == "none":
-            return settle(mine)
+            return settle(mine, collective=False)
         # gather == "all": equal-sized pieces for the collective; the pad rows are dropped below
         w = to_wire(mine)
         if hi - lo < block:
