@@ -162,6 +162,15 @@ int32_t trw_prepare_plan(int64_t n_nodes, int64_t nnz, int64_t n_walkers, int32_
 size_t trw_prepare_csr_bytes(int64_t n_nodes, int64_t nnz, int32_t what);
 int trw_prepare_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col_idx, int64_t nnz,
                         int32_t what, void *prepared, size_t prepared_bytes, void *hip_stream);
+/* Where a part of the prepared buffer sits (diagnostics and tests: the layout is a function of the shapes alone).
+ * *bytes == 0: this `what` has no such part. */
+#define TRW_REGION_HEADER 0
+#define TRW_REGION_ROW32  1   /* uint32 row offsets, n_nodes + 1 */
+#define TRW_REGION_COL32  2   /* uint32 neighbours, nnz */
+#define TRW_REGION_EXT16  3   /* 16-byte entries of the uniform walk */
+#define TRW_REGION_TABLE  4   /* edge table */
+#define TRW_REGION_EXT32  5   /* 32-byte entries of the node2vec walk: {v, start(v), deg(v)|filter, rpos} + 128-bit mask */
+int trw_prepare_csr_region(int64_t n_nodes, int64_t nnz, int32_t what, int32_t which, size_t *offset, size_t *bytes);
 size_t trw_walk_csr_prepared_workspace_bytes(int64_t n_walkers, int32_t walk_length, double p, double q,
                                              int32_t rng_mode);
 int trw_walk_csr_prepared_hip(const void *prepared, size_t prepared_bytes, int32_t what,

@@ -321,6 +321,74 @@ def test_prepared_c_abi_direct(rw):
                 assert st[3] in (4, 5)                             # the mask / walker-pool kernel
 
 
+def _prepared_ext32(L, d_rp, d_ci, n, nnz, what):
+    """The 32-byte entries of a freshly prepared graph as an [nnz, 8] uint32 array (C ABI, raw pointers)."""
+    pb = L.trw_prepare_csr_bytes(n, nnz, what)
+    blob = torch.empty(pb, dtype=torch.uint8, device=DEV)
+    stream = torch.cuda.current_stream().cuda_stream
+    assert L.trw_prepare_csr_hip(d_rp.data_ptr(), n, d_ci.data_ptr(), nnz, what, blob.data_ptr(), pb, stream) == 0
+    off, size = ctypes.c_size_t(), ctypes.c_size_t()
+    assert L.trw_prepare_csr_region(n, nnz, what, 5, ctypes.byref(off), ctypes.byref(size)) == 0 and size.value == nnz * 32
+    torch.cuda.synchronize()
+    return blob[off.value:off.value + size.value].cpu().numpy().view(np.uint32).reshape(nnz, 8)
+
+
+def _skewed_graph(n, m, seed, hubs=()):
+    """R-MAT-like skew (ids drawn as products of uniforms) + a few hubs of given out-degree: rows from 1 to several
+    thousand entries, plenty of common neighbours among the long rows, a sprinkling of parallel edges."""
+    rng = np.random.default_rng(seed)
+    src = (n * rng.random(m) ** 3).astype(np.int64)
+    dst = (n * rng.random(m) ** 3).astype(np.int64)
+    extra_s, extra_d = [np.arange(n)], [(np.arange(n) + 1) % n]
+    for h, deg in hubs:
+        extra_s.append(np.full(deg, h))
+        extra_d.append((n * rng.random(deg) ** 2).astype(np.int64))
+    src, dst = np.concatenate([src] + extra_s), np.concatenate([dst] + extra_d)
+    order = np.lexsort((dst, src))
+    src, dst = src[order], dst[order]
+    row_ptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(src, minlength=n), out=row_ptr[1:])
+    return row_ptr, dst.astype(np.int64)
+
+
+@pytest.mark.parametrize("what", [6, 14])
+def test_tile_pass_masks_equal_the_wave_per_entry_pass_and_numpy(rw, what, monkeypatch):
+    """The neighbourhood masks of the entries whose shorter row is longer than 32: worked out by the tile pass (the
+    longer row in LDS, in-lists for the rows entered from shorter ones), by round 3's wave-per-entry pass
+    (TRW_HEAVY_TILE=0) and by numpy -- the same 32 bytes for every entry.  The graph has rows on both sides of every
+    threshold: 32, 128 (exact mask / filter), 256 / 1024 (the caps), and hubs beyond the 16 384-entry tile."""
+    from torch_random_walk_amd import _native
+    L = _native.cabi()
+    n = 40000
+    rp, ci = _skewed_graph(n, 500_000, 5, hubs=((3, 17000), (11, 20000), (40, 5000), (41, 1100), (77, 300)))
+    nnz = len(ci)
+    d_rp, d_ci = _dev(rp, ci)
+    monkeypatch.setenv("TRW_HEAVY_TILE", "1")
+    tiled = _prepared_ext32(L, d_rp, d_ci, n, nnz, what)
+    monkeypatch.setenv("TRW_HEAVY_TILE", "0")
+    queued = _prepared_ext32(L, d_rp, d_ci, n, nnz, what)
+    assert (tiled == queued).all(), np.nonzero((tiled != queued).any(1))[0][:10]
+    # numpy: entries whose shorter row has 33 .. cap entries carry the exact intersection (modulo 128 positions)
+    cap = 1024 if what & 8 else 256
+    deg = np.diff(rp)
+    src = np.repeat(np.arange(n), deg)
+    rng = np.random.default_rng(1)
+    heavy = np.nonzero((np.minimum(deg[src], deg[ci]) > 32) & (np.minimum(deg[src], deg[ci]) <= cap))[0]
+    assert 1000 < heavy.size < nnz // 2       # (the queue of the wave-per-entry pass has room for nnz/2 entries)
+    a_side = heavy[deg[src[heavy]] > deg[ci[heavy]]]
+    b_side = heavy[deg[src[heavy]] <= deg[ci[heavy]]]
+    assert a_side.size > 100 and b_side.size > 100
+    for e in np.concatenate([rng.choice(a_side, 150), rng.choice(b_side, 150), heavy[:20], heavy[-20:]]):
+        u, v = src[e], ci[e]
+        row_u, row_v = ci[rp[u]:rp[u + 1]], ci[rp[v]:rp[v + 1]]
+        bits = np.zeros(128, dtype=bool)
+        np.logical_or.at(bits, np.nonzero(np.isin(row_v, row_u))[0] % 128, True)
+        want = np.packbits(bits, bitorder="little").view(np.uint32)
+        assert (tiled[e, 4:] == want).all(), (e, u, v, deg[u], deg[v])
+        assert tiled[e, 0] == v and tiled[e, 1] == rp[v] and (tiled[e, 2] & 0x7FFFFFFF) == deg[v]
+        assert bool(tiled[e, 2] >> 31) == (deg[v] > 128)
+
+
 def test_prepared_edge_list_is_cached_per_padding_id_and_invalidated_by_writes(rw):
     from torch_rw import utils
     rng = np.random.default_rng(3)

@@ -55,6 +55,9 @@ def cabi():
         L.trw_prepare_csr_bytes.restype = ctypes.c_size_t
         L.trw_prepare_csr_hip.argtypes = [vp, i64, vp, i64, i32, vp, ctypes.c_size_t, vp]
         L.trw_prepare_csr_hip.restype = ctypes.c_int
+        L.trw_prepare_csr_region.argtypes = [i64, i64, i32, i32, ctypes.POINTER(ctypes.c_size_t),
+                                             ctypes.POINTER(ctypes.c_size_t)]
+        L.trw_prepare_csr_region.restype = ctypes.c_int
         L.trw_walk_csr_prepared_workspace_bytes.argtypes = [i64, i32, dbl, dbl, i32]
         L.trw_walk_csr_prepared_workspace_bytes.restype = ctypes.c_size_t
         L.trw_walk_csr_prepared_hip.argtypes = [vp, ctypes.c_size_t, i32, vp, i64, vp, i64, vp, i64, i64, dbl, dbl,

@@ -23,6 +23,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/trw.h"
@@ -126,8 +127,9 @@ struct PrepLayout {
     bool marks = false;    // ... with the neighbourhood masks worked out for long rows too
     bool marks_full = false;  // ... for rows up to 1024 entries (TRW_PREP_MARKS_FULL) instead of 256
     uint64_t hash_mask = 0;
-    uint32_t heavy_room = 0;
+    uint32_t heavy_room = 0, task_room = 0;
     size_t off_row32 = 0, off_col32 = 0, off_ext16 = 0, off_table = 0, off_ext32 = 0, off_heavy = 0, total = 0;
+    size_t off_incount = 0, off_inoff = 0, off_tasks = 0;  // the tile pass: per-node in-list counters / segments, tasks
 };
 
 bool graph_fits_narrow(int64_t n_nodes, int64_t nnz)
@@ -176,6 +178,17 @@ PrepLayout make_prep_layout(int64_t n_nodes, int64_t nnz, int32_t what)
                 pl.heavy_room = room > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)room;
                 pl.off_heavy = off;
                 off += align_up((size_t)pl.heavy_room * 8, 256);
+                // the tile pass (heavy_tile_kernel): in-list counter and segment per node, and its task records --
+                // at most nnz/128 + (nnz/2)/64 + two per row of more than 32 entries; a plan that runs out of room
+                // drops tasks, whose entries keep their all-ones masks
+                pl.off_incount = off;
+                off += align_up((size_t)(n_nodes + 1) * 4, 256);
+                pl.off_inoff = off;
+                off += align_up((size_t)(n_nodes + 1) * 4, 256);
+                const uint64_t troom = (uint64_t)nnz / 12 + 4096;
+                pl.task_room = troom > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)troom;
+                pl.off_tasks = off;
+                off += align_up((size_t)pl.task_room * 16, 256);
             }
         }
     }
@@ -467,6 +480,24 @@ size_t trw_prepare_csr_bytes(int64_t n_nodes, int64_t nnz, int32_t what)
     return make_prep_layout(n_nodes, nnz, what).total;
 }
 
+int trw_prepare_csr_region(int64_t n_nodes, int64_t nnz, int32_t what, int32_t which, size_t *offset, size_t *bytes)
+{
+    if (n_nodes < 0 || nnz < 0 || !offset || !bytes) return fail(TRW_E_ARG, "bad argument");
+    const PrepLayout pl = make_prep_layout(n_nodes, nnz, what);
+    *offset = 0;
+    *bytes = 0;
+    switch (which) {
+    case TRW_REGION_HEADER: *bytes = kStatusBytes; break;
+    case TRW_REGION_ROW32: if (pl.narrow) { *offset = pl.off_row32; *bytes = (size_t)(n_nodes + 1) * 4; } break;
+    case TRW_REGION_COL32: if (pl.narrow) { *offset = pl.off_col32; *bytes = (size_t)nnz * 4; } break;
+    case TRW_REGION_EXT16: if (pl.ext16) { *offset = pl.off_ext16; *bytes = (size_t)nnz * 16; } break;
+    case TRW_REGION_TABLE: if (pl.biased) { *offset = pl.off_table; *bytes = ((size_t)pl.hash_mask + 1) * 16; } break;
+    case TRW_REGION_EXT32: if (pl.biased) { *offset = pl.off_ext32; *bytes = (size_t)nnz * 32; } break;
+    default: return fail(TRW_E_ARG, "unknown region");
+    }
+    return TRW_OK;
+}
+
 int trw_prepare_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col_idx, int64_t nnz, int32_t what,
                         void *prepared, size_t prepared_bytes, void *hip_stream)
 {
@@ -511,10 +542,40 @@ int trw_prepare_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *
             const uint32_t heavy_cap =
                 pl.marks ? (uint32_t)env_long("TRW_HEAVY_MAX", 0, 1 << 20, pl.marks_full ? 1024 : 256) : 0u;
             HeavyItem *heavy = pl.marks ? (HeavyItem *)(ws + pl.off_heavy) : nullptr;
+            // The masks of entries whose shorter row is longer than inline_cap: the tile pass (heavy_tile_kernel: the
+            // longer row in LDS, the shorter rows streamed past it).  TRW_HEAVY_TILE=0: the wave-per-entry pass over
+            // a queue instead (round 3's form: every search a bisection in global memory).
+            const bool tiles = pl.marks && heavy_cap > inline_cap && env_long("TRW_HEAVY_TILE", 0, 1, 1) == 1;
+            uint32_t *in_count = pl.marks ? (uint32_t *)(ws + pl.off_incount) : nullptr;
+            uint32_t *in_off = pl.marks ? (uint32_t *)(ws + pl.off_inoff) : nullptr;
+            if (tiles) device_fill(in_count, 0u, align_up((size_t)(n_nodes + 1) * 4, 256), stream);
             csr_ext32_kernel<<<stream_grid((nnz + 7) / 8), kBlock, 0, stream>>>(
-                row32, col32, n_nodes, nnz, table, pl.hash_mask, inline_cap, heavy_cap,
-                (u32x4_a16 *)(ws + pl.off_ext32), heavy, pl.heavy_room, header);
-            if (pl.marks)
+                row32, col32, n_nodes, nnz, table, pl.hash_mask, inline_cap, heavy_cap, tiles ? 1u : 0u,
+                (u32x4_a16 *)(ws + pl.off_ext32), heavy, pl.heavy_room, in_count, header);
+            if (tiles) {
+                TileTask *tasks = (TileTask *)(ws + pl.off_tasks);
+                u32x4_a16 *ext32 = (u32x4_a16 *)(ws + pl.off_ext32);
+                heavy_plan_kernel<<<stream_grid(n_nodes), kBlock, 0, stream>>>(row32, n_nodes, in_count, in_off, tasks,
+                                                                               pl.task_room, pl.heavy_room, inline_cap, header);
+                heavy_scatter_kernel<<<stream_grid(n_nodes), kBlock, 0, stream>>>(row32, col32, n_nodes, inline_cap,
+                                                                                  heavy_cap, in_count, in_off, heavy);
+                // tile size / workgroup shape: LDS per workgroup decides how many waves a CU holds
+                const long shape = env_long("TRW_TILE_SHAPE", 0, 3, 0);
+                const unsigned cus = (unsigned)device_cu_count();
+                if (shape == 0)
+                    heavy_tile_kernel<16384, 512><<<cus * 2, 512, 0, stream>>>(row32, col32, ext32, heavy, tasks, pl.task_room,
+                                                                               inline_cap, heavy_cap, header);
+                else if (shape == 1)
+                    heavy_tile_kernel<8192, 512><<<cus * 4, 512, 0, stream>>>(row32, col32, ext32, heavy, tasks, pl.task_room,
+                                                                              inline_cap, heavy_cap, header);
+                else if (shape == 2)
+                    heavy_tile_kernel<8192, 256><<<cus * 4, 256, 0, stream>>>(row32, col32, ext32, heavy, tasks, pl.task_room,
+                                                                              inline_cap, heavy_cap, header);
+                else
+                    heavy_tile_kernel<4096, 256><<<cus * 8, 256, 0, stream>>>(row32, col32, ext32, heavy, tasks, pl.task_room,
+                                                                              inline_cap, heavy_cap, header);
+            }
+            if (pl.marks && !tiles)
                 csr_ext32_heavy_kernel<<<(unsigned)(device_cu_count() * 8), kBlock, 0, stream>>>(
                     row32, col32, table, pl.hash_mask, (u32x4_a16 *)(ws + pl.off_ext32), heavy, pl.heavy_room, header);
         }

@@ -1014,11 +1014,29 @@ struct HeavyItem {
     uint32_t e, u;
 };
 
+// Who works out the mask of entry u -> v (rows sorted), by the two rows' lengths:
+//   MK_INLINE  the thread that owns the entry, one table probe per entry of the shorter row (<= inline_cap)
+//   MK_TILE_A  the tile pass, u's row (the longer one) in LDS, v's row streamed past it -- found by u's entry range
+//   MK_TILE_B  the tile pass, v's row (longer or equal) in LDS, u's row streamed -- found through v's in-list
+//   MK_QUEUE   the wave-per-entry pass over the queue (longer row too long for a tile, or the tile pass is off)
+//   MK_NONE    nobody: the shorter row is beyond heavy_cap, the mask stays all ones + filter
+enum : uint32_t { MK_INLINE = 0, MK_TILE_A, MK_TILE_B, MK_QUEUE, MK_NONE };
+__device__ __forceinline__ uint32_t mask_route(uint32_t deg_u, uint32_t deg_v, uint32_t inline_cap, uint32_t heavy_cap,
+                                               uint32_t tile_cap)
+{
+    const uint32_t shorter = deg_u < deg_v ? deg_u : deg_v, longer = deg_u < deg_v ? deg_v : deg_u;
+    if (shorter <= inline_cap) return MK_INLINE;
+    if (shorter > heavy_cap) return MK_NONE;
+    (void)longer;
+    if (tile_cap == 0u) return MK_QUEUE;  // no tile pass
+    return deg_u > deg_v ? MK_TILE_A : MK_TILE_B;
+}
+
 __global__ void __launch_bounds__(kBlock)
 csr_ext32_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32, int64_t n_nodes,
                  int64_t nnz, const uint32_t *__restrict__ table, uint64_t tmask, uint32_t inline_cap,
-                 uint32_t heavy_cap, u32x4_a16 *__restrict__ ext, HeavyItem *__restrict__ heavy, uint32_t heavy_room,
-                 int64_t *__restrict__ header)
+                 uint32_t heavy_cap, uint32_t tile_cap, u32x4_a16 *__restrict__ ext, HeavyItem *__restrict__ heavy,
+                 uint32_t heavy_room, uint32_t *__restrict__ in_count, int64_t *__restrict__ header)
 {
     constexpr int kPer = 8;
     const bool sorted = header[kStDescents] == header[kStBoundary];
@@ -1057,14 +1075,16 @@ csr_ext32_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict_
                 if (edge_table_find(table, tmask, v, u, lo, cnt))
                     rpos = (cnt <= 15u && lo < (1u << 28)) ? ((cnt << 28) | lo) : kRposLookup;
                 const uint32_t deg_u = row_hi - row_lo;
-                const uint32_t shorter = deg_u < deg ? deg_u : deg;
-                if (sorted && shorter <= inline_cap) {
+                const uint32_t route = sorted ? mask_route(deg_u, deg, inline_cap, heavy ? heavy_cap : 0u, tile_cap) : MK_NONE;
+                if (route == MK_INLINE) {
                     m.clear();
                     common_mask_table(col32, table, tmask, u, row_lo, row_hi, v, start, deg, m);
                     flag = deg > 128u ? kMaskIsFilter : 0u;
-                } else if (sorted && shorter <= heavy_cap && heavy) {
+                } else if (route == MK_QUEUE) {
                     const uint32_t at = (uint32_t)atomicAdd((unsigned long long *)&header[kStHeavyCount], 1ull);
                     if (at < heavy_room) heavy[at] = HeavyItem{e, u};
+                } else if (route == MK_TILE_B) {
+                    atomicAdd(in_count + v, 1u);  // v's in-list grows by this entry (heavy_scatter_kernel fills it)
                 }
             }
             u32x4_a16 o = {v, start, deg | flag, rpos};
@@ -1107,6 +1127,311 @@ csr_ext32_heavy_kernel(const uint32_t *__restrict__ row32, const uint32_t *__res
             u32x4_a16 mm = {m.w[0], m.w[1], m.w[2], m.w[3]};
             ext[2 * (size_t)h.e + 1] = mm;
             if (deg <= 128u) reinterpret_cast<uint32_t *>(ext + 2 * (size_t)h.e)[2] = deg;  // exact: drop the filter bit
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The tile pass: neighbourhood masks of the entries whose shorter row has more than inline_cap entries
+// ---------------------------------------------------------------------------
+// The mask of u -> v is the intersection of two sorted rows, written as positions of v's row.  The wave-per-entry pass
+// above walks the shorter row and bisects every element into the longer one in GLOBAL memory: 1e10 searches of 4-5
+// dependent loads each on R-MAT 10M/110M, 116 ms at the L2s' request rate.  97 % of those searches go
+// into a row of fewer than 16 384 entries -- 64 KB, a tile of LDS -- and the entries that share a longer row can share
+// the tile:
+//   * longer row = u's  (MK_TILE_A): u's entries are consecutive in the CSR.  A task is (u, 128 of its entries);
+//     v's row is streamed (coalesced), element j found in the tile sets bit j.
+//   * longer row = v's  (MK_TILE_B): the entries that point AT v are scattered, so they are collected first:
+//     csr_ext32_kernel counts them per v, heavy_plan_kernel hands every v a segment of the item array,
+//     heavy_scatter_kernel fills the segments with (e, u).  A task is (v, 64 items of its in-list); u's row is
+//     streamed, element w found at position lo of the tile sets bits lo .. lo+run-1 (run > 1: parallel edges).
+// A workgroup of 8 waves keeps one row in LDS (padded with 0xFFFFFFFF to a power of two, so the bisection is
+// branch-free: add, ds_read, compare, select per level), takes tasks from a device counter four at a time -- tasks of one
+// row are consecutive, the tile stays -- and each wave streams the shorter rows of its share of the task's items,
+// four elements per lane at a time.  Every global load is a coalesced stream; the only random accesses left are
+// LDS reads.
+constexpr uint32_t kTaskEntries = 128;   // MK_TILE_A: entries of the tile row per task
+constexpr uint32_t kTaskItems = 64;      // MK_TILE_B: in-list items per task
+#ifndef TRW_TASK_GRAB
+#define TRW_TASK_GRAB 16
+#endif
+constexpr uint32_t kTaskGrab = TRW_TASK_GRAB;  // consecutive tasks a workgroup takes from the counter at a time
+constexpr int kStTaskCount = 16, kStSortedCursor = 17, kStTaskNext = 18;  // header slots
+constexpr uint32_t kNoSegment = 0xFFFFFFFFu;
+
+struct TileTask {
+    uint32_t node, start, count, mode;  // mode 0: entries [start, start+count) of node's row; 1: items [start, ...) of its in-list
+};
+
+// One thread per node: tasks for the rows that can be a tile, and a segment of the item array for the node's in-list.
+__global__ void __launch_bounds__(kBlock)
+heavy_plan_kernel(const uint32_t *__restrict__ row32, int64_t n_nodes, const uint32_t *__restrict__ in_count,
+                  uint32_t *__restrict__ in_off, TileTask *__restrict__ tasks, uint32_t task_room, uint32_t heavy_room,
+                  uint32_t inline_cap, int64_t *__restrict__ header)
+{
+    if (header[kStDescents] != header[kStBoundary]) return;  // rows not sorted: no masks, no tasks
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const uint64_t queued = (uint64_t)header[kStHeavyCount];
+    const uint32_t base0 = queued < heavy_room ? (uint32_t)queued : heavy_room;  // the queue's items come first
+    for (int64_t x = (int64_t)blockIdx.x * kBlock + threadIdx.x; x < n_nodes; x += stride) {
+        uint32_t start, deg;
+        load_row32(row32, (uint32_t)x, start, deg);
+        if (deg <= inline_cap) continue;  // never the longer row of a tile item
+        const uint32_t c = in_count[x];
+        uint32_t seg = kNoSegment;
+        if (c) {
+            const uint64_t o = (uint64_t)base0 + atomicAdd((unsigned long long *)&header[kStSortedCursor], (unsigned long long)c);
+            if (o + c <= heavy_room) seg = (uint32_t)o;
+            in_off[x] = seg;  // kNoSegment: no room, these entries keep their all-ones masks
+        }
+        // MK_TILE_A needs deg > deg(v) > inline_cap
+        const uint32_t n_a = deg >= inline_cap + 2u ? (deg + kTaskEntries - 1u) / kTaskEntries : 0u;
+        const uint32_t n_b = seg != kNoSegment ? (c + kTaskItems - 1u) / kTaskItems : 0u;
+        if (n_a + n_b == 0u) continue;
+        const uint64_t at = atomicAdd((unsigned long long *)&header[kStTaskCount], (unsigned long long)(n_a + n_b));
+        for (uint32_t k = 0; k < n_a + n_b; ++k) {
+            if (at + k >= task_room) break;
+            TileTask t;
+            t.node = (uint32_t)x;
+            if (k < n_a) {
+                t.start = start + k * kTaskEntries;
+                t.count = deg - k * kTaskEntries < kTaskEntries ? deg - k * kTaskEntries : kTaskEntries;
+                t.mode = 0u;
+            } else {
+                const uint32_t kb = k - n_a;
+                t.start = seg + kb * kTaskItems;
+                t.count = c - kb * kTaskItems < kTaskItems ? c - kb * kTaskItems : kTaskItems;
+                t.mode = 1u;
+            }
+            tasks[at + k] = t;
+        }
+    }
+}
+
+// The in-lists: every MK_TILE_B entry u -> v goes into v's segment.  A wave takes 64 consecutive nodes; the rows that
+// can be the shorter side of such an entry (inline_cap < deg <= heavy_cap) are scanned by the whole wave.
+__global__ void __launch_bounds__(kBlock)
+heavy_scatter_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32, int64_t n_nodes,
+                     uint32_t inline_cap, uint32_t heavy_cap, uint32_t *__restrict__ in_count,
+                     const uint32_t *__restrict__ in_off, HeavyItem *__restrict__ items)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t waves = (int64_t)gridDim.x * (kBlock / 64);
+    for (int64_t w = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); w * 64 < n_nodes; w += waves) {
+        const int64_t x = w * 64 + lane;
+        uint32_t start = 0, deg = 0;
+        if (x < n_nodes) load_row32(row32, (uint32_t)x, start, deg);
+        uint64_t todo = __ballot(deg > inline_cap && deg <= heavy_cap);
+        while (todo) {
+            const int src = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint32_t u = (uint32_t)(w * 64 + src);
+            const uint32_t u_start = __shfl(start, src), u_deg = __shfl(deg, src);
+            for (uint32_t i = (uint32_t)lane; i < u_deg; i += 64u) {
+                const uint32_t e = u_start + i, v = col32[e];
+                uint32_t v_start, v_deg;
+                load_row32(row32, v, v_start, v_deg);
+                if (mask_route(u_deg, v_deg, inline_cap, heavy_cap, 1u) != MK_TILE_B) continue;
+                const uint32_t seg = in_off[v];
+                if (seg == kNoSegment) continue;
+                const uint32_t k = atomicSub(in_count + v, 1u) - 1u;
+                items[seg + k] = HeavyItem{e, u};
+            }
+        }
+    }
+}
+
+// kCap: entries of LDS per tile (a power of two); kThreads: workgroup size.  A row of fewer than kCap entries is one
+// tile; a longer one is swept in chunks of kCap-1 entries, the workgroup's items streamed past every chunk and their
+// masks gathered in LDS in between (a dozen hub rows on R-MAT 10M/110M, 3 % of the searches -- which took the
+// wave-per-entry pass 10 ms).
+constexpr uint32_t kTileSentinel = 0x7FFFFFFFu;  // padding of a tile: above every node id (n_nodes < 2^31)
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
+// kCap: entries of LDS per tile (a power of two); kThreads: workgroup size.  A row of fewer than kCap entries is in the
+// tile whole.  Of a longer one (a few hundred rows of R-MAT 10M/110M, but 11 % of the searches) the tile holds every
+// m-th entry -- the last of each block of m = ceil(n / (kCap-1)) --, the bisection in LDS finds the block and the last
+// log2(m) levels read the block in global memory (L2 hits: 1 level for a row of 8-16 K entries, 5 for the longest).
+template <uint32_t kCap, int kThreads>
+__global__ void __launch_bounds__(kThreads)
+heavy_tile_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32, u32x4_a16 *__restrict__ ext,
+                  const HeavyItem *__restrict__ items, const TileTask *__restrict__ tasks, uint32_t task_room,
+                  uint32_t inline_cap, uint32_t heavy_cap, int64_t *__restrict__ header)
+{
+    constexpr uint32_t kWaves = kThreads / 64;
+    constexpr uint32_t kPerWave = (kTaskEntries > kTaskItems ? kTaskEntries : kTaskItems) / kWaves;  // items of a task per wave
+    static_assert(kPerWave <= 64 && (kCap & (kCap - 1)) == 0, "one lane per item; power-of-two tile");
+    constexpr uint32_t kHead = kWaves * kPerWave * 4 + 4;  // words in front of the tile: the waves' masks, `grabbed`
+    __shared__ uint32_t lds[kHead + kCap];
+    uint32_t *const tile = lds + kHead;
+    uint32_t(*const acc)[4] = reinterpret_cast<uint32_t(*)[4]>(lds + (threadIdx.x >> 6) * kPerWave * 4);  // this wave's items' masks
+    uint32_t &grabbed = lds[kHead - 4];
+    // the tile as an LDS byte address (the low half of its flat address): the bisection below computes addresses itself
+    const uint32_t tile_lds = (uint32_t)reinterpret_cast<uintptr_t>(tile);
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint64_t made = (uint64_t)header[kStTaskCount];
+    const uint32_t n_tasks = made < task_room ? (uint32_t)made : task_room;
+    // the tile holds cur_node's row [t_start, t_start + n): every m-th entry, nb of them; the bisection's first step is top4 bytes
+    uint32_t cur_node = 0xFFFFFFFFu, n = 0, t_start = 0, m = 1, nb = 0, top4 = 0, mtop = 0;
+    while (true) {
+        __syncthreads();  // (everyone has read `grabbed` of the last round)
+        if (threadIdx.x == 0) grabbed = (uint32_t)atomicAdd((unsigned long long *)&header[kStTaskNext], (unsigned long long)kTaskGrab);
+        __syncthreads();
+        const uint32_t t0 = grabbed;
+        if (t0 >= n_tasks) break;
+        const uint32_t t1 = t0 + kTaskGrab < n_tasks ? t0 + kTaskGrab : n_tasks;
+        for (uint32_t ti = t0; ti < t1; ++ti) {
+            const TileTask task = tasks[ti];
+            const bool new_node = task.node != cur_node;  // (workgroup-uniform)
+            uint32_t n_new = n, start_new = t_start;
+            if (new_node) load_row32(row32, task.node, start_new, n_new);
+            // this wave's items of the task: lane j looks at item wave + kWaves * j
+            const uint32_t k = wave + kWaves * (uint32_t)lane;
+            uint32_t s_start = 0, s_len = 0, e = 0, deg_v = 0;
+            bool mine = false;
+            if (k < task.count) {
+                if (task.mode == 0u) {
+                    e = task.start + k;
+                    const uint32_t v = col32[e];
+                    load_row32(row32, v, s_start, s_len);
+                    deg_v = s_len;
+                    mine = mask_route(n_new, s_len, inline_cap, heavy_cap, kCap) == MK_TILE_A;
+                } else {
+                    const HeavyItem it = items[task.start + k];
+                    e = it.e;
+                    load_row32(row32, it.u, s_start, s_len);
+                    deg_v = n_new;
+                    mine = true;
+                }
+            }
+            const uint64_t todo = __ballot(mine);
+            // Waves only meet when the tile changes (a barrier per task made every wave wait for the task's slowest:
+            // 72 % of the wave cycles were waits); between two changes each wave works through its share of the tasks
+            // at its own pace.
+            if (!new_node && todo == 0) continue;
+            if (new_node) {
+                // (a barrier: every wave is done with the old tile) nobody has anything to do in this task -- a
+                // hub's run of short rows?  Then the old tile stays.
+                if (!__syncthreads_or(todo != 0)) continue;
+                n = n_new;
+                t_start = start_new;
+                m = n < kCap ? 1u : (n + kCap - 2u) / (kCap - 1u);
+                nb = (n + m - 1u) / m;
+                uint32_t pow2 = 64u;
+                while (pow2 < nb + 1u) pow2 <<= 1;
+                for (uint32_t i = threadIdx.x; i < pow2; i += kThreads) {
+                    const uint32_t last = (i + 1u) * m < n ? (i + 1u) * m : n;  // one past block i's last entry
+                    tile[i] = i < nb ? col32[t_start + last - 1u] : kTileSentinel;
+                }
+                top4 = pow2 * 2u;  // bytes of the first bisection step: pow2/2 entries
+                mtop = 1u;
+                while (mtop < m) mtop <<= 1;  // first step inside a block (m > 1): covers offsets 0 .. m-1
+                cur_node = task.node;
+                __syncthreads();
+                if (todo == 0) continue;
+            }
+            if (lane < (int)kPerWave) acc[lane][0] = acc[lane][1] = acc[lane][2] = acc[lane][3] = 0u;
+            // the wave's (item, 256 elements) pieces, one after the other; the next piece's elements are on their way
+            // while this one's are searched.  Buffer loads: lanes beyond the row's end read 0 (no exec-mask region
+            // per load), and are kept out where a hit is looked at.
+            uint64_t left = todo;
+            int src = left ? __builtin_ctzll(left) : -1;
+            uint32_t base = 0;
+            uint32_t xn[4];
+            auto fetch = [&](int item, uint32_t from) {
+                const uint32_t i_start = __builtin_amdgcn_readlane(s_start, item), i_len = __builtin_amdgcn_readlane(s_len, item);
+                const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(col32 + i_start + from), 0,
+                                                                    (int)((i_len - from) * 4u), 0x00020000);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xn[r] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (lane + 64 * r) * 4, 0, 0);
+            };
+            if (src >= 0) fetch(src, 0u);
+            while (src >= 0) {
+                const int item = src;
+                const uint32_t from = base;
+                const uint32_t i_len = __builtin_amdgcn_readlane(s_len, item);
+                uint32_t x[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] = xn[r];
+                base += 256u;
+                if (base >= i_len) {
+                    left &= left - 1;
+                    src = left ? __builtin_ctzll(left) : -1;
+                    base = 0;
+                }
+                if (src >= 0) fetch(src, base);
+                const uint32_t rest = i_len - from;  // (wave-uniform)
+                // The kernel is bound by the NUMBER of vector instructions (4 cycles each on a SIMD, whatever they
+                // are: 82 % VALU-busy when a level took five): a level of the bisection is add, ds_read, compare,
+                // select, and a piece shorter than 256 elements searches only the 64-element groups it has.
+                // `qa` = LDS address of the last tile entry known to be < x (tile[-1] to start with).
+                auto search = [&](auto groups) {
+                    constexpr int kR = decltype(groups)::value;
+                    uint32_t qa[kR];
+#pragma unroll
+                    for (int r = 0; r < kR; ++r) qa[r] = tile_lds - 4u;
+                    for (uint32_t s4 = top4; s4 >= 4u; s4 >>= 1) {
+#pragma unroll
+                        for (int r = 0; r < kR; ++r) {
+                            const uint32_t a = qa[r] + s4;
+                            const uint32_t t = *reinterpret_cast<const lds_u32 *>((uintptr_t)a);
+                            qa[r] = t < x[r] ? a : qa[r];
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < kR; ++r) {
+                        const uint32_t at_lane = 64u * r + (uint32_t)lane;
+                        const bool live = at_lane < rest;
+                        const uint32_t jb = (qa[r] + 4u - tile_lds) >> 2;  // tile entries < x
+                        uint32_t pos = jb;                                   // entries of the ROW < x
+                        bool hit;
+                        if (m == 1u) {  // (workgroup-uniform) the tile is the row
+                            hit = live && *reinterpret_cast<const lds_u32 *>((uintptr_t)(qa[r] + 4u)) == x[r];
+                        } else {  // x can only be in block jb: its entries below the block's last one, in global memory
+                            const uint32_t lo = jb * m;
+                            const uint32_t len = (live && jb < nb) ? (n - lo < m ? n - lo : m) : 0u;
+                            uint32_t off = 0;
+                            for (uint32_t step = mtop >> 1; step; step >>= 1) {
+                                const uint32_t p = off + step;
+                                if (p <= len && col32[t_start + lo + p - 1u] < x[r]) off = p;
+                            }
+                            pos = lo + off;
+                            hit = off < len && col32[t_start + pos] == x[r];
+                        }
+                        if (hit) {
+                            if (task.mode == 0u) {  // element idx of v's row is in u's row
+                                const uint32_t idx = from + at_lane;
+                                atomicOr(&acc[item][(idx >> 5) & 3u], 1u << (idx & 31u));
+                            } else if (m == 1u) {  // this element of u's row sits at pos .. of v's row (a run: parallel edges)
+                                uint32_t qb = qa[r] + 4u;
+                                do {
+                                    const uint32_t at = (qb - tile_lds) >> 2;
+                                    atomicOr(&acc[item][(at >> 5) & 3u], 1u << (at & 31u));
+                                    qb += 4u;
+                                } while (*reinterpret_cast<const lds_u32 *>((uintptr_t)qb) == x[r]);  // (the padding ends every run)
+                            } else {
+                                do {
+                                    atomicOr(&acc[item][(pos >> 5) & 3u], 1u << (pos & 31u));
+                                    ++pos;
+                                } while (pos < n && col32[t_start + pos] == x[r]);
+                            }
+                        }
+                    }
+                };
+                if (rest <= 64u) search(std::integral_constant<int, 1>{});
+                else if (rest <= 128u) search(std::integral_constant<int, 2>{});
+                else search(std::integral_constant<int, 4>{});
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (mine) {
+                u32x4_a16 mm = {acc[lane][0], acc[lane][1], acc[lane][2], acc[lane][3]};
+                ext[2 * (size_t)e + 1] = mm;
+                if (deg_v <= 128u) reinterpret_cast<uint32_t *>(ext + 2 * (size_t)e)[2] = deg_v;  // exact: drop the filter bit
+            }
+            __builtin_amdgcn_wave_barrier();  // (the next task clears acc)
         }
     }
 }
