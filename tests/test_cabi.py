@@ -78,7 +78,7 @@ def test_workspace_bytes():
     assert f(n, nnz, N, L, 1.0, 1.0, 2) == head                       # uniform on the walker stream: int64 kernels
     table = 16 * 1024                                                 # edge table: >= 3 slots per edge, >= 1024 slots
     fat = 32 * nnz                                                    # 32-byte entries of the biased walk
-    assert shadow + table + fat <= f(n, nnz, N, L, 0.5, 2.0, 2) - head <= shadow + table + fat + 6 * 256
+    assert shadow + table + fat <= f(n, nnz, 1, L, 0.5, 2.0, 2) - head <= shadow + table + fat + 6 * 256   # 4 steps per entry
     uniform = f(n, nnz, N, L, 1.0, 1.0, 0)                            # windows + shadow; rows written in place
     assert head + N * 124 + shadow <= uniform < head + N * 124 + shadow + stage
     assert f(2**31, nnz, N, L, 0.5, 2.0, 2) == head                   # too many nodes for the uint32 shadow
@@ -91,7 +91,9 @@ def test_workspace_bytes():
     w = lib.trw_walk_csr_prepared_workspace_bytes
     assert w(N, L, 0.5, 2.0, 2) == 256 and 256 + N * 124 <= w(N, L, 1.0, 1.0, 0) < 256 + N * 124 + 1024
     plan = lib.trw_prepare_plan
-    assert plan(n, nnz, N, L, 0.5, 2.0, 2) == 2 and plan(1000, 10**6, 100, L, 0.5, 2.0, 2) == 0
+    assert plan(n, nnz, 1, L, 0.5, 2.0, 2) == 2 and plan(1000, 10**6, 100, L, 0.5, 2.0, 2) == 0
+    # one call that makes 5 / 14 steps per entry brings the masks of rows up to 256 / 1 024 entries along
+    assert plan(n, nnz, 2, L, 0.5, 2.0, 2) == 2 | 4 and plan(n, nnz, N, L, 0.5, 2.0, 2) == 2 | 4 | 8
     assert plan(1000, 10**8, 5, 6, 0.5, 2.0, 1) == -1 and plan(n, nnz, N, L, 1.0, 1.0, 2) == -2
     assert plan(n, nnz, N, L, 0.5, 2.0, 1) == 2          # a serial replay of this many steps rides the prepared graph
     # a graph the size of BASELINE configs[3] keeps the table path: 2^32 slots (64-bit slot arithmetic)

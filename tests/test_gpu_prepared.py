@@ -28,7 +28,8 @@ def _dev(*arrays):
     return [torch.as_tensor(np.asarray(a), dtype=torch.int64).to(DEV) for a in arrays]
 
 
-def test_second_walk_reuses_the_prepared_graph_and_third_has_full_marks(rw):
+def test_second_walk_reuses_the_prepared_graph_and_third_has_full_marks(rw, monkeypatch):
+    monkeypatch.setenv("TRW_PLAN_MARKS_AT", "1000000")   # (a call this size would bring the marks along by itself, see below)
     rp, ci = hub_graph(3000, 6)
     tg = np.random.default_rng(2).integers(0, 3000, 20_000)
     d_rp, d_ci, d_tg = _dev(rp, ci, tg)
@@ -56,9 +57,12 @@ def test_second_walk_reuses_the_prepared_graph_and_third_has_full_marks(rw):
     rw.check_status()
 
 
-def test_masks_of_longer_rows_join_with_the_steps_made_unless_prepared_by_hand(rw):
+def test_masks_of_longer_rows_join_with_the_steps_made_unless_prepared_by_hand(rw, monkeypatch):
     """The wave-per-entry marking passes are built by the first node2vec walk that finds 6 (rows up to 256) / 55 (up to
-    1 024) steps per CSR entry behind it on this graph -- never by the first walk, never behind rw.prepare()'s back."""
+    1 024) steps per CSR entry behind it on this graph -- never behind rw.prepare()'s back; by the first walk only when
+    that one call makes 5 / 14 steps per entry itself (trw_prepare_plan; the tile pass made the marks that cheap)."""
+    monkeypatch.setenv("TRW_PLAN_MARKS_AT", "1000000")
+    monkeypatch.setenv("TRW_PLAN_FULL_AT", "1000000")
     rp, ci = hub_graph(1500, 6)
     tg = np.random.default_rng(3).integers(0, 1500, 8000)
     d_rp, d_ci, d_tg = _dev(rp, ci, tg)
@@ -80,6 +84,16 @@ def test_masks_of_longer_rows_join_with_the_steps_made_unless_prepared_by_hand(r
         rw.walk(d_rp, d_ci, d_tg, 0.25, 4.0, 12, 4)
     assert rw.cache_info()[0][2] == rw.PREP_BIASED
     rw.check_status()
+    # one call that makes enough steps by itself brings the marks along (the default plan)
+    monkeypatch.delenv("TRW_PLAN_MARKS_AT")
+    monkeypatch.delenv("TRW_PLAN_FULL_AT")
+    for walkers, want in ((nnz * 4 // 12, rw.PREP_BIASED), (nnz * 6 // 12, rw.PREP_BIASED | rw.PREP_MARKS),
+                          (nnz * 15 // 12, rw.PREP_BIASED | rw.PREP_MARKS | rw.PREP_MARKS_FULL)):
+        rw.clear_cache()
+        t = torch.as_tensor(np.resize(tg, walkers)).to(DEV)
+        got = rw.walk(d_rp, d_ci, t, 0.25, 4.0, 12, 4)
+        assert rw.cache_info()[0][2] == want, (walkers, rw.cache_info()[0][2])
+        assert (got.cpu().numpy() == O.walk(rp, ci, np.resize(tg, walkers), 0.25, 4.0, 12, 4, rng_mode=O.RNG_WALKER)).all()
 
 
 def test_uniform_entries_join_once_the_calls_add_up_to_the_graph(rw):
@@ -160,8 +174,9 @@ def test_entries_die_with_their_tensors_and_lru(rw):
 
 @pytest.mark.parametrize("deg,inline_cap", [(5, None), (60, None), (60, "0"), (150, None), (150, "4096"), (150, "0")])
 def test_every_marking_path_walks_the_same_rows(rw, deg, inline_cap, monkeypatch):
-    """Masks worked out by the owning thread (short rows), by the wave-per-entry pass (rows of 33..4096), exact
+    """Masks worked out by the owning thread (short rows), by the tile pass (rows of 33..4096), exact
     (rows <= 128) and as filters (longer rows: set bits ask the table), or not at all (cap 0 without marks)."""
+    monkeypatch.setenv("TRW_PLAN_MARKS_AT", "1000000")          # (first walk: entries only; second: the cache adds the marks)
     if inline_cap is not None:
         monkeypatch.setenv("TRW_COMMON_MAX", inline_cap)
     rp, ci = random_graph(400, deg, 11)

@@ -224,8 +224,16 @@ int32_t plan_what(int64_t n_nodes, int64_t nnz, int64_t n_walkers, int32_t L, bo
         return (forced == 1 || (forced == -1 && worth)) ? TRW_PREP_UNIFORM : 0;
     }
     const long forced = env_long("TRW_HASH", 0, 1, -1);
-    const bool worth = (__int128)n_walkers * L >= (__int128)nnz / 2;
-    return (forced == 1 || (forced == -1 && worth)) ? TRW_PREP_BIASED : 0;
+    const __int128 steps = (__int128)n_walkers * L;
+    const bool worth = steps >= (__int128)nnz / 2;
+    if (!(forced == 1 || (forced == -1 && worth))) return 0;
+    // The masks of longer rows, since the tile pass made them cheap (R-MAT 10M/110M: 35 ms for table + entries, +23 ms
+    // for rows up to 256, +17 ms up to 1 024; a walk of 7.3 steps per entry: 82 / 47 / 37.5 ms): one call is worth
+    // the first from 5 steps per entry on, the second from 14.
+    int32_t what = TRW_PREP_BIASED;
+    if (steps >= (__int128)nnz * env_long("TRW_PLAN_MARKS_AT", 0, 1 << 20, 5)) what |= TRW_PREP_MARKS;
+    if (steps >= (__int128)nnz * env_long("TRW_PLAN_FULL_AT", 0, 1 << 20, 14)) what |= TRW_PREP_MARKS | TRW_PREP_MARKS_FULL;
+    return what;
 }
 
 // Per-call scratch of a walk over a prepared graph: the status block and the uniform walk's RNG windows.
@@ -555,25 +563,29 @@ int trw_prepare_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *
             if (tiles) {
                 TileTask *tasks = (TileTask *)(ws + pl.off_tasks);
                 u32x4_a16 *ext32 = (u32x4_a16 *)(ws + pl.off_ext32);
+                // Rows of fewer than `small_row` entries are tiles of ONE wave each (no barrier anywhere: 0.52 M of the
+                // 0.53 M rows that are tiles on R-MAT 10M/110M, 69 % of the searches), longer ones of a workgroup of 8.
+                const long shape = env_long("TRW_TILE_SHAPE", 0, 3, 3);
+                const uint32_t small_row = shape == 3 ? 0u : (shape == 1 ? 1024u : 2048u);
                 heavy_plan_kernel<<<stream_grid(n_nodes), kBlock, 0, stream>>>(row32, n_nodes, in_count, in_off, tasks,
-                                                                               pl.task_room, pl.heavy_room, inline_cap, header);
+                                                                               pl.task_room, pl.heavy_room, inline_cap,
+                                                                               small_row, header);
                 heavy_scatter_kernel<<<stream_grid(n_nodes), kBlock, 0, stream>>>(row32, col32, n_nodes, inline_cap,
                                                                                   heavy_cap, in_count, in_off, heavy);
-                // tile size / workgroup shape: LDS per workgroup decides how many waves a CU holds
-                const long shape = env_long("TRW_TILE_SHAPE", 0, 3, 0);
                 const unsigned cus = (unsigned)device_cu_count();
+                const uint32_t room_small = pl.task_room - pl.task_room / 4u, room_big = pl.task_room / 4u;
+                const TileTask *tasks_big = tasks + room_small;
+                heavy_tile_kernel<8192, 512, true><<<cus * 4, 512, 0, stream>>>(row32, col32, ext32, heavy, tasks_big, room_big,
+                                                                                inline_cap, heavy_cap, header);
                 if (shape == 0)
-                    heavy_tile_kernel<16384, 512><<<cus * 2, 512, 0, stream>>>(row32, col32, ext32, heavy, tasks, pl.task_room,
-                                                                               inline_cap, heavy_cap, header);
+                    heavy_tile_kernel<2048, 64, false><<<cus * 16, 64, 0, stream>>>(row32, col32, ext32, heavy, tasks, room_small,
+                                                                                    inline_cap, heavy_cap, header);
                 else if (shape == 1)
-                    heavy_tile_kernel<8192, 512><<<cus * 4, 512, 0, stream>>>(row32, col32, ext32, heavy, tasks, pl.task_room,
-                                                                              inline_cap, heavy_cap, header);
+                    heavy_tile_kernel<1024, 64, false><<<cus * 28, 64, 0, stream>>>(row32, col32, ext32, heavy, tasks, room_small,
+                                                                                    inline_cap, heavy_cap, header);
                 else if (shape == 2)
-                    heavy_tile_kernel<8192, 256><<<cus * 4, 256, 0, stream>>>(row32, col32, ext32, heavy, tasks, pl.task_room,
-                                                                              inline_cap, heavy_cap, header);
-                else
-                    heavy_tile_kernel<4096, 256><<<cus * 8, 256, 0, stream>>>(row32, col32, ext32, heavy, tasks, pl.task_room,
-                                                                              inline_cap, heavy_cap, header);
+                    heavy_tile_kernel<2048, 128, false><<<cus * 8, 128, 0, stream>>>(row32, col32, ext32, heavy, tasks, room_small,
+                                                                                     inline_cap, heavy_cap, header);
             }
             if (pl.marks && !tiles)
                 csr_ext32_heavy_kernel<<<(unsigned)(device_cu_count() * 8), kBlock, 0, stream>>>(

@@ -746,24 +746,33 @@ __device__ __forceinline__ uint32_t edge_hash(uint32_t u, uint32_t v)
     return h;
 }
 
-// Slot of edge (u, v) in a table of mask+1 slots (a power of two).  Tables beyond 2^32 slots (graphs with more
-// than ~1.4e9 entries) take a second hash word for the high bits; `mask` is wave-uniform, so is the branch.
-__device__ __forceinline__ uint64_t edge_slot(uint32_t u, uint32_t v, uint64_t mask)
-{
-    uint64_t h = edge_hash(u, v);
-    if (mask > 0xFFFFFFFFull) h |= (uint64_t)edge_hash(v ^ 0x9E3779B9u, u + 0x7F4A7C15u) << 32;
-    return h & mask;
-}
+// The edge set (round 4: 16 bytes per edge where the table of {u, v, first offset, multiplicity} slots took 78).
+// Keys of 8 bytes {u, v} (u == 0xFFFFFFFF: free) in BLOCKS of four -- 32 bytes, an aligned half of a cache line, what a
+// probe reads anyway -- `nb` blocks, any number (>= 2 keys per edge: load <= 0.5; the block of an edge is
+// mulhi(hash, nb), no power of two needed).  A key lives in the first free place of its home block or of the blocks
+// after it, so places fill in order: a lookup that meets a free place has seen everything its key could be behind.
+// Walkers only ever ask "is (a, b) an edge"; WHERE b sits in a's row -- the prepare pass wants it for rpos and for
+// the masks, the walk for the rare run of parallel edges that does not fit rpos -- is a bisection of the sorted row
+// on a hit (row_find32).
+__device__ __forceinline__ uint32_t edge_block(uint32_t u, uint32_t v, uint32_t nb) { return __umulhi(edge_hash(u, v), nb); }
 
-// table: `mask`+1 slots of {u, v, lo, cnt-1}, all bytes 0xFF when empty.
+// One 16-byte half of a block, g = {u0, v0, u1, v1}: is (a, b) one of the two keys / is the chain over here?
+template <class V4>
+__device__ __forceinline__ bool half_has(const V4 &g, uint32_t a, uint32_t b)
+{
+    return (g.x == a && g.y == b) || (g.z == a && g.w == b);
+}
+template <class V4>
+__device__ __forceinline__ bool half_ends(const V4 &g) { return g.z == 0xFFFFFFFFu; }  // (places fill in order)
+
+// table: nb blocks of four keys, all bytes 0xFF when empty.
 // Each thread owns 8 consecutive entries: one bisection of row32 finds the row of the first,
 // the others follow by walking row32 forward.  With sorted rows (the shadow pass counted no
-// descent inside a row) equal neighbours are adjacent, so the first entry of a run claims the
-// slot with ONE compare-and-swap and stores offset and multiplicity plainly; otherwise every
-// entry goes through CAS + min + add.
+// descent inside a row) equal neighbours are adjacent and only the first entry of a run is inserted;
+// otherwise every entry is, and a parallel edge finds its key there already.
 __global__ void __launch_bounds__(kBlock)
 edge_table_build_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32, int64_t n_nodes,
-                        int64_t nnz, uint32_t *__restrict__ table, uint64_t mask,
+                        int64_t nnz, uint32_t *__restrict__ table, uint32_t nb,
                         const int64_t *__restrict__ status)
 {
     constexpr int kPer = 8;
@@ -795,28 +804,17 @@ edge_table_build_kernel(const uint32_t *__restrict__ row32, const uint32_t *__re
             }
             if (e < e_first || e >= e_last) continue;
             const uint32_t v = col32[e];
-            uint32_t cnt = 1;
-            if (sorted) {
-                if (e > row_lo && col32[e - 1] == v) continue;  // not the first of its run
-                while (e + cnt < row_hi && col32[e + cnt] == v) ++cnt;
-            }
+            if (sorted && e > row_lo && col32[e - 1] == v) continue;  // not the first of its run: one key per distinct edge
             const unsigned long long key = ((unsigned long long)v << 32) | u;
-            uint64_t slot = edge_slot(u, v, mask);
-            while (true) {
-                uint32_t *ent = table + 4 * slot;
-                const unsigned long long old = atomicCAS((unsigned long long *)ent, ~0ull, key);
-                if (sorted) {
-                    if (old == ~0ull) {
-                        ent[2] = e - row_lo;
-                        ent[3] = cnt - 1u;
-                        break;
-                    }
-                } else if (old == ~0ull || old == key) {
-                    atomicMin(ent + 2, e - row_lo);
-                    atomicAdd(ent + 3, 1u);  // 0xFFFFFFFF + k = k - 1
-                    break;
+            unsigned long long *keys = (unsigned long long *)table;
+            uint32_t b = edge_block(u, v, nb);
+            for (bool placed = false; !placed;) {
+#pragma unroll
+                for (int j = 0; j < 4 && !placed; ++j) {
+                    const unsigned long long old = atomicCAS(keys + 4 * (size_t)b + j, ~0ull, key);
+                    placed = old == ~0ull || old == key;  // (old == key: a parallel edge of an unsorted row)
                 }
-                slot = (slot + 1) & mask;
+                b = b + 1u == nb ? 0u : b + 1u;
             }
         }
     }
@@ -846,20 +844,16 @@ constexpr uint32_t kMaskIsFilter = 0x80000000u;  // top bit of the deg word (row
 constexpr uint32_t kNoCommon = kMaskIsFilter;    // (name used by the unsorted-rows kernel when it strips the bit)
 constexpr int kStHeavyCount = 11;                // status slot of the PREPARED header: entries queued for the heavy pass
 
-// is (a -> b) an edge?  (one probe chain of the edge table); lo/cnt: first offset of b in a's row, multiplicity
-__device__ __forceinline__ bool edge_table_find(const uint32_t *__restrict__ table, uint64_t mask, uint32_t a,
-                                                uint32_t b, uint32_t &lo, uint32_t &cnt)
+// is (a -> b) an edge?  (one probe chain of the edge set, a block -- both halves, one line -- at a time)
+__device__ __forceinline__ bool edge_table_find(const uint32_t *__restrict__ table, uint32_t nb, uint32_t a, uint32_t b)
 {
-    uint64_t slot = edge_slot(a, b, mask);
+    uint32_t blk = edge_block(a, b, nb);
     while (true) {
-        const u32x4_a16 g = *reinterpret_cast<const u32x4_a16 *>(table + 4 * slot);
-        if (g.x == 0xFFFFFFFFu) return false;
-        if (g.x == a && g.y == b) {
-            lo = g.z;
-            cnt = g.w + 1u;
-            return true;
-        }
-        slot = (slot + 1) & mask;
+        const u32x4_a16 g0 = *reinterpret_cast<const u32x4_a16 *>(table + 8 * (size_t)blk);
+        const u32x4_a16 g1 = *reinterpret_cast<const u32x4_a16 *>(table + 8 * (size_t)blk + 4);
+        if (half_has(g0, a, b) || half_has(g1, a, b)) return true;
+        if (half_ends(g0) || half_ends(g1)) return false;
+        blk = blk + 1u == nb ? 0u : blk + 1u;
     }
 }
 
@@ -916,20 +910,23 @@ __device__ __forceinline__ uint32_t row_find32(const uint32_t *__restrict__ col3
 //                       over long rows does best (rows up to 4096: 212 ms instead of 354 ms with table probes)
 // The caller's lane handles entries first, first+stride, ... of the shorter row.
 __device__ __forceinline__ void common_mask_table(const uint32_t *__restrict__ col32, const uint32_t *__restrict__ table,
-                                                  uint64_t tmask, uint32_t u, uint32_t u_lo, uint32_t u_hi, uint32_t v,
+                                                  uint32_t nb, uint32_t u, uint32_t u_lo, uint32_t u_hi, uint32_t v,
                                                   uint32_t v_start, uint32_t v_deg, Mask128 &m)
 {
     const uint32_t u_deg = u_hi - u_lo;
-    uint32_t lo, cnt;
     if (u_deg <= v_deg) {  // walk u's row: each distinct w in it, looked up in v's row
         for (uint32_t i = 0; i < u_deg; ++i) {
             const uint32_t w = col32[u_lo + i];
             if (i > 0 && col32[u_lo + i - 1] == w) continue;  // sorted rows: a run of equal entries is one node
-            if (edge_table_find(table, tmask, v, w, lo, cnt)) m.set_run(lo, cnt);
+            if (edge_table_find(table, nb, v, w)) {  // a common neighbour: where it sits in v's row
+                uint32_t run;
+                const uint32_t lo = row_find32(col32, v_start, v_deg, w, run);
+                m.set_run(lo, run);
+            }
         }
     } else {  // walk v's row: the node at each offset, looked up in u's row
         for (uint32_t j = 0; j < v_deg; ++j)
-            if (edge_table_find(table, tmask, u, col32[v_start + j], lo, cnt)) m.set(j);
+            if (edge_table_find(table, nb, u, col32[v_start + j])) m.set(j);
     }
 }
 
@@ -1034,7 +1031,7 @@ __device__ __forceinline__ uint32_t mask_route(uint32_t deg_u, uint32_t deg_v, u
 
 __global__ void __launch_bounds__(kBlock)
 csr_ext32_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32, int64_t n_nodes,
-                 int64_t nnz, const uint32_t *__restrict__ table, uint64_t tmask, uint32_t inline_cap,
+                 int64_t nnz, const uint32_t *__restrict__ table, uint32_t tnb, uint32_t inline_cap,
                  uint32_t heavy_cap, uint32_t tile_cap, u32x4_a16 *__restrict__ ext, HeavyItem *__restrict__ heavy,
                  uint32_t heavy_room, uint32_t *__restrict__ in_count, int64_t *__restrict__ header)
 {
@@ -1071,14 +1068,16 @@ csr_ext32_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict_
             m.fill();
             uint32_t flag = kMaskIsFilter, rpos = kRposAbsent;
             if (e >= e_first && e < e_last) {
-                uint32_t lo, cnt;
-                if (edge_table_find(table, tmask, v, u, lo, cnt))
-                    rpos = (cnt <= 15u && lo < (1u << 28)) ? ((cnt << 28) | lo) : kRposLookup;
+                if (edge_table_find(table, tnb, v, u)) {  // the reverse edge exists: where u sits in v's row
+                    uint32_t cnt = 0;
+                    const uint32_t lo = sorted ? row_find32(col32, start, deg, u, cnt) : 0u;
+                    rpos = (sorted && cnt <= 15u && lo < (1u << 28)) ? ((cnt << 28) | lo) : kRposLookup;
+                }
                 const uint32_t deg_u = row_hi - row_lo;
                 const uint32_t route = sorted ? mask_route(deg_u, deg, inline_cap, heavy ? heavy_cap : 0u, tile_cap) : MK_NONE;
                 if (route == MK_INLINE) {
                     m.clear();
-                    common_mask_table(col32, table, tmask, u, row_lo, row_hi, v, start, deg, m);
+                    common_mask_table(col32, table, tnb, u, row_lo, row_hi, v, start, deg, m);
                     flag = deg > 128u ? kMaskIsFilter : 0u;
                 } else if (route == MK_QUEUE) {
                     const uint32_t at = (uint32_t)atomicAdd((unsigned long long *)&header[kStHeavyCount], 1ull);
@@ -1098,7 +1097,7 @@ csr_ext32_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict_
 // The queued entries, one wave each: 64 lanes stride over the shorter row, OR their masks together.
 __global__ void __launch_bounds__(kBlock)
 csr_ext32_heavy_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32,
-                       const uint32_t *__restrict__ table, uint64_t tmask, u32x4_a16 *__restrict__ ext,
+                       u32x4_a16 *__restrict__ ext,
                        const HeavyItem *__restrict__ heavy, uint32_t heavy_room, const int64_t *__restrict__ header)
 {
     __shared__ uint32_t piv_mem[kBlock / 64][64];
@@ -1150,13 +1149,16 @@ csr_ext32_heavy_kernel(const uint32_t *__restrict__ row32, const uint32_t *__res
 // row are consecutive, the tile stays -- and each wave streams the shorter rows of its share of the task's items,
 // four elements per lane at a time.  Every global load is a coalesced stream; the only random accesses left are
 // LDS reads.
-constexpr uint32_t kTaskEntries = 128;   // MK_TILE_A: entries of the tile row per task
+constexpr uint32_t kTaskEntries = 128;   // MK_TILE_A: entries of the tile row per task (rows of kSmallRow entries or more)
+constexpr uint32_t kTaskEntriesSmall = 64;  // ... of a shorter row: a task is one wave's
 constexpr uint32_t kTaskItems = 64;      // MK_TILE_B: in-list items per task
 #ifndef TRW_TASK_GRAB
 #define TRW_TASK_GRAB 16
 #endif
 constexpr uint32_t kTaskGrab = TRW_TASK_GRAB;  // consecutive tasks a workgroup takes from the counter at a time
-constexpr int kStTaskCount = 16, kStSortedCursor = 17, kStTaskNext = 18;  // header slots
+// header slots; tasks of short rows (one wave each, heavy_tile_kernel<.., 64, ..>) fill the task array from the front, those
+// of long rows (a workgroup each) the last quarter
+constexpr int kStTaskCount = 16, kStSortedCursor = 17, kStTaskNext = 18, kStTaskCountBig = 19, kStTaskNextBig = 20;
 constexpr uint32_t kNoSegment = 0xFFFFFFFFu;
 
 struct TileTask {
@@ -1167,7 +1169,7 @@ struct TileTask {
 __global__ void __launch_bounds__(kBlock)
 heavy_plan_kernel(const uint32_t *__restrict__ row32, int64_t n_nodes, const uint32_t *__restrict__ in_count,
                   uint32_t *__restrict__ in_off, TileTask *__restrict__ tasks, uint32_t task_room, uint32_t heavy_room,
-                  uint32_t inline_cap, int64_t *__restrict__ header)
+                  uint32_t inline_cap, uint32_t small_row, int64_t *__restrict__ header)
 {
     if (header[kStDescents] != header[kStBoundary]) return;  // rows not sorted: no masks, no tasks
     const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -1185,17 +1187,21 @@ heavy_plan_kernel(const uint32_t *__restrict__ row32, int64_t n_nodes, const uin
             in_off[x] = seg;  // kNoSegment: no room, these entries keep their all-ones masks
         }
         // MK_TILE_A needs deg > deg(v) > inline_cap
-        const uint32_t n_a = deg >= inline_cap + 2u ? (deg + kTaskEntries - 1u) / kTaskEntries : 0u;
+        const bool big = deg >= small_row;
+        const uint32_t per_a = big ? kTaskEntries : kTaskEntriesSmall;
+        const uint32_t n_a = deg >= inline_cap + 2u ? (deg + per_a - 1u) / per_a : 0u;
         const uint32_t n_b = seg != kNoSegment ? (c + kTaskItems - 1u) / kTaskItems : 0u;
         if (n_a + n_b == 0u) continue;
-        const uint64_t at = atomicAdd((unsigned long long *)&header[kStTaskCount], (unsigned long long)(n_a + n_b));
+        const uint32_t room = big ? task_room / 4u : task_room - task_room / 4u;
+        TileTask *const list = big ? tasks + (task_room - task_room / 4u) : tasks;
+        const uint64_t at = atomicAdd((unsigned long long *)&header[big ? kStTaskCountBig : kStTaskCount], (unsigned long long)(n_a + n_b));
         for (uint32_t k = 0; k < n_a + n_b; ++k) {
-            if (at + k >= task_room) break;
+            if (at + k >= room) break;
             TileTask t;
             t.node = (uint32_t)x;
             if (k < n_a) {
-                t.start = start + k * kTaskEntries;
-                t.count = deg - k * kTaskEntries < kTaskEntries ? deg - k * kTaskEntries : kTaskEntries;
+                t.start = start + k * per_a;
+                t.count = deg - k * per_a < per_a ? deg - k * per_a : per_a;
                 t.mode = 0u;
             } else {
                 const uint32_t kb = k - n_a;
@@ -1203,7 +1209,7 @@ heavy_plan_kernel(const uint32_t *__restrict__ row32, int64_t n_nodes, const uin
                 t.count = c - kb * kTaskItems < kTaskItems ? c - kb * kTaskItems : kTaskItems;
                 t.mode = 1u;
             }
-            tasks[at + k] = t;
+            list[at + k] = t;
         }
     }
 }
@@ -1252,14 +1258,17 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 // tile whole.  Of a longer one (a few hundred rows of R-MAT 10M/110M, but 11 % of the searches) the tile holds every
 // m-th entry -- the last of each block of m = ceil(n / (kCap-1)) --, the bisection in LDS finds the block and the last
 // log2(m) levels read the block in global memory (L2 hits: 1 level for a row of 8-16 K entries, 5 for the longest).
-template <uint32_t kCap, int kThreads>
+// kBig: the list of long rows' tasks (128 entries each) / of short rows' (64 each; `tasks`, `task_room`: that list).
+template <uint32_t kCap, int kThreads, bool kBig>
 __global__ void __launch_bounds__(kThreads)
 heavy_tile_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32, u32x4_a16 *__restrict__ ext,
                   const HeavyItem *__restrict__ items, const TileTask *__restrict__ tasks, uint32_t task_room,
                   uint32_t inline_cap, uint32_t heavy_cap, int64_t *__restrict__ header)
 {
     constexpr uint32_t kWaves = kThreads / 64;
-    constexpr uint32_t kPerWave = (kTaskEntries > kTaskItems ? kTaskEntries : kTaskItems) / kWaves;  // items of a task per wave
+    constexpr uint32_t kEntries = kBig ? kTaskEntries : kTaskEntriesSmall;
+    constexpr uint32_t kPerWave = (kEntries > kTaskItems ? kEntries : kTaskItems) / kWaves;  // items of a task per wave
+    constexpr int kCountSlot = kBig ? kStTaskCountBig : kStTaskCount, kNextSlot = kBig ? kStTaskNextBig : kStTaskNext;
     static_assert(kPerWave <= 64 && (kCap & (kCap - 1)) == 0, "one lane per item; power-of-two tile");
     constexpr uint32_t kHead = kWaves * kPerWave * 4 + 4;  // words in front of the tile: the waves' masks, `grabbed`
     __shared__ uint32_t lds[kHead + kCap];
@@ -1270,13 +1279,13 @@ heavy_tile_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
     const uint32_t tile_lds = (uint32_t)reinterpret_cast<uintptr_t>(tile);
     const int lane = threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6;
-    const uint64_t made = (uint64_t)header[kStTaskCount];
+    const uint64_t made = (uint64_t)header[kCountSlot];
     const uint32_t n_tasks = made < task_room ? (uint32_t)made : task_room;
     // the tile holds cur_node's row [t_start, t_start + n): every m-th entry, nb of them; the bisection's first step is top4 bytes
     uint32_t cur_node = 0xFFFFFFFFu, n = 0, t_start = 0, m = 1, nb = 0, top4 = 0, mtop = 0;
     while (true) {
         __syncthreads();  // (everyone has read `grabbed` of the last round)
-        if (threadIdx.x == 0) grabbed = (uint32_t)atomicAdd((unsigned long long *)&header[kStTaskNext], (unsigned long long)kTaskGrab);
+        if (threadIdx.x == 0) grabbed = (uint32_t)atomicAdd((unsigned long long *)&header[kNextSlot], (unsigned long long)kTaskGrab);
         __syncthreads();
         const uint32_t t0 = grabbed;
         if (t0 >= n_tasks) break;
@@ -1461,7 +1470,7 @@ constexpr int kTrialsPerIter = TRW_TRIALS_PER_ITER;
 template <bool kCount>
 __global__ void __launch_bounds__(kBlock)
 biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32,
-                   const uint32_t *__restrict__ ext, const uint32_t *__restrict__ table, uint64_t mask, const int64_t *__restrict__ targets,
+                   const uint32_t *__restrict__ ext, const uint32_t *__restrict__ table, uint32_t tnb, const int64_t *__restrict__ targets,
                    int64_t n_nodes, int64_t n_walkers, int64_t walker_base, int32_t L, uint32_t seed,
                    BiasedParams bp, int32_t want_pos, int32_t only_unsorted, int64_t *__restrict__ out,
                    int64_t *__restrict__ status)
@@ -1478,8 +1487,11 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
         status[2] = TRW_RNG_WALKER;
         status[3] = 2;
     }
-    // offsets of t inside prev's row are contiguous only when rows are sorted
-    const bool use_pos = want_pos && status[kStDescents] == status[kStBoundary];
+    // Offsets of t inside prev's row: the edge set answers "is it an edge", not "where" (that was the 16-byte slots'
+    // job until round 4), so this kernel -- the walk over UNSORTED rows, where a node's parallel edges are not one run
+    // anyway -- always looks at its candidate.  (LS_POS and the code under use_pos stay for the day it is wanted.)
+    const bool use_pos = false;
+    (void)want_pos;
     const int lane = threadIdx.x & 63;
     uint32_t *my_ring = ring + threadIdx.x;
     // candidates come from the fat entries (32 bytes each; this kernel reads the first 16: {v, start(v), deg(v),
@@ -1614,12 +1626,12 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                     state = LS_TRIAL;
                 }
             }
-        } else if (run_probe && (state == LS_POS || state == LS_MEMBER)) {  // g = {u, v, lo, cnt-1} of one slot
+        } else if (run_probe && (state == LS_POS || state == LS_MEMBER)) {  // g = one half (two keys) of a block of the edge set
             if (kCount) ++n_probes;
-            const bool empty = g.x == 0xFFFFFFFFu;
-            const bool match = g.x == ku && g.y == kv;
+            const bool match = half_has(g, ku, kv);
+            const bool empty = !match && half_ends(g);
             if (!empty && !match) {
-                slot = (slot + 1) & mask;
+                slot = slot + 1u == 2ull * tnb ? 0u : slot + 1u;
                 addr = table + 4 * slot;
                 fresh = true;
             } else if (state == LS_POS) {  // where t sits in prev's row
@@ -1765,7 +1777,7 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
 
         // ---- start a table probe ----
         if (ev_probe) {
-            slot = edge_slot(ku, kv, mask);
+            slot = 2ull * edge_block(ku, kv, tnb);
             addr = table + 4 * slot;
             fresh = true;
             state = probe_state;
@@ -1813,8 +1825,8 @@ constexpr int kMaskPairs = TRW_MASK_PAIRS;  // Philox blocks (= pairs of trials)
 
 template <bool kCount>
 __global__ void __launch_bounds__(kBlock)
-biased_mask_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restrict__ ext,
-                   const uint32_t *__restrict__ table, uint64_t mask, const int64_t *__restrict__ targets,
+biased_mask_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32, const u32x4_a16 *__restrict__ ext,
+                   const uint32_t *__restrict__ table, uint32_t tnb, const int64_t *__restrict__ targets,
                    int64_t n_nodes, int64_t n_walkers, int64_t walker_base, int32_t L, uint32_t seed, BiasedParams bp,
                    int64_t *__restrict__ out, int64_t *__restrict__ status)
 {
@@ -1895,21 +1907,17 @@ biased_mask_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                 adopt = true;
             } else {  // a candidate from a row whose mask is only a filter: is it in t's row?
                 if (kCount) ++n_tests;
-                slot = edge_slot(t, c0.x, mask);
+                slot = 2ull * edge_block(t, c0.x, tnb);
                 want = 3u;
                 state = MS_MEMBER;
             }
-        } else if (state == MS_MEMBER || state == MS_POS) {  // e0 = {u, v, lo, cnt-1} of one slot
+        } else if (state == MS_MEMBER) {  // e0 = one half (two keys) of a block of the edge set
             if (kCount) ++n_probes;
-            const bool empty = e0.x == 0xFFFFFFFFu;
-            const bool match = state == MS_MEMBER ? (e0.x == t && e0.y == c0.x) : (e0.x == prev && e0.y == t);
+            const bool match = half_has(e0, t, c0.x);
+            const bool empty = !match && half_ends(e0);
             if (!empty && !match) {
-                slot = (slot + 1) & mask;
+                slot = slot + 1u == 2ull * tnb ? 0u : slot + 1u;
                 want = 3u;
-            } else if (state == MS_POS) {  // where t sits in prev's row
-                pos_lo = match ? e0.z : 0u;
-                pos_cnt = match ? e0.w + 1u : 0u;
-                state = MS_TRIAL;
             } else if (ru < (match ? bp.t1 : bp.t2)) {
                 adopt = true;
             } else {
@@ -1951,11 +1959,8 @@ biased_mask_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restri
                 pos_lo = c0.w & 0x0FFFFFFFu;
                 pos_cnt = c0.w >> 28;
                 state = MS_TRIAL;
-                if (c0.w == kRposLookup) {  // too many parallel edges / too far into the row for the packed form
-                    slot = edge_slot(prev, t, mask);
-                    want = 3u;
-                    state = MS_POS;
-                }
+                if (c0.w == kRposLookup)  // too many parallel edges / too far into the row for the packed form: found here
+                    pos_lo = row_find32(col32, p_start, p_deg, t, pos_cnt);
             }
         }
 
@@ -2137,11 +2142,10 @@ constexpr int kPoolWaves = kBlock / 64;
 #define TRW_POOL_REFILL_MIN 8
 #endif
 constexpr uint32_t kPoolIssueMin = TRW_POOL_ISSUE_MIN, kPoolTrialMin = TRW_POOL_TRIAL_MIN, kPoolRefillMin = TRW_POOL_REFILL_MIN;
-enum : uint32_t { PK_ROW = 0, PK_ENTRY = 1, PK_TEST = 2, PK_MEMBER = 3, PK_POS = 4 };  // what a slot's gather is for
+enum : uint32_t { PK_ROW = 0, PK_ENTRY = 1, PK_TEST = 2, PK_MEMBER = 3 };  // what a slot's gather is for
 // kPfExact: the slot's mask bits are exact answers (a filter otherwise); kPfOdd: the stream stands at word 3 of the
 // current block; kPfWide: t's run in prev's row does not fit PF_RPOS
 constexpr uint32_t kPfExact = 1u, kPfOdd = 2u, kPfWide = 8u;
-constexpr uint32_t kPfSkip = 128u;  // table lookup, first pair: the chain starts at the pair's SECOND slot
 constexpr uint32_t kPfKind = 7u << 4, kPfRejShift = 8, kPfRejMask = 0x1FFFFFu << 8, kPfProbeShift = 29, kPfProbe = 7u << 29;
 static_assert(kTrialCap <= (kPfRejMask >> kPfRejShift), "the rejection count must fit its field");
 
@@ -2209,7 +2213,7 @@ enum : int {
 template <bool kCount>
 __global__ void __launch_bounds__(kBlock)
 biased_pool_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32,
-                   const u32x4_a16 *__restrict__ ext, const uint32_t *__restrict__ table, uint64_t mask,
+                   const u32x4_a16 *__restrict__ ext, const uint32_t *__restrict__ table, uint32_t tnb,
                    const int64_t *__restrict__ targets, int64_t n_nodes, int64_t n_walkers, int64_t walker_base, int32_t L,
                    uint32_t seed, BiasedParams bp, int64_t *__restrict__ out, int64_t *__restrict__ status)
 {
@@ -2323,67 +2327,50 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                         P[PF_RPOS][slot] = e0.w;
                         const uint32_t keep = P[PF_FLAGS][slot] & kPfOdd;  // (rejections and probe count start at 0)
                         const uint32_t ex = (e0.z & kMaskIsFilter) ? 0u : kPfExact;
-                        if (e0.w == kRposLookup) {  // too many parallel edges / too far into the row for the packed form
-                            P[PF_FLAGS][slot] = keep | ex | (PK_POS << 4);
-                            to_issue = true;
+                        if (e0.w == kRposLookup) {
+                            // t's run in x's row has too many parallel edges / starts too far in for the packed form:
+                            // found here, by bisection (rare).  It goes where two mask words were; the mask then says
+                            // "look" for every offset.
+                            uint32_t cnt = 0;
+                            const uint32_t lo = row_find32(col32, e0.y, deg, prev, cnt);
+                            u32x4_a16 mm = M[slot];
+                            mm.z = lo;
+                            mm.w = cnt;
+                            M[slot] = mm;
+                            P[PF_FLAGS][slot] = keep | kPfWide;
                         } else {
                             P[PF_FLAGS][slot] = keep | ex;
-                            to_trial = true;
                         }
+                        to_trial = true;
                     }
                 } else if (hkind == PK_TEST) {  // e0.x = a candidate whose mask bit is only a filter: ask the table
                     if (kCount) ++n_tests;
                     P[PF_X][slot] = e0.x;
                     P[PF_FLAGS][slot] = (P[PF_FLAGS][slot] & ~(kPfKind | kPfProbe)) | (PK_MEMBER << 4);
                     to_issue = true;
-                } else {  // PK_MEMBER / PK_POS: e0, e1 = an aligned PAIR of table slots {u, v, lo, cnt-1}
+                } else {  // PK_MEMBER: e0, e1 = a block (four keys) of the edge set -- is (t, x) an edge?
                     if (kCount) ++n_probes;
-                    const uint32_t t = P[PF_T][slot], prev = P[PF_PREV][slot];
-                    const uint32_t ku = hkind == PK_MEMBER ? t : prev, kv = hkind == PK_MEMBER ? P[PF_X][slot] : t;
+                    const uint32_t ku = P[PF_T][slot], kv = P[PF_X][slot];
                     uint32_t flags = P[PF_FLAGS][slot];
-                    const bool skip0 = (flags & kPfSkip) != 0u;  // (set by the issue phase, which has the slot number)
-                    flags &= ~kPfSkip;
-                    bool empty = !skip0 && e0.x == 0xFFFFFFFFu;
-                    bool match = !skip0 && e0.x == ku && e0.y == kv;
-                    if (!empty && !match) {  // the second slot of the pair
-                        empty = e1.x == 0xFFFFFFFFu;
-                        match = e1.x == ku && e1.y == kv;
-                        e0.z = e1.z;
-                        e0.w = e1.w;
-                    }
+                    bool match = half_has(e0, ku, kv) || half_has(e1, ku, kv);
+                    bool empty = !match && (half_ends(e0) || half_ends(e1));
                     if (!empty && !match && (flags & kPfProbe) == kPfProbe) {
                         // the chain is longer than the probe field counts: this lane walks the rest of it here
-                        uint64_t sl = (((edge_slot(ku, kv, mask) >> 1) + 8u) << 1) & mask;
+                        uint32_t blk = edge_block(ku, kv, tnb);
+                        for (int k = 0; k < 8; ++k) blk = blk + 1u == tnb ? 0u : blk + 1u;
                         while (true) {
-                            const u32x4_a16 g = *reinterpret_cast<const u32x4_a16 *>(table + 4 * sl);
+                            const u32x4_a16 g0 = *reinterpret_cast<const u32x4_a16 *>(table + 8 * (size_t)blk);
+                            const u32x4_a16 g1 = *reinterpret_cast<const u32x4_a16 *>(table + 8 * (size_t)blk + 4);
                             if (kCount) ++n_probes;
-                            empty = g.x == 0xFFFFFFFFu;
-                            match = g.x == ku && g.y == kv;
-                            if (empty || match) {
-                                e0.z = g.z;
-                                e0.w = g.w;
-                                break;
-                            }
-                            sl = (sl + 1u) & mask;
+                            match = half_has(g0, ku, kv) || half_has(g1, ku, kv);
+                            empty = !match && (half_ends(g0) || half_ends(g1));
+                            if (empty || match) break;
+                            blk = blk + 1u == tnb ? 0u : blk + 1u;
                         }
                     }
                     if (!empty && !match) {
                         P[PF_FLAGS][slot] = flags + (1u << kPfProbeShift);
                         to_issue = true;
-                    } else if (hkind == PK_POS) {  // where t sits in prev's row
-                        const uint32_t lo = match ? e0.z : 0u, cnt = match ? e0.w + 1u : 0u;
-                        flags &= ~(kPfKind | kPfProbe);
-                        if (cnt <= 15u && lo < (1u << 28)) {
-                            P[PF_RPOS][slot] = cnt ? (cnt << 28 | lo) : 0u;
-                        } else {  // the run goes where two mask words were; the mask then says "look" for every offset
-                            u32x4_a16 mm = M[slot];
-                            mm.z = lo;
-                            mm.w = cnt;
-                            M[slot] = mm;
-                            flags = (flags & ~kPfExact) | kPfWide;
-                        }
-                        P[PF_FLAGS][slot] = flags;
-                        to_trial = true;
                     } else {  // the trial drew inside the band: a neighbour is accepted iff t1 is the upper threshold
                         bool accept = match == band_takes_near;
                         flags &= ~(kPfKind | kPfProbe);
@@ -2527,10 +2514,9 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                     if (kind == PK_ENTRY) {
                         addr = reinterpret_cast<const uint32_t *>(ext + 2 * (size_t)P[PF_AT][slot]);
                     } else {
-                        const uint32_t t = P[PF_T][slot], prev = P[PF_PREV][slot];
-                        const uint64_t s0 = kind == PK_MEMBER ? edge_slot(t, P[PF_X][slot], mask) : edge_slot(prev, t, mask);
-                        addr = table + 4 * ((((s0 >> 1) + (flags >> kPfProbeShift)) << 1) & mask);  // an aligned pair of slots
-                        if ((flags & kPfProbe) == 0u && (s0 & 1u) != 0u) P[PF_FLAGS][slot] = flags | kPfSkip;
+                        uint32_t blk = edge_block(P[PF_T][slot], P[PF_X][slot], tnb) + (flags >> kPfProbeShift);  // (PK_MEMBER)
+                        blk = blk >= tnb ? blk - tnb : blk;
+                        addr = table + 8 * (size_t)blk;  // a block of the edge set: four keys, an aligned half line
                     }
                     e0 = *reinterpret_cast<const u32x4_a4 *>(addr);
                     e1 = *reinterpret_cast<const u32x4_a4 *>(addr + 4);
@@ -2700,8 +2686,8 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
 constexpr int kGlRing = 4096;  // stream positions held in LDS (a power of two)
 
 __global__ void __launch_bounds__(64)
-biased_glibc_wave_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restrict__ ext,
-                         const uint32_t *__restrict__ table, uint64_t mask, const int64_t *__restrict__ targets,
+biased_glibc_wave_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32, const u32x4_a16 *__restrict__ ext,
+                         const uint32_t *__restrict__ table, uint32_t tnb, const int64_t *__restrict__ targets,
                          int64_t n_nodes, int64_t n_walkers, int32_t L, SeedWindow sw, BiasedParams bp,
                          int64_t *__restrict__ out, int64_t *__restrict__ status)
 {
@@ -2774,12 +2760,8 @@ biased_glibc_wave_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__
             pos_cnt = e0.w >> 28;
             if (p_deg == 0) return;
             fm.init_exact(p_deg);
-            if (e0.w == kRposLookup) {  // where t sits in prev's row: ask the table
-                uint32_t lo = 0, cnt = 0;
-                const bool found = edge_table_find(table, mask, prev, t, lo, cnt);
-                pos_lo = found ? lo : 0u;
-                pos_cnt = found ? cnt : 0u;
-            }
+            if (e0.w == kRposLookup)  // where t sits in prev's row: a run too long / too far in for the packed form
+                pos_lo = row_find32(col32, p_start, p_deg, t, pos_cnt);
         };
         // step 1: uniform neighbour of the start node, one draw (rw_cpu.cpp:159)
         {
@@ -2832,10 +2814,7 @@ biased_glibc_wave_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__
                     const unsigned long long pend = tests & before;
                     if (pend == 0) break;
                     bool ok = false;
-                    if ((pend >> lane) & 1ull) {
-                        uint32_t lo, cnt;
-                        ok = edge_table_find(table, mask, t, c0.x, lo, cnt) == band_takes_near;
-                    }
+                    if ((pend >> lane) & 1ull) ok = edge_table_find(table, tnb, t, c0.x) == band_takes_near;
                     accepts |= __ballot(ok);
                     tests &= ~pend;
                 }
