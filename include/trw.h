@@ -170,6 +170,7 @@ int trw_prepare_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *
 #define TRW_REGION_EXT16  3   /* 16-byte entries of the uniform walk */
 #define TRW_REGION_TABLE  4   /* edge table */
 #define TRW_REGION_EXT32  5   /* 32-byte entries of the node2vec walk: {v, start(v), deg(v)|filter, rpos} + 128-bit mask */
+#define TRW_REGION_TASKS  6   /* the tile pass's task records {node, start, count, mode} (scratch of the prepare pass) */
 int trw_prepare_csr_region(int64_t n_nodes, int64_t nnz, int32_t what, int32_t which, size_t *offset, size_t *bytes);
 size_t trw_walk_csr_prepared_workspace_bytes(int64_t n_walkers, int32_t walk_length, double p, double q,
                                              int32_t rng_mode);

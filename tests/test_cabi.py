@@ -76,7 +76,7 @@ def test_workspace_bytes():
     assert f(n, nnz, 0, 5, 1.0, 1.0, 0) >= 256
     assert f(1000, 10**8, 5, 6, 0.5, 2.0, 1) == head                  # short serial glibc replay: int64 kernels, no shadow
     assert f(n, nnz, N, L, 1.0, 1.0, 2) == head                       # uniform on the walker stream: int64 kernels
-    table = 16 * 1024                                                 # edge table: >= 3 slots per edge, >= 1024 slots
+    table = 32 * 256                                                  # edge set: 2.5 places of 8 bytes per edge in blocks of 4, >= 256 blocks
     fat = 32 * nnz                                                    # 32-byte entries of the biased walk
     assert shadow + table + fat <= f(n, nnz, 1, L, 0.5, 2.0, 2) - head <= shadow + table + fat + 6 * 256   # 4 steps per entry
     uniform = f(n, nnz, N, L, 1.0, 1.0, 0)                            # windows + shadow; rows written in place
@@ -96,9 +96,13 @@ def test_workspace_bytes():
     assert plan(n, nnz, 2, L, 0.5, 2.0, 2) == 2 | 4 and plan(n, nnz, N, L, 0.5, 2.0, 2) == 2 | 4 | 8
     assert plan(1000, 10**8, 5, 6, 0.5, 2.0, 1) == -1 and plan(n, nnz, N, L, 1.0, 1.0, 2) == -2
     assert plan(n, nnz, N, L, 0.5, 2.0, 1) == 2          # a serial replay of this many steps rides the prepared graph
-    # a graph the size of BASELINE configs[3] keeps the table path: 2^32 slots (64-bit slot arithmetic)
+    # a graph the size of BASELINE configs[3]: 20 bytes of edge set + 32 of entry + 4 of shadow per edge (it was a
+    # 2^32-slot, 69 GB table until round 4)
     big = g(111_000_000, 1_711_000_000, 2)
-    assert 16 * 2**32 + 32 * 1_711_000_000 < big < 16 * 2**32 + 32 * 1_711_000_000 + 9 * 10**9
+    assert 56 * 1_711_000_000 < big < 56 * 1_711_000_000 + 10**9
+    full = g(111_000_000, 1_711_000_000, 2 | 4 | 8)
+    assert full < 64 * 1_711_000_000                                  # <= 64 bytes per edge with every mask built
+    assert g(10_000_000, 110_000_000, 2 | 4 | 8) < 64 * 110_000_000   # ... on the headline graph too
 
 
 def test_argument_errors_return_codes_without_touching_the_gpu():

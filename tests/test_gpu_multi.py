@@ -289,10 +289,10 @@ def test_config4_papers100m_sharded_equals_unsharded():
 
 def test_config4_graph_node2vec_shard_keeps_the_table_path():
     """The node2vec walk at BASELINE configs[3] scale: 1.71 G entries used to be beyond the edge
-    table's 2^31-slot cap, which silently sent such graphs to the bisection kernel.  Slot arithmetic is 64-bit now:
-    the prepared graph holds a 2^32-slot table (69 GB) + 32-byte entries (55 GB), one GPU's shard of the start nodes
-    (13.9 M walkers, global walker indices of shard 5) walks on the walker-pool kernel, and sampled rows equal the
-    oracle's per-walker stream."""
+    table's 2^31-slot cap, which silently sent such graphs to the bisection kernel; then the table had 2^32 slots of
+    16 bytes (69 GB).  Round 4: an edge set of 8-byte keys, 20 bytes per edge (34 GB) -- the prepared graph is 96 GB,
+    56 bytes per edge, one GPU's shard of the start nodes (13.9 M walkers, global walker indices of shard 5) walks on
+    the walker-pool kernel, and sampled rows equal the oracle's per-walker stream."""
     from torch_random_walk_amd import graphs
     from torch_random_walk_amd.dist import shard_bounds
     from torch_rw import rw
@@ -304,7 +304,7 @@ def test_config4_graph_node2vec_shard_keeps_the_table_path():
     w = rw.walk_ex(rp, ci, tg, 0.25, 4.0, L, seed, walker_base=lo, rng_mode=rw.RNG_WALKER, check=True)
     info = rw.cache_info()
     assert len(info) == 1 and info[0][2] & rw.PREP_BIASED, info
-    assert info[0][3] > 16 * 2**32 + 32 * ci.numel()             # the table really has 2^32 slots
+    assert 56 * ci.numel() < info[0][3] < 57 * ci.numel()        # shadow 4 + edge set 20 + entries 32 bytes per edge
     assert torch.equal(w[:, 0], tg) and int(w.min()) >= 0 and int(w.max()) < n
     rows = np.unique(np.concatenate([[0, 1, hi - lo - 1], np.random.default_rng(0).integers(0, hi - lo, 21)]))
     got = w[torch.as_tensor(rows, device=DEV)].cpu().numpy()

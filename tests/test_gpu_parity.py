@@ -380,7 +380,7 @@ VARIANTS = [{"TRW_FORCE_WIDE": "1"},                      # int64 kernels
             {"TRW_HASH": "1"},                           # edge table + state machine
             {"TRW_HASH": "1", "TRW_NO_POS": "1"},
             {"TRW_HASH": "1", "TRW_RESIDENT_BLOCKS": "1"},   # persistent kernel: workgroups per CU is launch geometry
-            {"TRW_HASH": "1", "TRW_RESIDENT_BLOCKS": "8", "TRW_HASH_SLACK": "2"},
+            {"TRW_HASH": "1", "TRW_RESIDENT_BLOCKS": "8", "TRW_HASH_SLACK": "12"},
             {"TRW_HASH": "1", "TRW_EXT": "1", "TRW_COMMON_MAX": "0"},      # fat entries without / with the
             {"TRW_HASH": "1", "TRW_EXT": "1", "TRW_COMMON_MAX": "4096"}]   # no-common-neighbour marks everywhere
 

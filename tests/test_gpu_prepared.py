@@ -30,6 +30,7 @@ def _dev(*arrays):
 
 def test_second_walk_reuses_the_prepared_graph_and_third_has_full_marks(rw, monkeypatch):
     monkeypatch.setenv("TRW_PLAN_MARKS_AT", "1000000")   # (a call this size would bring the marks along by itself, see below)
+    monkeypatch.setenv("TRW_PLAN_FULL_AT", "1000000")
     rp, ci = hub_graph(3000, 6)
     tg = np.random.default_rng(2).integers(0, 3000, 20_000)
     d_rp, d_ci, d_tg = _dev(rp, ci, tg)
@@ -91,7 +92,7 @@ def test_masks_of_longer_rows_join_with_the_steps_made_unless_prepared_by_hand(r
                           (nnz * 15 // 12, rw.PREP_BIASED | rw.PREP_MARKS | rw.PREP_MARKS_FULL)):
         rw.clear_cache()
         t = torch.as_tensor(np.resize(tg, walkers)).to(DEV)
-        got = rw.walk(d_rp, d_ci, t, 0.25, 4.0, 12, 4)
+        got = rw.walk_ex(d_rp, d_ci, t, 0.25, 4.0, 12, 4, rng_mode=rw.RNG_WALKER)   # (2 500 walkers: AUTO would replay the serial stream)
         assert rw.cache_info()[0][2] == want, (walkers, rw.cache_info()[0][2])
         assert (got.cpu().numpy() == O.walk(rp, ci, np.resize(tg, walkers), 0.25, 4.0, 12, 4, rng_mode=O.RNG_WALKER)).all()
 
@@ -177,6 +178,7 @@ def test_every_marking_path_walks_the_same_rows(rw, deg, inline_cap, monkeypatch
     """Masks worked out by the owning thread (short rows), by the tile pass (rows of 33..4096), exact
     (rows <= 128) and as filters (longer rows: set bits ask the table), or not at all (cap 0 without marks)."""
     monkeypatch.setenv("TRW_PLAN_MARKS_AT", "1000000")          # (first walk: entries only; second: the cache adds the marks)
+    monkeypatch.setenv("TRW_PLAN_FULL_AT", "1000000")
     if inline_cap is not None:
         monkeypatch.setenv("TRW_COMMON_MAX", inline_cap)
     rp, ci = random_graph(400, deg, 11)
@@ -201,11 +203,11 @@ def test_every_marking_path_walks_the_same_rows(rw, deg, inline_cap, monkeypatch
     assert rw.cache_info()[0][2] == full
 
 
-@pytest.mark.parametrize("env", [{}, {"TRW_POOL_KERNEL": "0"}, {"TRW_HASH_SLACK": "2", "TRW_COMMON_MAX": "0"}])
+@pytest.mark.parametrize("env", [{}, {"TRW_POOL_KERNEL": "0"}, {"TRW_HASH_SLACK": "12", "TRW_COMMON_MAX": "0"}])
 def test_parallel_edges_beyond_the_packed_run_and_long_probe_chains(rw, env, monkeypatch):
     """An entry packs "where t sits in prev's row" as multiplicity (4 bits) and first offset: pairs joined by more
     than 15 parallel edges go through the table instead, and the walker pool then keeps the run where two of its
-    mask words were.  With a table at load 1/2 and no masks every in-band trial is a table lookup, some of them
+    mask words were.  With an edge set at load 0.8 and no masks every in-band trial is a lookup, some of them
     with probe chains longer than the pool's 3-bit probe counter."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -235,7 +237,7 @@ def test_parallel_edges_beyond_the_packed_run_and_long_probe_chains(rw, env, mon
 
 
 @pytest.mark.parametrize("env", [{"TRW_MASK_KERNEL": "0"}, {"TRW_MASK_KERNEL": "0", "TRW_NO_POS": "1"},
-                                 {"TRW_RESIDENT_BLOCKS": "1"}, {"TRW_HASH_SLACK": "2", "TRW_RESIDENT_BLOCKS": "8"}])
+                                 {"TRW_RESIDENT_BLOCKS": "1"}, {"TRW_HASH_SLACK": "12", "TRW_RESIDENT_BLOCKS": "8"}])
 def test_mask_kernel_and_state_machine_kernel_agree(rw, env, monkeypatch):
     for k, v in env.items():
         monkeypatch.setenv(k, v)

@@ -126,7 +126,7 @@ struct PrepLayout {
     bool biased = false;   // edge table + 32-byte fat entries
     bool marks = false;    // ... with the neighbourhood masks worked out for long rows too
     bool marks_full = false;  // ... for rows up to 1024 entries (TRW_PREP_MARKS_FULL) instead of 256
-    uint64_t hash_mask = 0;
+    uint32_t table_blocks = 0;  // the edge set: blocks of four 8-byte keys
     uint32_t heavy_room = 0, task_room = 0;
     size_t off_row32 = 0, off_col32 = 0, off_ext16 = 0, off_table = 0, off_ext32 = 0, off_heavy = 0, total = 0;
     size_t off_incount = 0, off_inoff = 0, off_tasks = 0;  // the tile pass: per-node in-list counters / segments, tasks
@@ -137,15 +137,16 @@ bool graph_fits_narrow(int64_t n_nodes, int64_t nnz)
     return n_nodes < ((int64_t)1 << 31) && nnz < ((int64_t)1 << 32) - 64 && env_long("TRW_FORCE_WIDE", 0, 1, 0) == 0;
 }
 
-// Slots of the edge table: a power of two, at least `TRW_HASH_SLACK` (default 3) per edge, i.e. load factor
-// <= 1/3 -- relaxed towards 1/2 for graphs whose table would pass 48 GB (1.7e9 entries: 2^32 slots, 69 GB).
-uint64_t edge_table_slots(int64_t nnz)
+// Blocks (of four 8-byte keys) of the edge set: `TRW_HASH_SLACK` TENTHS of a place per edge (default 25: load factor
+// 0.4, 20 bytes per edge -- with 20 the whole prepared graph is 58 bytes per edge and the prepare pass 4 % slower, with
+// 30 it is 66 and 4 % faster: misses, nine probes in ten of the prepare pass, end at the first block that has a free
+// place), any number of blocks -- a block is picked by mulhi(hash, blocks).
+uint32_t edge_table_blocks(int64_t nnz)
 {
-    const uint64_t slack = (uint64_t)env_long("TRW_HASH_SLACK", 2, 16, 3);
-    uint64_t cap = 1024;
-    while (cap < slack * (uint64_t)nnz) cap <<= 1;
-    while (cap * 16 > ((uint64_t)48 << 30) && (cap >> 1) >= 2 * (uint64_t)nnz) cap >>= 1;
-    return cap;
+    const uint64_t tenths = (uint64_t)env_long("TRW_HASH_SLACK", 12, 160, 25);
+    uint64_t blocks = (tenths * (uint64_t)nnz + 39) / 40;
+    if (blocks < 256) blocks = 256;
+    return blocks > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)blocks;  // (nnz < 2^32 and 3 places per edge stay below)
 }
 
 PrepLayout make_prep_layout(int64_t n_nodes, int64_t nnz, int32_t what)
@@ -167,10 +168,9 @@ PrepLayout make_prep_layout(int64_t n_nodes, int64_t nnz, int32_t what)
             pl.biased = true;
             pl.marks = (what & (TRW_PREP_MARKS | TRW_PREP_MARKS_FULL)) != 0;
             pl.marks_full = (what & TRW_PREP_MARKS_FULL) != 0;
-            const uint64_t cap = edge_table_slots(nnz);
-            pl.hash_mask = cap - 1;
+            pl.table_blocks = edge_table_blocks(nnz);
             pl.off_table = off;
-            off += (size_t)cap * 16 + 64;
+            off += align_up((size_t)pl.table_blocks * 32 + 64, 256);
             pl.off_ext32 = off;
             off += align_up((size_t)nnz * 32 + 64, 256);
             if (pl.marks) {  // queue of the entries whose mask takes a whole wave
@@ -185,7 +185,7 @@ PrepLayout make_prep_layout(int64_t n_nodes, int64_t nnz, int32_t what)
                 off += align_up((size_t)(n_nodes + 1) * 4, 256);
                 pl.off_inoff = off;
                 off += align_up((size_t)(n_nodes + 1) * 4, 256);
-                const uint64_t troom = (uint64_t)nnz / 12 + 4096;
+                const uint64_t troom = (uint64_t)nnz / 10 + 4096;
                 pl.task_room = troom > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)troom;
                 pl.off_tasks = off;
                 off += align_up((size_t)pl.task_room * 16, 256);
@@ -499,8 +499,9 @@ int trw_prepare_csr_region(int64_t n_nodes, int64_t nnz, int32_t what, int32_t w
     case TRW_REGION_ROW32: if (pl.narrow) { *offset = pl.off_row32; *bytes = (size_t)(n_nodes + 1) * 4; } break;
     case TRW_REGION_COL32: if (pl.narrow) { *offset = pl.off_col32; *bytes = (size_t)nnz * 4; } break;
     case TRW_REGION_EXT16: if (pl.ext16) { *offset = pl.off_ext16; *bytes = (size_t)nnz * 16; } break;
-    case TRW_REGION_TABLE: if (pl.biased) { *offset = pl.off_table; *bytes = ((size_t)pl.hash_mask + 1) * 16; } break;
+    case TRW_REGION_TABLE: if (pl.biased) { *offset = pl.off_table; *bytes = (size_t)pl.table_blocks * 32; } break;
     case TRW_REGION_EXT32: if (pl.biased) { *offset = pl.off_ext32; *bytes = (size_t)nnz * 32; } break;
+    case TRW_REGION_TASKS: if (pl.marks) { *offset = pl.off_tasks; *bytes = (size_t)pl.task_room * 16; } break;
     default: return fail(TRW_E_ARG, "unknown region");
     }
     return TRW_OK;
@@ -537,9 +538,9 @@ int trw_prepare_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *
             csr_ext_kernel<<<stream_grid(nnz), kBlock, 0, stream>>>(row32, col32, nnz, (u32x4_a16 *)(ws + pl.off_ext16));
         if (pl.biased) {
             uint32_t *table = (uint32_t *)(ws + pl.off_table);
-            device_fill(table, 0xFFFFFFFFu, ((size_t)pl.hash_mask + 1) * 16 + 64, stream);
+            device_fill(table, 0xFFFFFFFFu, (size_t)pl.table_blocks * 32 + 64, stream);
             edge_table_build_kernel<<<stream_grid((nnz + 7) / 8), kBlock, 0, stream>>>(row32, col32, n_nodes, nnz, table,
-                                                                                     pl.hash_mask, header);
+                                                                                     pl.table_blocks, header);
             // Rows up to inline_cap are marked by the thread that owns the entry; with TRW_PREP_MARKS longer ones (up
             // to heavy_cap) go through the wave-per-entry pass.  Measured on R-MAT 10M/110M (prepare ms -> walk ms of
             // the 8e8-step batch): inline 8: 22 -> 101; inline 32: 36 -> 86; inline 64: 72 -> 72; inline 32 + heavy
@@ -558,7 +559,7 @@ int trw_prepare_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *
             uint32_t *in_off = pl.marks ? (uint32_t *)(ws + pl.off_inoff) : nullptr;
             if (tiles) device_fill(in_count, 0u, align_up((size_t)(n_nodes + 1) * 4, 256), stream);
             csr_ext32_kernel<<<stream_grid((nnz + 7) / 8), kBlock, 0, stream>>>(
-                row32, col32, n_nodes, nnz, table, pl.hash_mask, inline_cap, heavy_cap, tiles ? 1u : 0u,
+                row32, col32, n_nodes, nnz, table, pl.table_blocks, inline_cap, heavy_cap, tiles ? 1u : 0u,
                 (u32x4_a16 *)(ws + pl.off_ext32), heavy, pl.heavy_room, in_count, header);
             if (tiles) {
                 TileTask *tasks = (TileTask *)(ws + pl.off_tasks);
@@ -573,7 +574,7 @@ int trw_prepare_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *
                 heavy_scatter_kernel<<<stream_grid(n_nodes), kBlock, 0, stream>>>(row32, col32, n_nodes, inline_cap,
                                                                                   heavy_cap, in_count, in_off, heavy);
                 const unsigned cus = (unsigned)device_cu_count();
-                const uint32_t room_small = pl.task_room - pl.task_room / 4u, room_big = pl.task_room / 4u;
+                const uint32_t room_small = small_row ? pl.task_room - pl.task_room / 4u : 0u, room_big = pl.task_room - room_small;
                 const TileTask *tasks_big = tasks + room_small;
                 heavy_tile_kernel<8192, 512, true><<<cus * 4, 512, 0, stream>>>(row32, col32, ext32, heavy, tasks_big, room_big,
                                                                                 inline_cap, heavy_cap, header);
@@ -589,13 +590,23 @@ int trw_prepare_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *
             }
             if (pl.marks && !tiles)
                 csr_ext32_heavy_kernel<<<(unsigned)(device_cu_count() * 8), kBlock, 0, stream>>>(
-                    row32, col32, table, pl.hash_mask, (u32x4_a16 *)(ws + pl.off_ext32), heavy, pl.heavy_room, header);
+                    row32, col32, (u32x4_a16 *)(ws + pl.off_ext32), heavy, pl.heavy_room, header);
         }
     }
     if (g_prof.on && g_prof.prep[0] && (g_prof.prep[1] || hipEventCreate(&g_prof.prep[1]) == hipSuccess)) {
         (void)hipEventRecord(g_prof.prep[1], stream);
         g_prof.prep_valid = true;
     }
+#ifdef TRW_PREP_COUNT
+    {
+        (void)hipStreamSynchronize(stream);
+        unsigned long long a = 0, b = 0, c = 0;
+        (void)hipMemcpyFromSymbol(&a, HIP_SYMBOL(g_cnt_hits_u), 8);
+        (void)hipMemcpyFromSymbol(&b, HIP_SYMBOL(g_cnt_rpos), 8);
+        (void)hipMemcpyFromSymbol(&c, HIP_SYMBOL(g_cnt_probes_u), 8);
+        fprintf(stderr, "[TRW_PREP_COUNT] mask hits walking u's row %llu of %llu probes, reverse edges found %llu\n", a, c, b);
+    }
+#endif
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "kernel launch");
     return TRW_OK;
@@ -763,8 +774,8 @@ static int walk_prepared(const void *prepared, size_t prepared_bytes, int32_t wh
         // its kind (the row order is known on the device only).
         const bool wave_replay = pl.narrow && pl.biased && env_long("TRW_WAVE_REPLAY", 0, 1, 1) == 1;
         if (wave_replay)
-            biased_glibc_wave_kernel<<<1, 64, 0, stream>>>(row32, (const u32x4_a16 *)(pw + pl.off_ext32), table,
-                                                          pl.hash_mask, targets, n_nodes, n_walkers, walk_length, sw,
+            biased_glibc_wave_kernel<<<1, 64, 0, stream>>>(row32, col32, (const u32x4_a16 *)(pw + pl.off_ext32), table,
+                                                          pl.table_blocks, targets, n_nodes, n_walkers, walk_length, sw,
                                                           bp, out, status);
         biased_glibc_seq_kernel<<<1, 64, 0, stream>>>(row_ptr, col_idx, targets, n_nodes, nnz, n_walkers,
                                                      walk_length, sw, th, wave_replay ? 1 : 0, out, status);
@@ -798,30 +809,30 @@ static int walk_prepared(const void *prepared, size_t prepared_bytes, int32_t wh
             if (pblocks > president) pblocks = president;
             if (g_prof.count)
                 biased_pool_kernel<true><<<(unsigned)pblocks, kBlock, 0, stream>>>(
-                    row32, col32, ext32, table, pl.hash_mask, targets, n_nodes, n_walkers, walker_base, walk_length,
+                    row32, col32, ext32, table, pl.table_blocks, targets, n_nodes, n_walkers, walker_base, walk_length,
                     (uint32_t)seed, bp, out, status);
             else
                 biased_pool_kernel<false><<<(unsigned)pblocks, kBlock, 0, stream>>>(
-                    row32, col32, ext32, table, pl.hash_mask, targets, n_nodes, n_walkers, walker_base, walk_length,
+                    row32, col32, ext32, table, pl.table_blocks, targets, n_nodes, n_walkers, walker_base, walk_length,
                     (uint32_t)seed, bp, out, status);
         } else if (mask_kernel) {
             if (g_prof.count)
                 biased_mask_kernel<true><<<(unsigned)blocks, kBlock, 0, stream>>>(
-                    row32, ext32, table, pl.hash_mask, targets, n_nodes, n_walkers, walker_base, walk_length,
+                    row32, col32, ext32, table, pl.table_blocks, targets, n_nodes, n_walkers, walker_base, walk_length,
                     (uint32_t)seed, bp, out, status);
             else
                 biased_mask_kernel<false><<<(unsigned)blocks, kBlock, 0, stream>>>(
-                    row32, ext32, table, pl.hash_mask, targets, n_nodes, n_walkers, walker_base, walk_length,
+                    row32, col32, ext32, table, pl.table_blocks, targets, n_nodes, n_walkers, walker_base, walk_length,
                     (uint32_t)seed, bp, out, status);
         }
         const int32_t want_pos = (bp.t0 > bp.hi && env_long("TRW_NO_POS", 0, 1, 0) == 0) ? 1 : 0;
         if (g_prof.count)
             biased_hash_kernel<true><<<(unsigned)blocks, kBlock, 0, stream>>>(
-                row32, col32, (const uint32_t *)ext32, table, pl.hash_mask, targets, n_nodes, n_walkers, walker_base,
+                row32, col32, (const uint32_t *)ext32, table, pl.table_blocks, targets, n_nodes, n_walkers, walker_base,
                 walk_length, (uint32_t)seed, bp, want_pos, mask_kernel ? 1 : 0, out, status);
         else
             biased_hash_kernel<false><<<(unsigned)blocks, kBlock, 0, stream>>>(
-                row32, col32, (const uint32_t *)ext32, table, pl.hash_mask, targets, n_nodes, n_walkers, walker_base,
+                row32, col32, (const uint32_t *)ext32, table, pl.table_blocks, targets, n_nodes, n_walkers, walker_base,
                 walk_length, (uint32_t)seed, bp, want_pos, mask_kernel ? 1 : 0, out, status);
     } else if (pl.narrow) {
         // Locating t inside prev's row once per step (a bisection here) pays when at least half of the trials

@@ -901,6 +901,33 @@ __device__ __forceinline__ uint32_t row_find32(const uint32_t *__restrict__ col3
     return lo;
 }
 
+// The two rare detours of the walker pool that read memory on the spot -- a run of parallel edges too long for rpos, a
+// probe chain longer than the slot's counter -- as REAL calls: inlined, their loads shared registers with the pool's
+// gathers in flight, and the compiler put a full `s_waitcnt vmcnt(0)` in front of the issue pass's loads of every
+// iteration (walk 36.3 -> 40.4 ms on R-MAT 10M/110M).
+__device__ __attribute__((noinline)) uint32_t row_find32_cold(const uint32_t *col32, uint32_t start, uint32_t n, uint32_t x,
+                                                              uint32_t *run_out)
+{
+    uint32_t run;
+    const uint32_t lo = row_find32(col32, start, n, x, run);
+    *run_out = run;
+    return lo;
+}
+__device__ __attribute__((noinline)) bool edge_chain_cold(const uint32_t *table, uint32_t nb, uint32_t a, uint32_t b, uint32_t skip,
+                                                          uint32_t *probes)
+{
+    uint32_t blk = edge_block(a, b, nb);
+    for (uint32_t k = 0; k < skip; ++k) blk = blk + 1u == nb ? 0u : blk + 1u;
+    while (true) {
+        const u32x4_a16 g0 = *reinterpret_cast<const u32x4_a16 *>(table + 8 * (size_t)blk);
+        const u32x4_a16 g1 = *reinterpret_cast<const u32x4_a16 *>(table + 8 * (size_t)blk + 4);
+        ++*probes;
+        if (half_has(g0, a, b) || half_has(g1, a, b)) return true;
+        if (half_ends(g0) || half_ends(g1)) return false;
+        blk = blk + 1u == nb ? 0u : blk + 1u;
+    }
+}
+
 // Mask of the step after u -> v: offsets of v's row [v_start, v_start+v_deg) whose node is in u's row
 // [u_lo, u_hi).  Two ways to intersect, each where it measured faster (R-MAT 10M/110M):
 //   common_mask_table   walk the shorter row, one edge-table probe per entry: independent gathers, what a single
@@ -909,6 +936,9 @@ __device__ __forceinline__ uint32_t row_find32(const uint32_t *__restrict__ col3
 //                       rows, and long rows are re-read by everyone and stay in L2 -- what the wave-per-entry pass
 //                       over long rows does best (rows up to 4096: 212 ms instead of 354 ms with table probes)
 // The caller's lane handles entries first, first+stride, ... of the shorter row.
+#ifdef TRW_PREP_COUNT
+static __device__ unsigned long long g_cnt_hits_u = 0, g_cnt_rpos = 0, g_cnt_probes_u = 0;  // (debug counters)
+#endif
 __device__ __forceinline__ void common_mask_table(const uint32_t *__restrict__ col32, const uint32_t *__restrict__ table,
                                                   uint32_t nb, uint32_t u, uint32_t u_lo, uint32_t u_hi, uint32_t v,
                                                   uint32_t v_start, uint32_t v_deg, Mask128 &m)
@@ -918,7 +948,13 @@ __device__ __forceinline__ void common_mask_table(const uint32_t *__restrict__ c
         for (uint32_t i = 0; i < u_deg; ++i) {
             const uint32_t w = col32[u_lo + i];
             if (i > 0 && col32[u_lo + i - 1] == w) continue;  // sorted rows: a run of equal entries is one node
+#ifdef TRW_PREP_COUNT
+            atomicAdd(&g_cnt_probes_u, 1ull);
+#endif
             if (edge_table_find(table, nb, v, w)) {  // a common neighbour: where it sits in v's row
+#ifdef TRW_PREP_COUNT
+                atomicAdd(&g_cnt_hits_u, 1ull);
+#endif
                 uint32_t run;
                 const uint32_t lo = row_find32(col32, v_start, v_deg, w, run);
                 m.set_run(lo, run);
@@ -1069,6 +1105,9 @@ csr_ext32_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict_
             uint32_t flag = kMaskIsFilter, rpos = kRposAbsent;
             if (e >= e_first && e < e_last) {
                 if (edge_table_find(table, tnb, v, u)) {  // the reverse edge exists: where u sits in v's row
+#ifdef TRW_PREP_COUNT
+                    atomicAdd(&g_cnt_rpos, 1ull);
+#endif
                     uint32_t cnt = 0;
                     const uint32_t lo = sorted ? row_find32(col32, start, deg, u, cnt) : 0u;
                     rpos = (sorted && cnt <= 15u && lo < (1u << 28)) ? ((cnt << 28) | lo) : kRposLookup;
@@ -1165,52 +1204,104 @@ struct TileTask {
     uint32_t node, start, count, mode;  // mode 0: entries [start, start+count) of node's row; 1: items [start, ...) of its in-list
 };
 
-// One thread per node: tasks for the rows that can be a tile, and a segment of the item array for the node's in-list.
+// One lane per node, a wave per 64 nodes: tasks for the rows that can be a tile, and a segment of the item array for the
+// node's in-list.  The wave takes its segments and its task numbers with ONE atomic each (a prefix sum over the lanes:
+// one atomic per node serialised half a million of them on two addresses, 5 of the pass's 7 ms), and writes the
+// task records of a long row together (a hub's two thousand records were one lane's loop).
+__device__ __forceinline__ uint32_t wave_prefix_excl(uint32_t v, int lane, uint32_t &total)
+{
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)inc, d);
+        if (lane >= d) inc += y;
+    }
+    total = (uint32_t)__shfl((int)inc, 63);
+    return inc - v;
+}
+
 __global__ void __launch_bounds__(kBlock)
 heavy_plan_kernel(const uint32_t *__restrict__ row32, int64_t n_nodes, const uint32_t *__restrict__ in_count,
                   uint32_t *__restrict__ in_off, TileTask *__restrict__ tasks, uint32_t task_room, uint32_t heavy_room,
                   uint32_t inline_cap, uint32_t small_row, int64_t *__restrict__ header)
 {
     if (header[kStDescents] != header[kStBoundary]) return;  // rows not sorted: no masks, no tasks
+    const int lane = threadIdx.x & 63;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     const uint64_t queued = (uint64_t)header[kStHeavyCount];
     const uint32_t base0 = queued < heavy_room ? (uint32_t)queued : heavy_room;  // the queue's items come first
-    for (int64_t x = (int64_t)blockIdx.x * kBlock + threadIdx.x; x < n_nodes; x += stride) {
-        uint32_t start, deg;
-        load_row32(row32, (uint32_t)x, start, deg);
-        if (deg <= inline_cap) continue;  // never the longer row of a tile item
-        const uint32_t c = in_count[x];
+    // (no list of short rows -- small_row == 0 --: the whole room is the long rows')
+    const uint32_t room_small = small_row ? task_room - task_room / 4u : 0u, room_big = task_room - room_small;
+    for (int64_t x0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) & ~(int64_t)63; x0 < n_nodes; x0 += stride) {
+        const int64_t x = x0 + lane;
+        uint32_t start = 0, deg = 0;
+        if (x < n_nodes) load_row32(row32, (uint32_t)x, start, deg);
+        const bool tile = deg > inline_cap;  // (else: never the longer row of a tile item)
+        const uint32_t c = tile ? in_count[x] : 0u;
+        // segments of the item array
+        uint32_t c_total;
+        const uint32_t c_before = wave_prefix_excl(c, lane, c_total);
+        uint64_t seg_base = 0;
+        if (c_total) {
+            if (lane == 0) seg_base = atomicAdd((unsigned long long *)&header[kStSortedCursor], (unsigned long long)c_total);
+            seg_base = (uint64_t)__shfl((long long)seg_base, 0) + base0;
+        }
         uint32_t seg = kNoSegment;
         if (c) {
-            const uint64_t o = (uint64_t)base0 + atomicAdd((unsigned long long *)&header[kStSortedCursor], (unsigned long long)c);
-            if (o + c <= heavy_room) seg = (uint32_t)o;
+            if (seg_base + c_before + c <= heavy_room) seg = (uint32_t)(seg_base + c_before);
             in_off[x] = seg;  // kNoSegment: no room, these entries keep their all-ones masks
         }
-        // MK_TILE_A needs deg > deg(v) > inline_cap
-        const bool big = deg >= small_row;
+        // tasks; MK_TILE_A needs deg > deg(v) > inline_cap
+        const bool big = tile && deg >= small_row;
         const uint32_t per_a = big ? kTaskEntries : kTaskEntriesSmall;
-        const uint32_t n_a = deg >= inline_cap + 2u ? (deg + per_a - 1u) / per_a : 0u;
+        const uint32_t n_a = (tile && deg >= inline_cap + 2u) ? (deg + per_a - 1u) / per_a : 0u;
         const uint32_t n_b = seg != kNoSegment ? (c + kTaskItems - 1u) / kTaskItems : 0u;
-        if (n_a + n_b == 0u) continue;
-        const uint32_t room = big ? task_room / 4u : task_room - task_room / 4u;
-        TileTask *const list = big ? tasks + (task_room - task_room / 4u) : tasks;
-        const uint64_t at = atomicAdd((unsigned long long *)&header[big ? kStTaskCountBig : kStTaskCount], (unsigned long long)(n_a + n_b));
-        for (uint32_t k = 0; k < n_a + n_b; ++k) {
-            if (at + k >= room) break;
+        const uint32_t n_t = n_a + n_b;
+        uint32_t tot_big, tot_small;
+        const uint32_t before_big = wave_prefix_excl(big ? n_t : 0u, lane, tot_big);
+        const uint32_t before_small = wave_prefix_excl(big ? 0u : n_t, lane, tot_small);
+        uint64_t at_big = 0, at_small = 0;
+        if (lane == 0 && tot_big) at_big = atomicAdd((unsigned long long *)&header[kStTaskCountBig], (unsigned long long)tot_big);
+        if (lane == 0 && tot_small) at_small = atomicAdd((unsigned long long *)&header[kStTaskCount], (unsigned long long)tot_small);
+        // (both broadcasts outside the select: a shuffle inside one arm of it runs with the other arm's lanes switched off,
+        // lane 0 possibly among them)
+        const uint64_t base_big = (uint64_t)__shfl((long long)at_big, 0), base_small = (uint64_t)__shfl((long long)at_small, 0);
+        const uint64_t at = big ? base_big + before_big : base_small + before_small;
+        const uint32_t room = big ? room_big : room_small;
+        TileTask *const list = big ? tasks + room_small : tasks;
+        auto record = [&](uint32_t node, uint32_t r_start, uint32_t r_deg, uint32_t r_seg, uint32_t r_c, uint32_t r_na, uint32_t r_per,
+                          uint32_t k) {
             TileTask t;
-            t.node = (uint32_t)x;
-            if (k < n_a) {
-                t.start = start + k * per_a;
-                t.count = deg - k * per_a < per_a ? deg - k * per_a : per_a;
+            t.node = node;
+            if (k < r_na) {
+                t.start = r_start + k * r_per;
+                t.count = r_deg - k * r_per < r_per ? r_deg - k * r_per : r_per;
                 t.mode = 0u;
             } else {
-                const uint32_t kb = k - n_a;
-                t.start = seg + kb * kTaskItems;
-                t.count = c - kb * kTaskItems < kTaskItems ? c - kb * kTaskItems : kTaskItems;
+                const uint32_t kb = k - r_na;
+                t.start = r_seg + kb * kTaskItems;
+                t.count = r_c - kb * kTaskItems < kTaskItems ? r_c - kb * kTaskItems : kTaskItems;
                 t.mode = 1u;
             }
-            list[at + k] = t;
+            return t;
+        };
+        // rows with many records: the whole wave writes them; the others: their own lane
+        uint64_t wide = __ballot(n_t > 16u);
+        while (wide) {
+            const int src = __builtin_ctzll(wide);
+            wide &= wide - 1;
+            const uint32_t w_n = (uint32_t)__shfl((int)n_t, src), w_na = (uint32_t)__shfl((int)n_a, src);
+            const uint32_t w_start = (uint32_t)__shfl((int)start, src), w_deg = (uint32_t)__shfl((int)deg, src);
+            const uint32_t w_seg = (uint32_t)__shfl((int)seg, src), w_c = (uint32_t)__shfl((int)c, src), w_per = (uint32_t)__shfl((int)per_a, src);
+            const uint64_t w_at = (uint64_t)__shfl((long long)at, src);
+            const uint32_t w_room = (uint32_t)__shfl((int)room, src);
+            TileTask *const w_list = (TileTask *)__shfl((long long)(uintptr_t)list, src);
+            for (uint32_t k = (uint32_t)lane; k < w_n; k += 64u)
+                if (w_at + k < w_room) w_list[w_at + k] = record((uint32_t)(x0 + src), w_start, w_deg, w_seg, w_c, w_na, w_per, k);
         }
+        if (n_t <= 16u)
+            for (uint32_t k = 0; k < n_t; ++k)
+                if (at + k < room) list[at + k] = record((uint32_t)x, start, deg, seg, c, n_a, per_a, k);
     }
 }
 
@@ -2288,6 +2379,10 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
             }
             if (hold) {
                 const uint32_t slot = hs;
+                // ONE wait for the gather, here, where the compiler can see it: left to itself it sank the wait into the
+                // branches below -- one of them BEHIND the column store, a store's round trip per iteration (adopt 21 ->
+                // 34 % of the iteration when the branches were touched in round 4; the edge-list pool had the same)
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
                 if (hkind == PK_ENTRY) {  // e0, e1 = the accepted entry: step onto it
                     const uint32_t x = e0.x;
                     int32_t s = (int32_t)P[PF_S][slot];
@@ -2332,7 +2427,7 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                             // found here, by bisection (rare).  It goes where two mask words were; the mask then says
                             // "look" for every offset.
                             uint32_t cnt = 0;
-                            const uint32_t lo = row_find32(col32, e0.y, deg, prev, cnt);
+                            const uint32_t lo = row_find32_cold(col32, e0.y, deg, prev, &cnt);
                             u32x4_a16 mm = M[slot];
                             mm.z = lo;
                             mm.w = cnt;
@@ -2356,17 +2451,10 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                     bool empty = !match && (half_ends(e0) || half_ends(e1));
                     if (!empty && !match && (flags & kPfProbe) == kPfProbe) {
                         // the chain is longer than the probe field counts: this lane walks the rest of it here
-                        uint32_t blk = edge_block(ku, kv, tnb);
-                        for (int k = 0; k < 8; ++k) blk = blk + 1u == tnb ? 0u : blk + 1u;
-                        while (true) {
-                            const u32x4_a16 g0 = *reinterpret_cast<const u32x4_a16 *>(table + 8 * (size_t)blk);
-                            const u32x4_a16 g1 = *reinterpret_cast<const u32x4_a16 *>(table + 8 * (size_t)blk + 4);
-                            if (kCount) ++n_probes;
-                            match = half_has(g0, ku, kv) || half_has(g1, ku, kv);
-                            empty = !match && (half_ends(g0) || half_ends(g1));
-                            if (empty || match) break;
-                            blk = blk + 1u == tnb ? 0u : blk + 1u;
-                        }
+                        uint32_t walked = 0;
+                        match = edge_chain_cold(table, tnb, ku, kv, 8u, &walked);
+                        empty = !match;
+                        if (kCount) n_probes += walked;
                     }
                     if (!empty && !match) {
                         P[PF_FLAGS][slot] = flags + (1u << kPfProbeShift);
