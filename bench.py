@@ -584,8 +584,9 @@ def main():
         if family in (4, 5):
             # biased_pool_kernel / biased_mask_kernel, bytes the algorithm as run must move: per walker 8 B target + 8 B row32 pair; per
             # column 8 B stored; 32 B per fat entry gathered (every accepted offset, plus candidates the table is
-            # asked about); 16 B per table probe (the walker pool reads an aligned PAIR of slots per probe, 32 B of one
-            # line; the second slot is speculation and is not counted).
+            # asked about); 16 B per probe of the edge set (a probe reads a block of four 8-byte keys, 32 B of one line;
+            # half of it is counted, as when a probe was an aligned pair of 16-byte slots: the figure stays comparable
+            # with the earlier rounds' and does not grow with a layout change).
             alg_bytes = B * 16 + 8 * B * (L + 1) + 32 * fetches + 16 * probes
         else:
             # int64-API-layout bytes (with this kernel's own counts): per walker 8 B target + 8 B column 0

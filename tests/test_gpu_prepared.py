@@ -404,6 +404,21 @@ def test_tile_pass_masks_equal_the_wave_per_entry_pass_and_numpy(rw, what, monke
         assert (tiled[e, 4:] == want).all(), (e, u, v, deg[u], deg[v])
         assert tiled[e, 0] == v and tiled[e, 1] == rp[v] and (tiled[e, 2] & 0x7FFFFFFF) == deg[v]
         assert bool(tiled[e, 2] >> 31) == (deg[v] > 128)
+    # the entries the owning thread marks itself (shorter row <= 32: probes of the edge set, a common neighbour's
+    # position by bisection) and rpos -- where u sits in v's row: multiplicity << 28 | first offset, 1 = "too wide", 0 = absent
+    light = np.nonzero(np.minimum(deg[src], deg[ci]) <= 32)[0]
+    recip = light[np.isin(ci[light] * n + src[light], src * n + ci)]          # entries whose reverse edge exists
+    assert recip.size > 200
+    for e in np.concatenate([rng.choice(light, 300), rng.choice(recip, 200), rng.choice(heavy, 100)]):
+        u, v = src[e], ci[e]
+        row_u, row_v = ci[rp[u]:rp[u + 1]], ci[rp[v]:rp[v + 1]]
+        if min(deg[u], deg[v]) <= 32:
+            bits = np.zeros(128, dtype=bool)
+            np.logical_or.at(bits, np.nonzero(np.isin(row_v, row_u))[0] % 128, True)
+            assert (tiled[e, 4:] == np.packbits(bits, bitorder="little").view(np.uint32)).all(), (e, u, v, deg[u], deg[v])
+        at = np.nonzero(row_v == u)[0]
+        want_rpos = 0 if at.size == 0 else ((at.size << 28) | int(at[0]) if at.size <= 15 else 1)
+        assert tiled[e, 3] == want_rpos, (e, u, v, tiled[e, 3], want_rpos)
 
 
 def test_prepared_edge_list_is_cached_per_padding_id_and_invalidated_by_writes(rw):

@@ -564,29 +564,17 @@ int trw_prepare_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *
             if (tiles) {
                 TileTask *tasks = (TileTask *)(ws + pl.off_tasks);
                 u32x4_a16 *ext32 = (u32x4_a16 *)(ws + pl.off_ext32);
-                // Rows of fewer than `small_row` entries are tiles of ONE wave each (no barrier anywhere: 0.52 M of the
-                // 0.53 M rows that are tiles on R-MAT 10M/110M, 69 % of the searches), longer ones of a workgroup of 8.
-                const long shape = env_long("TRW_TILE_SHAPE", 0, 3, 3);
-                const uint32_t small_row = shape == 3 ? 0u : (shape == 1 ? 1024u : 2048u);
                 heavy_plan_kernel<<<stream_grid(n_nodes), kBlock, 0, stream>>>(row32, n_nodes, in_count, in_off, tasks,
-                                                                               pl.task_room, pl.heavy_room, inline_cap,
-                                                                               small_row, header);
+                                                                               pl.task_room, pl.heavy_room, inline_cap, header);
                 heavy_scatter_kernel<<<stream_grid(n_nodes), kBlock, 0, stream>>>(row32, col32, n_nodes, inline_cap,
                                                                                   heavy_cap, in_count, in_off, heavy);
-                const unsigned cus = (unsigned)device_cu_count();
-                const uint32_t room_small = small_row ? pl.task_room - pl.task_room / 4u : 0u, room_big = pl.task_room - room_small;
-                const TileTask *tasks_big = tasks + room_small;
-                heavy_tile_kernel<8192, 512, true><<<cus * 4, 512, 0, stream>>>(row32, col32, ext32, heavy, tasks_big, room_big,
-                                                                                inline_cap, heavy_cap, header);
-                if (shape == 0)
-                    heavy_tile_kernel<2048, 64, false><<<cus * 16, 64, 0, stream>>>(row32, col32, ext32, heavy, tasks, room_small,
-                                                                                    inline_cap, heavy_cap, header);
-                else if (shape == 1)
-                    heavy_tile_kernel<1024, 64, false><<<cus * 28, 64, 0, stream>>>(row32, col32, ext32, heavy, tasks, room_small,
-                                                                                    inline_cap, heavy_cap, header);
-                else if (shape == 2)
-                    heavy_tile_kernel<2048, 128, false><<<cus * 8, 128, 0, stream>>>(row32, col32, ext32, heavy, tasks, room_small,
-                                                                                     inline_cap, heavy_cap, header);
+                // 8 192 entries of LDS per tile, 8 waves per workgroup, 4 workgroups per CU.  Measured on R-MAT 10M/110M
+                // (full prepare): 16 384 x 8 waves (2 per CU) +8 ms; 8 192 x 4 waves +7; 4 096 x 4 waves +2; tiles of ONE
+                // wave for rows below 1 024 / 2 048 entries next to workgroup tiles for the rest (no barrier for
+                // 98 % of the rows) +6 / +10 -- the workgroup's waves hide each other's latencies better than they
+                // cost each other in barriers.
+                heavy_tile_kernel<8192, 512><<<(unsigned)device_cu_count() * 4, 512, 0, stream>>>(
+                    row32, col32, ext32, heavy, tasks, pl.task_room, inline_cap, heavy_cap, header);
             }
             if (pl.marks && !tiles)
                 csr_ext32_heavy_kernel<<<(unsigned)(device_cu_count() * 8), kBlock, 0, stream>>>(
@@ -597,6 +585,17 @@ int trw_prepare_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *
         (void)hipEventRecord(g_prof.prep[1], stream);
         g_prof.prep_valid = true;
     }
+#ifdef TRW_TILE_CLOCKS
+    {
+        (void)hipStreamSynchronize(stream);
+        long long h[32];
+        (void)hipMemcpy(h, prepared, sizeof(h), hipMemcpyDeviceToHost);
+        double tot = 0;
+        for (int k = 24; k < 29; ++k) tot += (double)h[k];
+        fprintf(stderr, "[TRW_TILE_CLOCKS] wave cycles: grab %.1f%% examine %.1f%% tile change %.1f%% items %.1f%% write-out %.1f%% (total %.3e over all waves; tasks %lld)\n",
+                100.0 * h[24] / tot, 100.0 * h[25] / tot, 100.0 * h[26] / tot, 100.0 * h[27] / tot, 100.0 * h[28] / tot, tot, h[16]);
+    }
+#endif
 #ifdef TRW_PREP_COUNT
     {
         (void)hipStreamSynchronize(stream);

@@ -901,6 +901,34 @@ __device__ __forceinline__ uint32_t row_find32(const uint32_t *__restrict__ col3
     return lo;
 }
 
+// row_find32 for the prepare pass's hits (a common neighbour / a reverse edge found in the edge set: 6 M of them on
+// R-MAT 10M/110M, 29 per wave of csr_ext32_kernel -- and a lane that bisects holds its whole wave for ten dependent
+// round trips): FOUR pivots per round, loaded together, so a round trip divides the range by five -- four rounds
+// for a row of a thousand entries instead of ten.
+__device__ __forceinline__ uint32_t row_find32_wide(const uint32_t *__restrict__ col32, uint32_t start, uint32_t n, uint32_t x,
+                                                    uint32_t &run)
+{
+    uint32_t lo = 0, len = n;  // the answer (first offset whose entry is >= x) lies in [lo, lo + len]
+    while (len > 8u) {
+        const uint32_t step = len / 5u;
+        const uint32_t *p = col32 + start + lo - 1u;
+        const uint32_t a = p[step], b = p[2u * step], c = p[3u * step], d = p[4u * step];  // (independent loads: one round trip)
+        const uint32_t k = (a < x ? 1u : 0u) + (b < x ? 1u : 0u) + (c < x ? 1u : 0u) + (d < x ? 1u : 0u);
+        lo += k * step;            // entries lo .. lo + k*step - 1 are < x
+        len = k == 4u ? len - 4u * step : step - 1u;  // (k < 4: the entry at lo + step - 1 is >= x)
+    }
+    uint32_t v[8];
+#pragma unroll
+    for (uint32_t i = 0; i < 8u; ++i) v[i] = i < len ? col32[start + lo + i] : 0xFFFFFFFFu;
+    uint32_t k = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 8u; ++i) k += v[i] < x ? 1u : 0u;
+    lo += k;
+    run = 0;
+    while (lo + run < n && col32[start + lo + run] == x) ++run;
+    return lo;
+}
+
 // The two rare detours of the walker pool that read memory on the spot -- a run of parallel edges too long for rpos, a
 // probe chain longer than the slot's counter -- as REAL calls: inlined, their loads shared registers with the pool's
 // gathers in flight, and the compiler put a full `s_waitcnt vmcnt(0)` in front of the issue pass's loads of every
@@ -956,7 +984,7 @@ __device__ __forceinline__ void common_mask_table(const uint32_t *__restrict__ c
                 atomicAdd(&g_cnt_hits_u, 1ull);
 #endif
                 uint32_t run;
-                const uint32_t lo = row_find32(col32, v_start, v_deg, w, run);
+                const uint32_t lo = row_find32_wide(col32, v_start, v_deg, w, run);
                 m.set_run(lo, run);
             }
         }
@@ -1109,7 +1137,7 @@ csr_ext32_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict_
                     atomicAdd(&g_cnt_rpos, 1ull);
 #endif
                     uint32_t cnt = 0;
-                    const uint32_t lo = sorted ? row_find32(col32, start, deg, u, cnt) : 0u;
+                    const uint32_t lo = sorted ? row_find32_wide(col32, start, deg, u, cnt) : 0u;
                     rpos = (sorted && cnt <= 15u && lo < (1u << 28)) ? ((cnt << 28) | lo) : kRposLookup;
                 }
                 const uint32_t deg_u = row_hi - row_lo;
@@ -1188,16 +1216,19 @@ csr_ext32_heavy_kernel(const uint32_t *__restrict__ row32, const uint32_t *__res
 // row are consecutive, the tile stays -- and each wave streams the shorter rows of its share of the task's items,
 // four elements per lane at a time.  Every global load is a coalesced stream; the only random accesses left are
 // LDS reads.
-constexpr uint32_t kTaskEntries = 128;   // MK_TILE_A: entries of the tile row per task (rows of kSmallRow entries or more)
-constexpr uint32_t kTaskEntriesSmall = 64;  // ... of a shorter row: a task is one wave's
-constexpr uint32_t kTaskItems = 64;      // MK_TILE_B: in-list items per task
+#ifndef TRW_TASK_ENTRIES
+#define TRW_TASK_ENTRIES 128
+#endif
+#ifndef TRW_TASK_ITEMS
+#define TRW_TASK_ITEMS 64
+#endif
+constexpr uint32_t kTaskEntries = TRW_TASK_ENTRIES;   // MK_TILE_A: entries of the tile row per task
+constexpr uint32_t kTaskItems = TRW_TASK_ITEMS;      // MK_TILE_B: in-list items per task
 #ifndef TRW_TASK_GRAB
 #define TRW_TASK_GRAB 16
 #endif
 constexpr uint32_t kTaskGrab = TRW_TASK_GRAB;  // consecutive tasks a workgroup takes from the counter at a time
-// header slots; tasks of short rows (one wave each, heavy_tile_kernel<.., 64, ..>) fill the task array from the front, those
-// of long rows (a workgroup each) the last quarter
-constexpr int kStTaskCount = 16, kStSortedCursor = 17, kStTaskNext = 18, kStTaskCountBig = 19, kStTaskNextBig = 20;
+constexpr int kStTaskCount = 16, kStSortedCursor = 17, kStTaskNext = 18;  // header slots
 constexpr uint32_t kNoSegment = 0xFFFFFFFFu;
 
 struct TileTask {
@@ -1223,15 +1254,13 @@ __device__ __forceinline__ uint32_t wave_prefix_excl(uint32_t v, int lane, uint3
 __global__ void __launch_bounds__(kBlock)
 heavy_plan_kernel(const uint32_t *__restrict__ row32, int64_t n_nodes, const uint32_t *__restrict__ in_count,
                   uint32_t *__restrict__ in_off, TileTask *__restrict__ tasks, uint32_t task_room, uint32_t heavy_room,
-                  uint32_t inline_cap, uint32_t small_row, int64_t *__restrict__ header)
+                  uint32_t inline_cap, int64_t *__restrict__ header)
 {
     if (header[kStDescents] != header[kStBoundary]) return;  // rows not sorted: no masks, no tasks
     const int lane = threadIdx.x & 63;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     const uint64_t queued = (uint64_t)header[kStHeavyCount];
     const uint32_t base0 = queued < heavy_room ? (uint32_t)queued : heavy_room;  // the queue's items come first
-    // (no list of short rows -- small_row == 0 --: the whole room is the long rows')
-    const uint32_t room_small = small_row ? task_room - task_room / 4u : 0u, room_big = task_room - room_small;
     for (int64_t x0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) & ~(int64_t)63; x0 < n_nodes; x0 += stride) {
         const int64_t x = x0 + lane;
         uint32_t start = 0, deg = 0;
@@ -1252,30 +1281,20 @@ heavy_plan_kernel(const uint32_t *__restrict__ row32, int64_t n_nodes, const uin
             in_off[x] = seg;  // kNoSegment: no room, these entries keep their all-ones masks
         }
         // tasks; MK_TILE_A needs deg > deg(v) > inline_cap
-        const bool big = tile && deg >= small_row;
-        const uint32_t per_a = big ? kTaskEntries : kTaskEntriesSmall;
-        const uint32_t n_a = (tile && deg >= inline_cap + 2u) ? (deg + per_a - 1u) / per_a : 0u;
+        const uint32_t n_a = (tile && deg >= inline_cap + 2u) ? (deg + kTaskEntries - 1u) / kTaskEntries : 0u;
         const uint32_t n_b = seg != kNoSegment ? (c + kTaskItems - 1u) / kTaskItems : 0u;
         const uint32_t n_t = n_a + n_b;
-        uint32_t tot_big, tot_small;
-        const uint32_t before_big = wave_prefix_excl(big ? n_t : 0u, lane, tot_big);
-        const uint32_t before_small = wave_prefix_excl(big ? 0u : n_t, lane, tot_small);
-        uint64_t at_big = 0, at_small = 0;
-        if (lane == 0 && tot_big) at_big = atomicAdd((unsigned long long *)&header[kStTaskCountBig], (unsigned long long)tot_big);
-        if (lane == 0 && tot_small) at_small = atomicAdd((unsigned long long *)&header[kStTaskCount], (unsigned long long)tot_small);
-        // (both broadcasts outside the select: a shuffle inside one arm of it runs with the other arm's lanes switched off,
-        // lane 0 possibly among them)
-        const uint64_t base_big = (uint64_t)__shfl((long long)at_big, 0), base_small = (uint64_t)__shfl((long long)at_small, 0);
-        const uint64_t at = big ? base_big + before_big : base_small + before_small;
-        const uint32_t room = big ? room_big : room_small;
-        TileTask *const list = big ? tasks + room_small : tasks;
-        auto record = [&](uint32_t node, uint32_t r_start, uint32_t r_deg, uint32_t r_seg, uint32_t r_c, uint32_t r_na, uint32_t r_per,
-                          uint32_t k) {
+        uint32_t n_total;
+        const uint32_t n_before = wave_prefix_excl(n_t, lane, n_total);
+        uint64_t at0 = 0;
+        if (lane == 0 && n_total) at0 = atomicAdd((unsigned long long *)&header[kStTaskCount], (unsigned long long)n_total);
+        const uint64_t at = (uint64_t)__shfl((long long)at0, 0) + n_before;  // (a shuffle must not sit inside a select's arm)
+        auto record = [&](uint32_t node, uint32_t r_start, uint32_t r_deg, uint32_t r_seg, uint32_t r_c, uint32_t r_na, uint32_t k) {
             TileTask t;
             t.node = node;
             if (k < r_na) {
-                t.start = r_start + k * r_per;
-                t.count = r_deg - k * r_per < r_per ? r_deg - k * r_per : r_per;
+                t.start = r_start + k * kTaskEntries;
+                t.count = r_deg - k * kTaskEntries < kTaskEntries ? r_deg - k * kTaskEntries : kTaskEntries;
                 t.mode = 0u;
             } else {
                 const uint32_t kb = k - r_na;
@@ -1292,16 +1311,14 @@ heavy_plan_kernel(const uint32_t *__restrict__ row32, int64_t n_nodes, const uin
             wide &= wide - 1;
             const uint32_t w_n = (uint32_t)__shfl((int)n_t, src), w_na = (uint32_t)__shfl((int)n_a, src);
             const uint32_t w_start = (uint32_t)__shfl((int)start, src), w_deg = (uint32_t)__shfl((int)deg, src);
-            const uint32_t w_seg = (uint32_t)__shfl((int)seg, src), w_c = (uint32_t)__shfl((int)c, src), w_per = (uint32_t)__shfl((int)per_a, src);
+            const uint32_t w_seg = (uint32_t)__shfl((int)seg, src), w_c = (uint32_t)__shfl((int)c, src);
             const uint64_t w_at = (uint64_t)__shfl((long long)at, src);
-            const uint32_t w_room = (uint32_t)__shfl((int)room, src);
-            TileTask *const w_list = (TileTask *)__shfl((long long)(uintptr_t)list, src);
             for (uint32_t k = (uint32_t)lane; k < w_n; k += 64u)
-                if (w_at + k < w_room) w_list[w_at + k] = record((uint32_t)(x0 + src), w_start, w_deg, w_seg, w_c, w_na, w_per, k);
+                if (w_at + k < task_room) tasks[w_at + k] = record((uint32_t)(x0 + src), w_start, w_deg, w_seg, w_c, w_na, k);
         }
         if (n_t <= 16u)
             for (uint32_t k = 0; k < n_t; ++k)
-                if (at + k < room) list[at + k] = record((uint32_t)x, start, deg, seg, c, n_a, per_a, k);
+                if (at + k < task_room) tasks[at + k] = record((uint32_t)x, start, deg, seg, c, n_a, k);
     }
 }
 
@@ -1349,17 +1366,15 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 // tile whole.  Of a longer one (a few hundred rows of R-MAT 10M/110M, but 11 % of the searches) the tile holds every
 // m-th entry -- the last of each block of m = ceil(n / (kCap-1)) --, the bisection in LDS finds the block and the last
 // log2(m) levels read the block in global memory (L2 hits: 1 level for a row of 8-16 K entries, 5 for the longest).
-// kBig: the list of long rows' tasks (128 entries each) / of short rows' (64 each; `tasks`, `task_room`: that list).
-template <uint32_t kCap, int kThreads, bool kBig>
+template <uint32_t kCap, int kThreads>
 __global__ void __launch_bounds__(kThreads)
 heavy_tile_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32, u32x4_a16 *__restrict__ ext,
                   const HeavyItem *__restrict__ items, const TileTask *__restrict__ tasks, uint32_t task_room,
                   uint32_t inline_cap, uint32_t heavy_cap, int64_t *__restrict__ header)
 {
     constexpr uint32_t kWaves = kThreads / 64;
-    constexpr uint32_t kEntries = kBig ? kTaskEntries : kTaskEntriesSmall;
-    constexpr uint32_t kPerWave = (kEntries > kTaskItems ? kEntries : kTaskItems) / kWaves;  // items of a task per wave
-    constexpr int kCountSlot = kBig ? kStTaskCountBig : kStTaskCount, kNextSlot = kBig ? kStTaskNextBig : kStTaskNext;
+    constexpr uint32_t kPerWave = (kTaskEntries > kTaskItems ? kTaskEntries : kTaskItems) / kWaves;  // items of a task per wave
+    constexpr int kCountSlot = kStTaskCount, kNextSlot = kStTaskNext;
     static_assert(kPerWave <= 64 && (kCap & (kCap - 1)) == 0, "one lane per item; power-of-two tile");
     constexpr uint32_t kHead = kWaves * kPerWave * 4 + 4;  // words in front of the tile: the waves' masks, `grabbed`
     __shared__ uint32_t lds[kHead + kCap];
@@ -1374,11 +1389,18 @@ heavy_tile_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
     const uint32_t n_tasks = made < task_room ? (uint32_t)made : task_room;
     // the tile holds cur_node's row [t_start, t_start + n): every m-th entry, nb of them; the bisection's first step is top4 bytes
     uint32_t cur_node = 0xFFFFFFFFu, n = 0, t_start = 0, m = 1, nb = 0, top4 = 0, mtop = 0;
+#ifdef TRW_TILE_CLOCKS
+    unsigned long long ck[6] = {0, 0, 0, 0, 0, 0}, ck_t = clock64();
+#define TRW_LAP(k) do { const unsigned long long now_ = clock64(); ck[k] += now_ - ck_t; ck_t = now_; } while (0)
+#else
+#define TRW_LAP(k) do { } while (0)
+#endif
     while (true) {
         __syncthreads();  // (everyone has read `grabbed` of the last round)
         if (threadIdx.x == 0) grabbed = (uint32_t)atomicAdd((unsigned long long *)&header[kNextSlot], (unsigned long long)kTaskGrab);
         __syncthreads();
         const uint32_t t0 = grabbed;
+        TRW_LAP(0);
         if (t0 >= n_tasks) break;
         const uint32_t t1 = t0 + kTaskGrab < n_tasks ? t0 + kTaskGrab : n_tasks;
         for (uint32_t ti = t0; ti < t1; ++ti) {
@@ -1406,6 +1428,7 @@ heavy_tile_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
                 }
             }
             const uint64_t todo = __ballot(mine);
+            TRW_LAP(1);
             // Waves only meet when the tile changes (a barrier per task made every wave wait for the task's slowest:
             // 72 % of the wave cycles were waits); between two changes each wave works through its share of the tasks
             // at its own pace.
@@ -1431,6 +1454,7 @@ heavy_tile_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
                 __syncthreads();
                 if (todo == 0) continue;
             }
+            TRW_LAP(2);
             if (lane < (int)kPerWave) acc[lane][0] = acc[lane][1] = acc[lane][2] = acc[lane][3] = 0u;
             // the wave's (item, 256 elements) pieces, one after the other; the next piece's elements are on their way
             // while this one's are searched.  Buffer loads: lanes beyond the row's end read 0 (no exec-mask region
@@ -1523,6 +1547,7 @@ heavy_tile_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
                 else if (rest <= 128u) search(std::integral_constant<int, 2>{});
                 else search(std::integral_constant<int, 4>{});
             }
+            TRW_LAP(3);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1532,8 +1557,14 @@ heavy_tile_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
                 if (deg_v <= 128u) reinterpret_cast<uint32_t *>(ext + 2 * (size_t)e)[2] = deg_v;  // exact: drop the filter bit
             }
             __builtin_amdgcn_wave_barrier();  // (the next task clears acc)
+            TRW_LAP(4);
         }
     }
+#ifdef TRW_TILE_CLOCKS
+    if (lane == 0)
+        for (int k = 0; k < 5; ++k) atomicAdd((unsigned long long *)&header[24 + k], ck[k]);
+#endif
+#undef TRW_LAP
 }
 
 enum : uint32_t { LS_IDLE = 0, LS_START, LS_ROW, LS_POS, LS_TRIAL, LS_CAND, LS_MEMBER, LS_ACCEPT };
