@@ -129,7 +129,7 @@ struct PrepLayout {
     uint32_t table_blocks = 0;  // the edge set: blocks of four 8-byte keys
     uint32_t heavy_room = 0, task_room = 0;
     size_t off_row32 = 0, off_col32 = 0, off_ext16 = 0, off_table = 0, off_ext32 = 0, off_heavy = 0, total = 0;
-    size_t off_incount = 0, off_inoff = 0, off_tasks = 0;  // the tile pass: per-node in-list counters / segments, tasks
+    size_t off_incount = 0, off_inoff = 0, off_infill = 0, off_tasks = 0;  // the tile pass: per-node in-list counters / segments / fill marks, tasks
 };
 
 bool graph_fits_narrow(int64_t n_nodes, int64_t nnz)
@@ -173,22 +173,28 @@ PrepLayout make_prep_layout(int64_t n_nodes, int64_t nnz, int32_t what)
             off += align_up((size_t)pl.table_blocks * 32 + 64, 256);
             pl.off_ext32 = off;
             off += align_up((size_t)nnz * 32 + 64, 256);
-            if (pl.marks) {  // queue of the entries whose mask takes a whole wave
-                const uint64_t room = (uint64_t)nnz / 2 + 1024;
+            if (pl.marks) {
+                // Scratch of the marking passes.  Items {entry, source node} of the in-lists (tile pass) or of the queue
+                // (wave-per-entry pass): the entries u -> v whose row of u is the shorter or equal one and longer than the
+                // inline cap -- about half of the entries at most; a pass that runs out of room leaves the rest of them
+                // their all-ones masks.
+                const uint64_t room = (uint64_t)nnz / 5 * 3 + 1024;
                 pl.heavy_room = room > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)room;
                 pl.off_heavy = off;
                 off += align_up((size_t)pl.heavy_room * 8, 256);
-                // the tile pass (heavy_tile_kernel): in-list counter and segment per node, and its task records --
-                // at most nnz/128 + (nnz/2)/64 + two per row of more than 32 entries; a plan that runs out of room
-                // drops tasks, whose entries keep their all-ones masks
+                // the tile pass (heavy_tile_kernel): in-list size, segment and fill mark per node, and its 8-byte task
+                // records -- one per 128 entries of a tile row, one per 64 items of an in-list, so two at least per row
+                // longer than the inline cap
                 pl.off_incount = off;
                 off += align_up((size_t)(n_nodes + 1) * 4, 256);
                 pl.off_inoff = off;
                 off += align_up((size_t)(n_nodes + 1) * 4, 256);
-                const uint64_t troom = (uint64_t)nnz / 10 + 4096;
+                pl.off_infill = off;
+                off += align_up((size_t)(n_nodes + 1) * 4, 256);
+                const uint64_t troom = (uint64_t)nnz / 5 + 4096;
                 pl.task_room = troom > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)troom;
                 pl.off_tasks = off;
-                off += align_up((size_t)pl.task_room * 16, 256);
+                off += align_up((size_t)pl.task_room * 8, 256);
             }
         }
     }
@@ -501,7 +507,7 @@ int trw_prepare_csr_region(int64_t n_nodes, int64_t nnz, int32_t what, int32_t w
     case TRW_REGION_EXT16: if (pl.ext16) { *offset = pl.off_ext16; *bytes = (size_t)nnz * 16; } break;
     case TRW_REGION_TABLE: if (pl.biased) { *offset = pl.off_table; *bytes = (size_t)pl.table_blocks * 32; } break;
     case TRW_REGION_EXT32: if (pl.biased) { *offset = pl.off_ext32; *bytes = (size_t)nnz * 32; } break;
-    case TRW_REGION_TASKS: if (pl.marks) { *offset = pl.off_tasks; *bytes = (size_t)pl.task_room * 16; } break;
+    case TRW_REGION_TASKS: if (pl.marks) { *offset = pl.off_tasks; *bytes = (size_t)pl.task_room * 8; } break;
     default: return fail(TRW_E_ARG, "unknown region");
     }
     return TRW_OK;
@@ -547,17 +553,25 @@ int trw_prepare_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *
             // 256: 128 -> 58; + heavy 1024: 252 -> 52.5; + heavy 4096: 390 -> 52 with one random table probe per entry
             // of the shorter row in both passes; the heavy pass bisects the (sorted, L2-resident) long rows instead
             // since: inline 32 + heavy 256: 107 -> 58; + heavy 1024: 178 -> 52; + heavy 4096: 248 -> 53 (no better).
-            const uint32_t inline_cap = (uint32_t)env_long("TRW_COMMON_MAX", 0, 4096, 32);
+            // (With the tile pass behind it the owning thread keeps only the rows up to 8: measured, full prepare, same walk:
+            // inline 32 / 16 / 12 / 8 / 4: 79.7 / 73.6 / 70.7 / 69.4 / 69.6 ms -- a probe of the edge set per entry of the
+            // shorter row costs more than the entry's share of a tile.  Without marks there is no tile pass: 32.)
+            const bool tile_pass = pl.marks && env_long("TRW_HEAVY_TILE", 0, 1, 1) == 1;
+            const uint32_t inline_cap = (uint32_t)env_long("TRW_COMMON_MAX", 0, 4096, tile_pass ? 8 : 32);
             const uint32_t heavy_cap =
                 pl.marks ? (uint32_t)env_long("TRW_HEAVY_MAX", 0, 1 << 20, pl.marks_full ? 1024 : 256) : 0u;
             HeavyItem *heavy = pl.marks ? (HeavyItem *)(ws + pl.off_heavy) : nullptr;
             // The masks of entries whose shorter row is longer than inline_cap: the tile pass (heavy_tile_kernel: the
             // longer row in LDS, the shorter rows streamed past it).  TRW_HEAVY_TILE=0: the wave-per-entry pass over
             // a queue instead (round 3's form: every search a bisection in global memory).
-            const bool tiles = pl.marks && heavy_cap > inline_cap && env_long("TRW_HEAVY_TILE", 0, 1, 1) == 1;
+            const bool tiles = tile_pass && heavy_cap > inline_cap;
             uint32_t *in_count = pl.marks ? (uint32_t *)(ws + pl.off_incount) : nullptr;
             uint32_t *in_off = pl.marks ? (uint32_t *)(ws + pl.off_inoff) : nullptr;
-            if (tiles) device_fill(in_count, 0u, align_up((size_t)(n_nodes + 1) * 4, 256), stream);
+            uint32_t *in_fill = pl.marks ? (uint32_t *)(ws + pl.off_infill) : nullptr;
+            if (tiles) {
+                device_fill(in_count, 0u, align_up((size_t)(n_nodes + 1) * 4, 256), stream);
+                device_fill(in_fill, 0u, align_up((size_t)(n_nodes + 1) * 4, 256), stream);
+            }
             csr_ext32_kernel<<<stream_grid((nnz + 7) / 8), kBlock, 0, stream>>>(
                 row32, col32, n_nodes, nnz, table, pl.table_blocks, inline_cap, heavy_cap, tiles ? 1u : 0u,
                 (u32x4_a16 *)(ws + pl.off_ext32), heavy, pl.heavy_room, in_count, header);
@@ -567,14 +581,14 @@ int trw_prepare_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *
                 heavy_plan_kernel<<<stream_grid(n_nodes), kBlock, 0, stream>>>(row32, n_nodes, in_count, in_off, tasks,
                                                                                pl.task_room, pl.heavy_room, inline_cap, header);
                 heavy_scatter_kernel<<<stream_grid(n_nodes), kBlock, 0, stream>>>(row32, col32, n_nodes, inline_cap,
-                                                                                  heavy_cap, in_count, in_off, heavy);
+                                                                                  heavy_cap, in_fill, in_off, heavy);
                 // 8 192 entries of LDS per tile, 8 waves per workgroup, 4 workgroups per CU.  Measured on R-MAT 10M/110M
                 // (full prepare): 16 384 x 8 waves (2 per CU) +8 ms; 8 192 x 4 waves +7; 4 096 x 4 waves +2; tiles of ONE
                 // wave for rows below 1 024 / 2 048 entries next to workgroup tiles for the rest (no barrier for
                 // 98 % of the rows) +6 / +10 -- the workgroup's waves hide each other's latencies better than they
                 // cost each other in barriers.
                 heavy_tile_kernel<8192, 512><<<(unsigned)device_cu_count() * 4, 512, 0, stream>>>(
-                    row32, col32, ext32, heavy, tasks, pl.task_room, inline_cap, heavy_cap, header);
+                    row32, col32, ext32, heavy, tasks, pl.task_room, in_count, in_off, inline_cap, heavy_cap, header);
             }
             if (pl.marks && !tiles)
                 csr_ext32_heavy_kernel<<<(unsigned)(device_cu_count() * 8), kBlock, 0, stream>>>(

@@ -1231,8 +1231,9 @@ constexpr uint32_t kTaskGrab = TRW_TASK_GRAB;  // consecutive tasks a workgroup 
 constexpr int kStTaskCount = 16, kStSortedCursor = 17, kStTaskNext = 18;  // header slots
 constexpr uint32_t kNoSegment = 0xFFFFFFFFu;
 
-struct TileTask {
-    uint32_t node, start, count, mode;  // mode 0: entries [start, start+count) of node's row; 1: items [start, ...) of its in-list
+struct TileTask {  // 8 bytes: what else a task needs (how many, of how many) the tile kernel has from row32 / the in-list arrays
+    uint32_t node_mode;  // node | mode << 31; mode 0: up to kTaskEntries entries of node's row from `start` on,
+    uint32_t start;      //                     mode 1: up to kTaskItems items of its in-list from items[start] on
 };
 
 // One lane per node, a wave per 64 nodes: tasks for the rows that can be a tile, and a segment of the item array for the
@@ -1289,18 +1290,14 @@ heavy_plan_kernel(const uint32_t *__restrict__ row32, int64_t n_nodes, const uin
         uint64_t at0 = 0;
         if (lane == 0 && n_total) at0 = atomicAdd((unsigned long long *)&header[kStTaskCount], (unsigned long long)n_total);
         const uint64_t at = (uint64_t)__shfl((long long)at0, 0) + n_before;  // (a shuffle must not sit inside a select's arm)
-        auto record = [&](uint32_t node, uint32_t r_start, uint32_t r_deg, uint32_t r_seg, uint32_t r_c, uint32_t r_na, uint32_t k) {
+        auto record = [&](uint32_t node, uint32_t r_start, uint32_t r_seg, uint32_t r_na, uint32_t k) {
             TileTask t;
-            t.node = node;
             if (k < r_na) {
+                t.node_mode = node;
                 t.start = r_start + k * kTaskEntries;
-                t.count = r_deg - k * kTaskEntries < kTaskEntries ? r_deg - k * kTaskEntries : kTaskEntries;
-                t.mode = 0u;
             } else {
-                const uint32_t kb = k - r_na;
-                t.start = r_seg + kb * kTaskItems;
-                t.count = r_c - kb * kTaskItems < kTaskItems ? r_c - kb * kTaskItems : kTaskItems;
-                t.mode = 1u;
+                t.node_mode = node | 0x80000000u;
+                t.start = r_seg + (k - r_na) * kTaskItems;
             }
             return t;
         };
@@ -1310,15 +1307,14 @@ heavy_plan_kernel(const uint32_t *__restrict__ row32, int64_t n_nodes, const uin
             const int src = __builtin_ctzll(wide);
             wide &= wide - 1;
             const uint32_t w_n = (uint32_t)__shfl((int)n_t, src), w_na = (uint32_t)__shfl((int)n_a, src);
-            const uint32_t w_start = (uint32_t)__shfl((int)start, src), w_deg = (uint32_t)__shfl((int)deg, src);
-            const uint32_t w_seg = (uint32_t)__shfl((int)seg, src), w_c = (uint32_t)__shfl((int)c, src);
+            const uint32_t w_start = (uint32_t)__shfl((int)start, src), w_seg = (uint32_t)__shfl((int)seg, src);
             const uint64_t w_at = (uint64_t)__shfl((long long)at, src);
             for (uint32_t k = (uint32_t)lane; k < w_n; k += 64u)
-                if (w_at + k < task_room) tasks[w_at + k] = record((uint32_t)(x0 + src), w_start, w_deg, w_seg, w_c, w_na, k);
+                if (w_at + k < task_room) tasks[w_at + k] = record((uint32_t)(x0 + src), w_start, w_seg, w_na, k);
         }
         if (n_t <= 16u)
             for (uint32_t k = 0; k < n_t; ++k)
-                if (at + k < task_room) tasks[at + k] = record((uint32_t)x, start, deg, seg, c, n_a, k);
+                if (at + k < task_room) tasks[at + k] = record((uint32_t)x, start, seg, n_a, k);
     }
 }
 
@@ -1326,7 +1322,7 @@ heavy_plan_kernel(const uint32_t *__restrict__ row32, int64_t n_nodes, const uin
 // can be the shorter side of such an entry (inline_cap < deg <= heavy_cap) are scanned by the whole wave.
 __global__ void __launch_bounds__(kBlock)
 heavy_scatter_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32, int64_t n_nodes,
-                     uint32_t inline_cap, uint32_t heavy_cap, uint32_t *__restrict__ in_count,
+                     uint32_t inline_cap, uint32_t heavy_cap, uint32_t *__restrict__ in_fill,
                      const uint32_t *__restrict__ in_off, HeavyItem *__restrict__ items)
 {
     const int lane = threadIdx.x & 63;
@@ -1348,7 +1344,7 @@ heavy_scatter_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restr
                 if (mask_route(u_deg, v_deg, inline_cap, heavy_cap, 1u) != MK_TILE_B) continue;
                 const uint32_t seg = in_off[v];
                 if (seg == kNoSegment) continue;
-                const uint32_t k = atomicSub(in_count + v, 1u) - 1u;
+                const uint32_t k = atomicAdd(in_fill + v, 1u);  // (in_count stays: the tile pass reads a task's size from it)
                 items[seg + k] = HeavyItem{e, u};
             }
         }
@@ -1370,7 +1366,8 @@ template <uint32_t kCap, int kThreads>
 __global__ void __launch_bounds__(kThreads)
 heavy_tile_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32, u32x4_a16 *__restrict__ ext,
                   const HeavyItem *__restrict__ items, const TileTask *__restrict__ tasks, uint32_t task_room,
-                  uint32_t inline_cap, uint32_t heavy_cap, int64_t *__restrict__ header)
+                  const uint32_t *__restrict__ in_count, const uint32_t *__restrict__ in_off, uint32_t inline_cap,
+                  uint32_t heavy_cap, int64_t *__restrict__ header)
 {
     constexpr uint32_t kWaves = kThreads / 64;
     constexpr uint32_t kPerWave = (kTaskEntries > kTaskItems ? kTaskEntries : kTaskItems) / kWaves;  // items of a task per wave
@@ -1404,10 +1401,20 @@ heavy_tile_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
         if (t0 >= n_tasks) break;
         const uint32_t t1 = t0 + kTaskGrab < n_tasks ? t0 + kTaskGrab : n_tasks;
         for (uint32_t ti = t0; ti < t1; ++ti) {
-            const TileTask task = tasks[ti];
+            const TileTask rec = tasks[ti];
+            struct {
+                uint32_t node, start, count, mode;
+            } task = {rec.node_mode & 0x7FFFFFFFu, rec.start, 0u, rec.node_mode >> 31};
             const bool new_node = task.node != cur_node;  // (workgroup-uniform)
             uint32_t n_new = n, start_new = t_start;
             if (new_node) load_row32(row32, task.node, start_new, n_new);
+            if (task.mode == 0u) {  // what is left of the row / of the in-list from `start` on, a task's worth at most
+                const uint32_t rest_a = start_new + n_new - task.start;
+                task.count = rest_a < kTaskEntries ? rest_a : kTaskEntries;
+            } else {
+                const uint32_t rest_b = in_off[task.node] + in_count[task.node] - task.start;
+                task.count = rest_b < kTaskItems ? rest_b : kTaskItems;
+            }
             // this wave's items of the task: lane j looks at item wave + kWaves * j
             const uint32_t k = wave + kWaves * (uint32_t)lane;
             uint32_t s_start = 0, s_len = 0, e = 0, deg_v = 0;
@@ -1486,6 +1493,7 @@ heavy_tile_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
                 }
                 if (src >= 0) fetch(src, base);
                 const uint32_t rest = i_len - from;  // (wave-uniform)
+                const bool odd_levels = (__builtin_clz(top4) & 1) != 0;  // top4 = 2^k bytes: k - 1 levels, odd iff k is even iff clz = 31 - k is odd
                 // The kernel is bound by the NUMBER of vector instructions (4 cycles each on a SIMD, whatever they
                 // are: 82 % VALU-busy when a level took five): a level of the bisection is add, ds_read, compare,
                 // select, and a piece shorter than 256 elements searches only the 64-element groups it has.
@@ -1495,13 +1503,24 @@ heavy_tile_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
                     uint32_t qa[kR];
 #pragma unroll
                     for (int r = 0; r < kR; ++r) qa[r] = tile_lds - 4u;
-                    for (uint32_t s4 = top4; s4 >= 4u; s4 >>= 1) {
+                    // (two levels per trip: with one group the loop's own shift, compare and branch were as many issue
+                    // slots as the level; a tile has six levels at least, `odd_levels` says whether one goes first)
+                    auto level = [&](uint32_t s4) {
 #pragma unroll
                         for (int r = 0; r < kR; ++r) {
                             const uint32_t a = qa[r] + s4;
                             const uint32_t t = *reinterpret_cast<const lds_u32 *>((uintptr_t)a);
                             qa[r] = t < x[r] ? a : qa[r];
                         }
+                    };
+                    uint32_t s4 = top4;
+                    if (odd_levels) {
+                        level(s4);
+                        s4 >>= 1;
+                    }
+                    for (; s4 >= 8u; s4 >>= 2) {
+                        level(s4);
+                        level(s4 >> 1);
                     }
 #pragma unroll
                     for (int r = 0; r < kR; ++r) {
