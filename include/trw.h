@@ -13,11 +13,15 @@
  * memset/memcpy nodes, no synchronisation) and may be captured into a HIP graph.  Environment knobs (debug/tests): TRW_GLIBC_CHAIN=k
  * walkers chained per lane in the uniform kernel; TRW_FORCE_WIDE=1 use the int64
  * kernels; TRW_NO_POS=1 disable the located-t shortcut of the biased kernel;
- * TRW_HASH=0/1, TRW_EXT=0/1 force the edge table / the fat entries off or on;
- * TRW_HASH_SLACK=k table slots per edge (default 3); TRW_RESIDENT_BLOCKS=k
- * workgroups per CU of the persistent biased kernel (default 5);
- * TRW_COMMON_MAX=k longest row for which "shares no node with the neighbour's
- * row" is worked out per edge (default 8, 0 = off).
+ * TRW_HASH=0/1, TRW_EXT=0/1 force the edge set / the fat entries off or on;
+ * TRW_HASH_SLACK=k TENTHS of a place of the edge set per edge (default 25: load 0.4);
+ * TRW_RESIDENT_BLOCKS=k workgroups per CU of the persistent biased kernel (default 5);
+ * TRW_COMMON_MAX=k longest (shorter) row whose neighbourhood mask the thread that owns
+ * the entry works out itself (default 32; 8 when the tile pass follows);
+ * TRW_HEAVY_MAX=k longest (shorter) row the marking passes take (default 256 / 1024);
+ * TRW_HEAVY_TILE=0 the wave-per-entry marking pass of rounds 2-3 instead of the tile pass;
+ * TRW_PLAN_MARKS_AT / TRW_PLAN_FULL_AT=k steps per CSR entry from which ONE call is
+ * planned with TRW_PREP_MARKS / _FULL (default 5 / 14).
  * None of them changes a result.
  */
 #ifndef TRW_H
@@ -89,7 +93,8 @@ const char *trw_last_error(void);
 /* Bytes of device scratch trw_walk_csr_hip needs for this call shape
  * (>= 256): status block, per-lane RNG windows (uniform walks), the uint32
  * shadow of the CSR (4*(n_nodes+1+nnz) bytes), and by call shape the fat
- * entries (16*nnz) and the edge table (16 * 2^k >= 48*nnz). */
+ * entries (16*nnz), or the edge set (20*nnz), the 32-byte entries (32*nnz) and, for a call that
+ * makes 5 steps per entry or more, the marking passes' scratch (8*nnz): 64 bytes per entry at most. */
 size_t trw_walk_csr_workspace_bytes(int64_t n_nodes, int64_t nnz, int64_t n_walkers,
                                     int32_t walk_length, double p, double q, int32_t rng_mode);
 
@@ -129,7 +134,7 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes,
 
 /*
  * The prepared graph.  Everything the walk derives from (row_ptr, col_idx) alone -- validation, the uint32
- * shadow, fat entries, the edge table, the per-edge neighbourhood masks -- is built into ONE caller-owned
+ * shadow, fat entries, the edge set, the per-edge neighbourhood masks -- is built into ONE caller-owned
  * device buffer and reused by any number of walks (the reference has no such object: it re-reads the int64
  * CSR on every call; SURVEY 8(b) "Ownership" allows cached derived data).  trw_walk_csr_hip above is the
  * one-shot form: it prepares inside its own workspace on every call.
@@ -140,10 +145,12 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes,
  *                       deg(v), where-the-reverse-edge-sits, 128-bit "is the node at this offset a neighbour
  *                       of the node I came from" mask}: a node2vec rejection trial is decided in registers and
  *                       the graph is read once per step.  Masks are worked out for entries one of whose rows
- *                       has at most 32 entries; the rest ask the table.
- *     TRW_PREP_MARKS    (implies BIASED) masks for every entry one of whose rows has at most 256 entries:
- *                       about 3x the prepare time, 35 % faster walks -- pays from about 3 walks of a graph
- *     TRW_PREP_MARKS_FULL (implies MARKS) ... at most 1024 entries: about 5x the prepare time, another 10 %
+ *                       has at most 32 entries; the rest ask the edge set.
+ *     TRW_PREP_MARKS    (implies BIASED) masks for every entry one of whose rows has at most 256 entries (the
+ *                       tile pass: the longer row in LDS): about 1.5x the prepare time, 45 % faster walks --
+ *                       worth it for a single call of 5 steps per CSR entry (trw_prepare_plan asks for it then)
+ *     TRW_PREP_MARKS_FULL (implies MARKS) ... at most 1024 entries: about 2x the prepare time, another 20 %
+ *                       (planned from 14 steps per entry on)
  *   or one of          TRW_PREP_ORDER_ONLY: no shadow, only the row-order probe the int64 biased kernels want;
  *                      TRW_PREP_NOTHING: header only (uniform walk on the per-walker stream)
  * trw_prepare_plan returns the `what` one call of the given shape is worth (what trw_walk_csr_hip builds).
@@ -168,7 +175,7 @@ int trw_prepare_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *
 #define TRW_REGION_ROW32  1   /* uint32 row offsets, n_nodes + 1 */
 #define TRW_REGION_COL32  2   /* uint32 neighbours, nnz */
 #define TRW_REGION_EXT16  3   /* 16-byte entries of the uniform walk */
-#define TRW_REGION_TABLE  4   /* edge table */
+#define TRW_REGION_TABLE  4   /* edge set: blocks of four 8-byte keys {u, v} */
 #define TRW_REGION_EXT32  5   /* 32-byte entries of the node2vec walk: {v, start(v), deg(v)|filter, rpos} + 128-bit mask */
 #define TRW_REGION_TASKS  6   /* the tile pass's task records {node, start, count, mode} (scratch of the prepare pass) */
 int trw_prepare_csr_region(int64_t n_nodes, int64_t nnz, int32_t what, int32_t which, size_t *offset, size_t *bytes);

@@ -7,7 +7,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 ORDER = ["default", "rmat10m_uniform", "er100k_uniform", "papers100m_uniform", "papers100m_biased", "papers100m_full", "kg5m_triples", "elist_rmat1m_uniform",
          "elist_rmat1m_biased", "windows_1m", "walk_windows_1m"]
 pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))

@@ -5,7 +5,7 @@
 # usage: scripts/regen_all.sh [tag] ["workloads to profile" (may be "")] [profiles-only]   (a gpurun call lasts 20 minutes
 # at most: profile the workloads in two or three calls with `profiles-only`, copying pmc_traffic.json into profiles/
 # between them, then run the bench lines and probes with an empty workload list)
-TAG=${1:-r03}
+TAG=${1:-r04}
 WLS=${2-"rmat10m_biased rmat10m_uniform er100k_uniform kg5m_triples elist_rmat1m_uniform elist_rmat1m_biased windows_1m walk_windows_1m"}
 mkdir -p gpurun_out/collected
 for w in $WLS; do

@@ -1498,8 +1498,11 @@ heavy_tile_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
                 // are: 82 % VALU-busy when a level took five): a level of the bisection is add, ds_read, compare,
                 // select, and a piece shorter than 256 elements searches only the 64-element groups it has.
                 // `qa` = LDS address of the last tile entry known to be < x (tile[-1] to start with).
-                auto search = [&](auto groups) {
+                // (kSampled: the tile holds every m-th entry of the row, the block is finished in global memory.  The
+                // two forms are separate code -- the common one has no branch but "did any lane hit", a hit being rare.)
+                auto search = [&](auto groups, auto sampled_row) {
                     constexpr int kR = decltype(groups)::value;
+                    constexpr bool kSampled = decltype(sampled_row)::value;
                     uint32_t qa[kR];
 #pragma unroll
                     for (int r = 0; r < kR; ++r) qa[r] = tile_lds - 4u;
@@ -1522,15 +1525,16 @@ heavy_tile_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
                         level(s4);
                         level(s4 >> 1);
                     }
+                    uint32_t pos[kR];  // entries of the ROW < x
+                    bool hit[kR];
+                    bool any = false;
 #pragma unroll
                     for (int r = 0; r < kR; ++r) {
-                        const uint32_t at_lane = 64u * r + (uint32_t)lane;
-                        const bool live = at_lane < rest;
+                        const bool live = 64u * r + (uint32_t)lane < rest;
                         const uint32_t jb = (qa[r] + 4u - tile_lds) >> 2;  // tile entries < x
-                        uint32_t pos = jb;                                   // entries of the ROW < x
-                        bool hit;
-                        if (m == 1u) {  // (workgroup-uniform) the tile is the row
-                            hit = live && *reinterpret_cast<const lds_u32 *>((uintptr_t)(qa[r] + 4u)) == x[r];
+                        if (!kSampled) {  // the tile is the row
+                            pos[r] = jb;
+                            hit[r] = live && *reinterpret_cast<const lds_u32 *>((uintptr_t)(qa[r] + 4u)) == x[r];
                         } else {  // x can only be in block jb: its entries below the block's last one, in global memory
                             const uint32_t lo = jb * m;
                             const uint32_t len = (live && jb < nb) ? (n - lo < m ? n - lo : m) : 0u;
@@ -1539,32 +1543,43 @@ heavy_tile_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
                                 const uint32_t p = off + step;
                                 if (p <= len && col32[t_start + lo + p - 1u] < x[r]) off = p;
                             }
-                            pos = lo + off;
-                            hit = off < len && col32[t_start + pos] == x[r];
+                            pos[r] = lo + off;
+                            hit[r] = off < len && col32[t_start + pos[r]] == x[r];
                         }
-                        if (hit) {
+                        any = any || hit[r];
+                    }
+                    if (__ballot(any) == 0) return;
+#pragma unroll
+                    for (int r = 0; r < kR; ++r) {
+                        if (hit[r]) {
                             if (task.mode == 0u) {  // element idx of v's row is in u's row
-                                const uint32_t idx = from + at_lane;
+                                const uint32_t idx = from + 64u * r + (uint32_t)lane;
                                 atomicOr(&acc[item][(idx >> 5) & 3u], 1u << (idx & 31u));
-                            } else if (m == 1u) {  // this element of u's row sits at pos .. of v's row (a run: parallel edges)
-                                uint32_t qb = qa[r] + 4u;
-                                do {
-                                    const uint32_t at = (qb - tile_lds) >> 2;
-                                    atomicOr(&acc[item][(at >> 5) & 3u], 1u << (at & 31u));
-                                    qb += 4u;
-                                } while (*reinterpret_cast<const lds_u32 *>((uintptr_t)qb) == x[r]);  // (the padding ends every run)
-                            } else {
-                                do {
-                                    atomicOr(&acc[item][(pos >> 5) & 3u], 1u << (pos & 31u));
-                                    ++pos;
-                                } while (pos < n && col32[t_start + pos] == x[r]);
+                            } else {  // this element of u's row sits at pos .. of v's row (a run: parallel edges)
+                                uint32_t at = pos[r];
+                                if (!kSampled) {
+                                    do {
+                                        atomicOr(&acc[item][(at >> 5) & 3u], 1u << (at & 31u));
+                                        ++at;
+                                    } while (tile[at] == x[r]);  // (the padding ends every run)
+                                } else {
+                                    do {
+                                        atomicOr(&acc[item][(at >> 5) & 3u], 1u << (at & 31u));
+                                        ++at;
+                                    } while (at < n && col32[t_start + at] == x[r]);
+                                }
                             }
                         }
                     }
                 };
-                if (rest <= 64u) search(std::integral_constant<int, 1>{});
-                else if (rest <= 128u) search(std::integral_constant<int, 2>{});
-                else search(std::integral_constant<int, 4>{});
+                if (m == 1u) {  // (workgroup-uniform)
+                    if (rest <= 64u) search(std::integral_constant<int, 1>{}, std::false_type{});
+                    else if (rest <= 128u) search(std::integral_constant<int, 2>{}, std::false_type{});
+                    else search(std::integral_constant<int, 4>{}, std::false_type{});
+                } else {
+                    if (rest <= 128u) search(std::integral_constant<int, 2>{}, std::true_type{});
+                    else search(std::integral_constant<int, 4>{}, std::true_type{});
+                }
             }
             TRW_LAP(3);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

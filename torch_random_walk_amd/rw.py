@@ -76,11 +76,12 @@ def prepare(row_ptr, col_idx, biased=True, uniform=False, marks=True):
     """Build now what the GPU walks derive from ``(row_ptr, col_idx)`` alone and keep it for every later
     ``walk`` over the same tensors (no reference counterpart: the reference re-reads the int64 CSR on each call).
 
-    ``walk`` does this by itself -- the first call over a graph prepares what one call is worth, the second
-    node2vec call adds the full neighbourhood masks -- so ``prepare`` is only a way to pay up front:
-    ``biased``: edge table + 32-byte fat entries (node2vec walks); ``marks``: with the neighbourhood masks of rows
-    up to 256 entries (about 3x the time, 35 % faster walks), ``marks="full"``: up to 1024 entries (about 5x the
-    time, another 10 %: for graphs walked a dozen times or more); ``uniform``: 16-byte fat entries for ``p == q == 1``.
+    ``walk`` does this by itself -- the first call over a graph prepares what one call is worth, later node2vec
+    calls add the neighbourhood masks of longer rows once enough steps have been made -- so ``prepare`` is only a way
+    to pay up front: ``biased``: edge set + 32-byte fat entries (node2vec walks); ``marks``: with the neighbourhood
+    masks of rows up to 256 entries (about 1.5x the time, 45 % faster walks), ``marks="full"``: up to 1024 entries
+    (about 2x the time, another 20 %); ``uniform``: 16-byte fat entries for ``p == q == 1``.  (R-MAT 10M/110M: 36 / 55 /
+    72 ms to prepare, 82 / 45 / 37 ms per 8e8-step walk; 56 / 64 / 64 bytes per edge.)
     Valid while the two tensors are alive and not written to (an in-place write re-prepares on the next walk).
     Returns the ``PREP_*`` bits the cached graph holds.
     """
