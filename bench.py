@@ -580,7 +580,8 @@ def main():
         assert torch.equal(out, walks), "counting variant of the kernel produced different walks"
         trials, fetches, tests, probes = (int(x) for x in c)
         counters = dict(trials=trials, candidate_loads=fetches, membership_tests=tests, table_or_bisect_entries=probes,
-                        prepared_what=what, prepared_bytes=int(pbytes))
+                        prepared_what=what, prepared_bytes=int(pbytes),
+                        prepared_bytes_per_edge=round(int(pbytes) / max(1, int(nnz)), 2))
         if family in (4, 5):
             # biased_pool_kernel / biased_mask_kernel, bytes the algorithm as run must move: per walker 8 B target + 8 B row32 pair; per
             # column 8 B stored; 32 B per fat entry gathered (every accepted offset, plus candidates the table is

@@ -105,6 +105,33 @@ def test_workspace_bytes():
     assert g(10_000_000, 110_000_000, 2 | 4 | 8) < 64 * 110_000_000   # ... on the headline graph too
 
 
+def test_prepared_graph_regions_are_disjoint_and_inside_the_blob():
+    """trw_prepare_csr_region (a host function: the layout depends on the shapes alone): the parts of a prepared graph
+    lie inside trw_prepare_csr_bytes, in order, without overlap; parts a `what` does not have report 0 bytes."""
+    import ctypes
+    from torch_random_walk_amd import _native
+    lib = _native.cabi()
+    for n, nnz in ((10, 20), (100_000, 1_100_000), (10_000_000, 110_000_000), (111_000_000, 1_711_000_000)):
+        for what in (0, 1, 2, 3, 6, 14, 15):
+            total = lib.trw_prepare_csr_bytes(n, nnz, what)
+            spans = {}
+            for which in range(7):
+                off, size = ctypes.c_size_t(), ctypes.c_size_t()
+                assert lib.trw_prepare_csr_region(n, nnz, what, which, ctypes.byref(off), ctypes.byref(size)) == 0
+                spans[which] = (off.value, size.value)
+                assert off.value + size.value <= total
+            assert spans[0] == (0, 256) and spans[1][1] == 4 * (n + 1) and spans[2][1] == 4 * nnz
+            assert (spans[3][1] == 16 * nnz) == bool(what & 1)
+            assert (spans[5][1] == 32 * nnz) == bool(what & 14) and (spans[4][1] > 0) == bool(what & 14)
+            assert (spans[6][1] > 0) == bool(what & 12)
+            live = sorted(v for v in spans.values() if v[1])
+            assert all(a[0] + a[1] <= b[0] for a, b in zip(live, live[1:])), (n, nnz, what, live)
+            if what & 14:
+                assert 16 * nnz <= spans[4][1] <= 24 * nnz + 8192        # the edge set: 2.5 places of 8 bytes per edge
+    off, size = ctypes.c_size_t(), ctypes.c_size_t()
+    assert lib.trw_prepare_csr_region(10, 20, 2, 99, ctypes.byref(off), ctypes.byref(size)) == -1
+
+
 def test_argument_errors_return_codes_without_touching_the_gpu():
     from torch_random_walk_amd import _native
     L = _native.cabi()
