@@ -421,6 +421,65 @@ def test_tile_pass_masks_equal_the_wave_per_entry_pass_and_numpy(rw, what, monke
         assert tiled[e, 3] == want_rpos, (e, u, v, tiled[e, 3], want_rpos)
 
 
+def test_tile_pass_at_every_boundary_of_its_layout(rw):
+    """Rows of exactly the lengths at which the marking passes change their ways -- 8 | 9 (the owning thread / the tile pass),
+    32 | 33, 63..65 (one group of lanes / two), 127..129 (exact mask / filter), 255..257 and 1 023..1 025 (the caps),
+    8 190..8 193 (a row that fits the tile whole / one that keeps every second entry in it), 16 384 and 20 000 (every third)
+    -- each pointing at each: every (length of u's row, length of v's row) pair occurs as an entry, in both orders.  The 32
+    bytes of sampled entries against numpy, for both cap levels."""
+    from torch_random_walk_amd import _native
+    L = _native.cabi()
+    rng = np.random.default_rng(11)
+    lens = [8, 9, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1023, 1024, 1025, 8190, 8191, 8192, 8193, 16384, 20000]
+    k = len(lens)
+    n = 30000
+    rows = []
+    for i, ln in enumerate(lens):                       # node i: edges to all k special nodes, the rest from a shared pool
+        rest = rng.choice(np.arange(k, n), ln - k, replace=False) if ln > k else np.empty(0, np.int64)
+        row = np.concatenate([np.arange(k)[:min(k, ln)], rest])
+        if ln > 300:                                    # parallel edges here and there
+            row[-3:] = row[-4]
+        rows.append(np.sort(row))
+    src = [np.full(r.size, i) for i, r in enumerate(rows)] + [np.arange(k, n)]
+    dst = rows + [(np.arange(k, n) + 1) % n]            # the other nodes: a ring (no dead ends)
+    src, dst = np.concatenate(src), np.concatenate(dst)
+    order = np.lexsort((dst, src))
+    src, dst = src[order], dst[order]
+    rp = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(src, minlength=n), out=rp[1:])
+    ci = dst.astype(np.int64)
+    nnz = len(ci)
+    deg = np.diff(rp)
+    assert sorted(deg[:k].tolist()) == sorted(lens)
+    d_rp, d_ci = _dev(rp, ci)
+    special = np.nonzero((src < k) & (ci < k))[0]       # the k x k entries between the special nodes (those of length < k aside)
+    assert special.size >= (k - 2) * k
+    for what, cap in ((6, 256), (14, 1024)):
+        ext = _prepared_ext32(L, d_rp, d_ci, n, nnz, what)
+        for e in special:
+            u, v = src[e], ci[e]
+            row_u, row_v = ci[rp[u]:rp[u + 1]], ci[rp[v]:rp[v + 1]]
+            assert ext[e, 0] == v and ext[e, 1] == rp[v] and (ext[e, 2] & 0x7FFFFFFF) == deg[v]
+            at = np.nonzero(row_v == u)[0]
+            want_rpos = 0 if at.size == 0 else ((at.size << 28) | int(at[0]) if at.size <= 15 else 1)
+            assert ext[e, 3] == want_rpos, (what, u, v, ext[e, 3], want_rpos)
+            if min(deg[u], deg[v]) <= cap:
+                bits = np.zeros(128, dtype=bool)
+                np.logical_or.at(bits, np.nonzero(np.isin(row_v, row_u))[0] % 128, True)
+                want = np.packbits(bits, bitorder="little").view(np.uint32)
+                assert (ext[e, 4:] == want).all(), (what, int(deg[u]), int(deg[v]), ext[e, 4:], want)
+                assert bool(ext[e, 2] >> 31) == (deg[v] > 128)
+            else:                                       # beyond the cap: all ones, "ask the edge set"
+                assert (ext[e, 4:] == 0xFFFFFFFF).all() and bool(ext[e, 2] >> 31)
+    # and the walk over it agrees with the oracle (start nodes among the special ones: hub -> hub steps every time)
+    tg = rng.integers(0, k, 1000)
+    ref = O.walk(rp, ci, tg, 0.25, 4.0, 8, 5, rng_mode=O.RNG_WALKER)
+    rw.clear_cache()
+    assert rw.prepare(d_rp, d_ci, marks="full") & rw.PREP_MARKS_FULL
+    got = rw.walk_ex(d_rp, d_ci, torch.as_tensor(tg).to(DEV), 0.25, 4.0, 8, 5, rng_mode=rw.RNG_WALKER)
+    assert (got.cpu().numpy() == ref).all()
+
+
 def test_prepared_edge_list_is_cached_per_padding_id_and_invalidated_by_writes(rw):
     from torch_rw import utils
     rng = np.random.default_rng(3)
