@@ -1363,7 +1363,7 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 // m-th entry -- the last of each block of m = ceil(n / (kCap-1)) --, the bisection in LDS finds the block and the last
 // log2(m) levels read the block in global memory (L2 hits: 1 level for a row of 8-16 K entries, 5 for the longest).
 template <uint32_t kCap, int kThreads>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kThreads, 8)  // (64 vector registers: four workgroups of 8 waves per CU)
 heavy_tile_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32, u32x4_a16 *__restrict__ ext,
                   const HeavyItem *__restrict__ items, const TileTask *__restrict__ tasks, uint32_t task_room,
                   const uint32_t *__restrict__ in_count, const uint32_t *__restrict__ in_off, uint32_t inline_cap,
@@ -1373,10 +1373,17 @@ heavy_tile_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
     constexpr uint32_t kPerWave = (kTaskEntries > kTaskItems ? kTaskEntries : kTaskItems) / kWaves;  // items of a task per wave
     constexpr int kCountSlot = kStTaskCount, kNextSlot = kStTaskNext;
     static_assert(kPerWave <= 64 && (kCap & (kCap - 1)) == 0, "one lane per item; power-of-two tile");
-    constexpr uint32_t kHead = kWaves * kPerWave * 4 + 4;  // words in front of the tile: the waves' masks, `grabbed`
+    static_assert((kPerWave & (kPerWave - 1)) == 0, "the items of a wave: a power of two (their prefix table is bisected)");
+    // words in front of the tile, per wave: its items' masks (4 each), where their elements start in the wave's flat
+    // numbering (+ the total), and where their rows start in col32; then `grabbed`
+    constexpr uint32_t kWaveWords = kPerWave * 6 + 4;
+    constexpr uint32_t kHead = kWaves * kWaveWords + 4;
     __shared__ uint32_t lds[kHead + kCap];
     uint32_t *const tile = lds + kHead;
-    uint32_t(*const acc)[4] = reinterpret_cast<uint32_t(*)[4]>(lds + (threadIdx.x >> 6) * kPerWave * 4);  // this wave's items' masks
+    uint32_t *const wave_lds = lds + (threadIdx.x >> 6) * kWaveWords;
+    uint32_t(*const acc)[4] = reinterpret_cast<uint32_t(*)[4]>(wave_lds);  // this wave's items' masks
+    uint32_t *const pfx = wave_lds + kPerWave * 4;                         // pfx[j]: first flat element of item j; pfx[kPerWave]: all
+    uint32_t *const row_at = pfx + kPerWave + 1;                           // row_at[j]: where item j's (shorter) row starts
     uint32_t &grabbed = lds[kHead - 4];
     // the tile as an LDS byte address (the low half of its flat address): the bisection below computes addresses itself
     const uint32_t tile_lds = (uint32_t)reinterpret_cast<uintptr_t>(tile);
@@ -1462,52 +1469,77 @@ heavy_tile_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
                 if (todo == 0) continue;
             }
             TRW_LAP(2);
-            if (lane < (int)kPerWave) acc[lane][0] = acc[lane][1] = acc[lane][2] = acc[lane][3] = 0u;
-            // the wave's (item, 256 elements) pieces, one after the other; the next piece's elements are on their way
-            // while this one's are searched.  Buffer loads: lanes beyond the row's end read 0 (no exec-mask region
-            // per load), and are kept out where a hit is looked at.
-            uint64_t left = todo;
-            int src = left ? __builtin_ctzll(left) : -1;
-            uint32_t base = 0;
-            uint32_t xn[4];
-            auto fetch = [&](int item, uint32_t from) {
-                const uint32_t i_start = __builtin_amdgcn_readlane(s_start, item), i_len = __builtin_amdgcn_readlane(s_len, item);
-                const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(col32 + i_start + from), 0,
-                                                                    (int)((i_len - from) * 4u), 0x00020000);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) xn[r] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (lane + 64 * r) * 4, 0, 0);
-            };
-            if (src >= 0) fetch(src, 0u);
-            while (src >= 0) {
-                const int item = src;
-                const uint32_t from = base;
-                const uint32_t i_len = __builtin_amdgcn_readlane(s_len, item);
-                uint32_t x[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) x[r] = xn[r];
-                base += 256u;
-                if (base >= i_len) {
-                    left &= left - 1;
-                    src = left ? __builtin_ctzll(left) : -1;
-                    base = 0;
+            // The elements of the wave's items -- the entries of their shorter rows -- in ONE flat numbering, 256 of them
+            // (four per lane) at a time: a lane finds the item its element belongs to in the wave's prefix table (sixteen
+            // entries of LDS: four levels) and the element itself at row_at[item] + offset.  (Until late in round 4 the wave
+            // went item by item, 256 elements of ONE item at a time: a piece was 1.4 groups of 64 on average and carried
+            // ~115 issue slots of cursor, buffer descriptor, dispatch and hit check for the ~50 its levels need; the kernel
+            // issued three times the instructions of its bisections.)  The next 256 are on their way while these are searched.
+            const uint32_t len_j = mine ? s_len : 0u;
+            uint32_t total;
+            const uint32_t first_j = wave_prefix_excl(len_j, lane, total);
+            if (lane < (int)kPerWave) {
+                acc[lane][0] = acc[lane][1] = acc[lane][2] = acc[lane][3] = 0u;
+                pfx[lane] = first_j;   // (an item without elements shares its number with the next one: the search below
+                row_at[lane] = s_start;  // takes the LAST item that starts at or before the element)
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const bool odd_levels = (__builtin_clz(top4) & 1) != 0;  // top4 = 2^k bytes: k - 1 levels, odd iff k is even iff clz = 31 - k is odd
+            uint32_t xn[4], jn[4];
+            int cur = 0;  // (wave-uniform) the item that holds the first element of the batch being fetched
+            auto fetch = [&](uint32_t f0) {
+                uint32_t c_first = __builtin_amdgcn_readlane(first_j, cur), c_len = __builtin_amdgcn_readlane(len_j, cur);
+                while (c_first + c_len <= f0) {  // (f0 < total: there is such an item)
+                    ++cur;
+                    c_first = __builtin_amdgcn_readlane(first_j, cur);
+                    c_len = __builtin_amdgcn_readlane(len_j, cur);
                 }
-                if (src >= 0) fetch(src, base);
-                const uint32_t rest = i_len - from;  // (wave-uniform)
-                const bool odd_levels = (__builtin_clz(top4) & 1) != 0;  // top4 = 2^k bytes: k - 1 levels, odd iff k is even iff clz = 31 - k is odd
-                // The kernel is bound by the NUMBER of vector instructions (4 cycles each on a SIMD, whatever they
-                // are: 82 % VALU-busy when a level took five): a level of the bisection is add, ds_read, compare,
-                // select, and a piece shorter than 256 elements searches only the 64-element groups it has.
-                // `qa` = LDS address of the last tile entry known to be < x (tile[-1] to start with).
-                // (kSampled: the tile holds every m-th entry of the row, the block is finished in global memory.  The
-                // two forms are separate code -- the common one has no branch but "did any lane hit", a hit being rare.)
+                const uint32_t last = f0 + 256u < total ? f0 + 255u : total - 1u;
+                if (last < c_first + c_len) {  // the whole batch is one item's (most elements belong to long rows): no search
+                    const uint32_t *const row = col32 + __builtin_amdgcn_readlane(s_start, cur) + (f0 - c_first);
+                    const uint32_t span = last - f0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const uint32_t o = 64u * r + (uint32_t)lane;
+                        xn[r] = row[o < span ? o : span];  // (a lane beyond the end reads the last element again)
+                        jn[r] = (uint32_t)cur;
+                    }
+                    return;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    uint32_t f = f0 + 64u * r + (uint32_t)lane;
+                    f = f < total ? f : total - 1u;  // (a lane beyond the end reads the last element again: no exec-mask region)
+                    uint32_t j = 0;
+#pragma unroll
+                    for (uint32_t step = kPerWave >> 1; step; step >>= 1) j = pfx[j + step] <= f ? j + step : j;
+                    xn[r] = col32[row_at[j] + (f - pfx[j])];
+                    jn[r] = j;
+                }
+            };
+            if (total) fetch(0u);
+            for (uint32_t f0 = 0; f0 < total; f0 += 256u) {
+                uint32_t x[4], item[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    x[r] = xn[r];
+                    item[r] = jn[r];
+                }
+                if (f0 + 256u < total) fetch(f0 + 256u);
+                const uint32_t rest = total - f0;  // (wave-uniform)
+                // A level of the bisection is add, ds_read, compare, select; `qa` = LDS address of the last tile entry
+                // known to be < x (tile[-1] to start with).  kSampled: the tile holds every m-th entry of the row, the
+                // block is finished in global memory -- separate code: the common form has no branch but "did any lane
+                // hit", a hit being rare.
                 auto search = [&](auto groups, auto sampled_row) {
                     constexpr int kR = decltype(groups)::value;
                     constexpr bool kSampled = decltype(sampled_row)::value;
                     uint32_t qa[kR];
 #pragma unroll
                     for (int r = 0; r < kR; ++r) qa[r] = tile_lds - 4u;
-                    // (two levels per trip: with one group the loop's own shift, compare and branch were as many issue
-                    // slots as the level; a tile has six levels at least, `odd_levels` says whether one goes first)
+                    // (two levels per trip; a tile has six levels at least, `odd_levels` says whether one goes first)
                     auto level = [&](uint32_t s4) {
 #pragma unroll
                         for (int r = 0; r < kR; ++r) {
@@ -1552,19 +1584,20 @@ heavy_tile_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
 #pragma unroll
                     for (int r = 0; r < kR; ++r) {
                         if (hit[r]) {
+                            uint32_t *const am = acc[item[r]];
                             if (task.mode == 0u) {  // element idx of v's row is in u's row
-                                const uint32_t idx = from + 64u * r + (uint32_t)lane;
-                                atomicOr(&acc[item][(idx >> 5) & 3u], 1u << (idx & 31u));
+                                const uint32_t idx = f0 + 64u * r + (uint32_t)lane - pfx[item[r]];
+                                atomicOr(&am[(idx >> 5) & 3u], 1u << (idx & 31u));
                             } else {  // this element of u's row sits at pos .. of v's row (a run: parallel edges)
                                 uint32_t at = pos[r];
                                 if (!kSampled) {
                                     do {
-                                        atomicOr(&acc[item][(at >> 5) & 3u], 1u << (at & 31u));
+                                        atomicOr(&am[(at >> 5) & 3u], 1u << (at & 31u));
                                         ++at;
                                     } while (tile[at] == x[r]);  // (the padding ends every run)
                                 } else {
                                     do {
-                                        atomicOr(&acc[item][(at >> 5) & 3u], 1u << (at & 31u));
+                                        atomicOr(&am[(at >> 5) & 3u], 1u << (at & 31u));
                                         ++at;
                                     } while (at < n && col32[t_start + at] == x[r]);
                                 }
