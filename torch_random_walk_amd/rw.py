@@ -80,8 +80,8 @@ def prepare(row_ptr, col_idx, biased=True, uniform=False, marks=True):
     calls add the neighbourhood masks of longer rows once enough steps have been made -- so ``prepare`` is only a way
     to pay up front: ``biased``: edge set + 32-byte fat entries (node2vec walks); ``marks``: with the neighbourhood
     masks of rows up to 256 entries (about 1.5x the time, 45 % faster walks), ``marks="full"``: up to 1024 entries
-    (about 2x the time, another 20 %); ``uniform``: 16-byte fat entries for ``p == q == 1``.  (R-MAT 10M/110M: 36 / 55 /
-    72 ms to prepare, 82 / 45 / 37 ms per 8e8-step walk; 56 / 64 / 64 bytes per edge.)
+    (about 2x the time, another 20 %); ``uniform``: 16-byte fat entries for ``p == q == 1``.  (R-MAT 10M/110M: 38 / 53 /
+    68 ms to prepare, 80 / 45 / 37 ms per 8e8-step walk; 56 / 64 / 64 bytes per edge.)
     Valid while the two tensors are alive and not written to (an in-place write re-prepares on the next walk).
     Returns the ``PREP_*`` bits the cached graph holds.
     """
