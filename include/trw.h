@@ -456,6 +456,11 @@ int trw_profile_last(double *prepare_ms, double *walk_ms, double *finish_ms);
 int trw_profile_prepare_last(double *prepare_ms);
 int trw_walk_counters(const void *workspace, void *hip_stream, uint64_t counters[4]);
 
+/* How often a window-builder call was handed a side lane (a second stream for its negatives, beside the main
+ * kernel) since the library was loaded: counts[0] = all calls that got one, counts[1] = those whose stream was being
+ * captured into a HIP graph at the time (the lane joins the capture through its fork event).  For tests. */
+void trw_side_lane_counts(int64_t counts[2]);
+
 /* Self-test of the device arithmetic the walk kernels are built on, over EVERY divisor a row length can be
  * (1 .. 2^31-1): the exact reciprocal of the walker pools' one-correction `draw % degree` (the stand-in for the
  * reference's `rand() % (row_end - row_start)`, csrc/cpu/rw_cpu.cpp:20), the two-correction form of the other

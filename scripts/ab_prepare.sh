@@ -4,10 +4,10 @@
 # times of the default one.
 set -o pipefail
 O=gpurun_out/prep; mkdir -p $O; rm -f $O/ab.txt
-timeout -k 10 600 python -m pytest tests/test_gpu_prepared.py -x -q -k "tile_pass or c_abi" > $O/pytest.log 2>&1; rc=$?; tail -3 $O/pytest.log
+timeout -k 10 600 python -m pytest tests/test_gpu_prepared.py -x -q -k "tile_pass or c_abi or dropped or unsorted_rows_with_marks" > $O/pytest.log 2>&1; rc=$?; tail -3 $O/pytest.log
 [ $rc -eq 0 ] || exit $rc
 for what in ${WHATS:-6 14}; do
-  for v in ${VARIANTS:-TRW_HEAVY_TILE=0 TRW_HEAVY_TILE=1}; do
+  for v in ${VARIANTS:-TRW_COMMON_MAX=8}; do
     timeout -k 10 300 python scripts/tune_biased.py --what $what --runs ${RUNS:-3} --env ${v//,/ } --tag "what=$what $v" 2>&1 | grep -v amdgpu.ids | tee -a $O/ab.txt || exit 1
   done
 done

@@ -368,30 +368,37 @@ def _skewed_graph(n, m, seed, hubs=()):
     return row_ptr, dst.astype(np.int64)
 
 
+def _prepared_header(L, d_rp, d_ci, n, nnz, what):
+    """The 256-byte header of a freshly prepared graph as 32 int64 slots."""
+    pb = L.trw_prepare_csr_bytes(n, nnz, what)
+    blob = torch.empty(pb, dtype=torch.uint8, device=DEV)
+    stream = torch.cuda.current_stream().cuda_stream
+    assert L.trw_prepare_csr_hip(d_rp.data_ptr(), n, d_ci.data_ptr(), nnz, what, blob.data_ptr(), pb, stream) == 0
+    torch.cuda.synchronize()
+    return blob[:256].cpu().numpy().view(np.int64)
+
+
 @pytest.mark.parametrize("what", [6, 14])
-def test_tile_pass_masks_equal_the_wave_per_entry_pass_and_numpy(rw, what, monkeypatch):
+def test_tile_pass_masks_equal_numpy(rw, what):
     """The neighbourhood masks of the entries whose shorter row is longer than 32: worked out by the tile pass (the
-    longer row in LDS, in-lists for the rows entered from shorter ones), by round 3's wave-per-entry pass
-    (TRW_HEAVY_TILE=0) and by numpy -- the same 32 bytes for every entry.  The graph has rows on both sides of every
-    threshold: 32, 128 (exact mask / filter), 256 / 1024 (the caps), and hubs beyond the 16 384-entry tile."""
+    longer row in LDS behind a Bloom filter, in-lists for the rows entered from shorter ones) and by numpy -- the same 32
+    bytes for every sampled entry.  The graph has rows on both sides of every threshold: 8 (the owning thread / the tile
+    pass), 128 (exact mask / filter), 255 (one-wave tiles / workgroup tiles), 256 / 1024 (the caps), and hubs beyond the
+    4 096-entry tile."""
     from torch_random_walk_amd import _native
     L = _native.cabi()
     n = 40000
     rp, ci = _skewed_graph(n, 500_000, 5, hubs=((3, 17000), (11, 20000), (40, 5000), (41, 1100), (77, 300)))
     nnz = len(ci)
     d_rp, d_ci = _dev(rp, ci)
-    monkeypatch.setenv("TRW_HEAVY_TILE", "1")
     tiled = _prepared_ext32(L, d_rp, d_ci, n, nnz, what)
-    monkeypatch.setenv("TRW_HEAVY_TILE", "0")
-    queued = _prepared_ext32(L, d_rp, d_ci, n, nnz, what)
-    assert (tiled == queued).all(), np.nonzero((tiled != queued).any(1))[0][:10]
     # numpy: entries whose shorter row has 33 .. cap entries carry the exact intersection (modulo 128 positions)
     cap = 1024 if what & 8 else 256
     deg = np.diff(rp)
     src = np.repeat(np.arange(n), deg)
     rng = np.random.default_rng(1)
     heavy = np.nonzero((np.minimum(deg[src], deg[ci]) > 32) & (np.minimum(deg[src], deg[ci]) <= cap))[0]
-    assert 1000 < heavy.size < nnz // 2       # (the queue of the wave-per-entry pass has room for nnz/2 entries)
+    assert heavy.size > 1000
     a_side = heavy[deg[src[heavy]] > deg[ci[heavy]]]
     b_side = heavy[deg[src[heavy]] <= deg[ci[heavy]]]
     assert a_side.size > 100 and b_side.size > 100
@@ -404,8 +411,9 @@ def test_tile_pass_masks_equal_the_wave_per_entry_pass_and_numpy(rw, what, monke
         assert (tiled[e, 4:] == want).all(), (e, u, v, deg[u], deg[v])
         assert tiled[e, 0] == v and tiled[e, 1] == rp[v] and (tiled[e, 2] & 0x7FFFFFFF) == deg[v]
         assert bool(tiled[e, 2] >> 31) == (deg[v] > 128)
-    # the entries the owning thread marks itself (shorter row <= 32: probes of the edge set, a common neighbour's
-    # position by bisection) and rpos -- where u sits in v's row: multiplicity << 28 | first offset, 1 = "too wide", 0 = absent
+    # the entries of short rows (the owning thread's: rows of u of up to 8 entries -- compared in registers or asked through
+    # the edge set -- and the short rows of v that ride along in u's tile) and rpos -- where u sits in v's row:
+    # multiplicity << 28 | first offset, 1 = "too wide", 0 = absent
     light = np.nonzero(np.minimum(deg[src], deg[ci]) <= 32)[0]
     recip = light[np.isin(ci[light] * n + src[light], src * n + ci)]          # entries whose reverse edge exists
     assert recip.size > 200
@@ -419,6 +427,112 @@ def test_tile_pass_masks_equal_the_wave_per_entry_pass_and_numpy(rw, what, monke
         at = np.nonzero(row_v == u)[0]
         want_rpos = 0 if at.size == 0 else ((at.size << 28) | int(at[0]) if at.size <= 15 else 1)
         assert tiled[e, 3] == want_rpos, (e, u, v, tiled[e, 3], want_rpos)
+
+
+def _numpy_entry(rp, ci, src, e):
+    """What the 32-byte entry e must hold: (v, start(v), deg(v), rpos, 128-bit mask as 4 words)."""
+    u, v = src[e], ci[e]
+    row_u, row_v = ci[rp[u]:rp[u + 1]], ci[rp[v]:rp[v + 1]]
+    bits = np.zeros(128, dtype=bool)
+    np.logical_or.at(bits, np.nonzero(np.isin(row_v, row_u))[0] % 128, True)
+    at = np.nonzero(row_v == u)[0]
+    rpos = 0 if at.size == 0 else ((at.size << 28) | int(at[0]) if at.size <= 15 else 1)
+    return v, rp[v], row_v.size, rpos, np.packbits(bits, bitorder="little").view(np.uint32)
+
+
+def test_every_edge_from_a_shorter_row_to_a_longer_one_nothing_dropped(rw):
+    """VERDICT r04 #6 / ADVICE r04: the in-lists of the tile pass hold the entries u -> v whose row of u is the shorter
+    one.  Round 4 had room for 3/5 of the entries and silently left the rest their all-ones masks; on THIS graph -- every
+    edge points from a row of 9 .. 60 entries at a row of 100 .. 700 -- every entry is such an item.  The arrays are
+    sized for the worst case now: the header counts nnz items and 0 dropped, no entry whose shorter row is within the
+    cap keeps an all-ones mask, sampled entries equal numpy, and the walk over it equals the oracle's."""
+    from torch_random_walk_amd import _native
+    L = _native.cabi()
+    rng = np.random.default_rng(21)
+    n_low, n_hub = 6000, 60
+    n = n_low + n_hub
+    rows = []
+    for u in range(n_low):                                  # short rows: only hubs in them
+        rows.append(np.sort(rng.choice(np.arange(n_low, n), rng.integers(9, 61), replace=True)))
+    for h in range(n_hub):                                  # long rows: short-row nodes and other hubs, LONGER than any short row
+        k = int(rng.integers(100, 701))
+        rows.append(np.sort(np.concatenate([rng.choice(n_low, k - 5), rng.choice(np.arange(n_low, n), 5)])))
+    deg = np.array([r.size for r in rows])
+    rp = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(deg, out=rp[1:])
+    ci = np.concatenate(rows).astype(np.int64)
+    nnz = len(ci)
+    src = np.repeat(np.arange(n), deg)
+    low_to_hub = np.nonzero(src < n_low)[0]
+    assert (deg[src[low_to_hub]] < deg[ci[low_to_hub]]).all() and low_to_hub.size > 0.85 * nnz
+    d_rp, d_ci = _dev(rp, ci)
+    for what in (6, 14):
+        hdr = _prepared_header(L, d_rp, d_ci, n, nnz, what)
+        items_expected = int(((deg[src] > 8) & (deg[src] <= (1024 if what & 8 else 256)) &
+                              ((deg[src] < deg[ci]) | ((deg[src] == deg[ci]) & (src >= ci)))).sum())
+        assert hdr[19] == 0, "in-list items or tasks dropped"
+        assert hdr[20] == items_expected and items_expected >= low_to_hub.size
+        ext = _prepared_ext32(L, d_rp, d_ci, n, nnz, what)
+        cap = 1024 if what & 8 else 256
+        within = np.minimum(deg[src], deg[ci]) <= cap
+        # a computed mask of this graph is never all ones (no row holds 128 common neighbours with another's; a hub's
+        # self-loop does, with itself)
+        assert not (ext[within & (src != ci), 4:] == 0xFFFFFFFF).all(axis=1).any()
+        for e in rng.choice(nnz, 1500, replace=False):
+            v, start, dv, rpos, mask = _numpy_entry(rp, ci, src, e)
+            assert ext[e, 0] == v and ext[e, 1] == start and (ext[e, 2] & 0x7FFFFFFF) == dv and ext[e, 3] == rpos
+            if within[e]:
+                assert (ext[e, 4:] == mask).all() and bool(ext[e, 2] >> 31) == (dv > 128), (what, e)
+    tg = rng.integers(0, n, 4000)
+    rw.clear_cache()
+    assert rw.prepare(d_rp, d_ci, marks="full") & rw.PREP_MARKS_FULL
+    got = rw.walk_ex(d_rp, d_ci, torch.as_tensor(tg).to(DEV), 0.25, 4.0, 20, 7, rng_mode=rw.RNG_WALKER)
+    assert (got.cpu().numpy() == O.walk(rp, ci, tg, 0.25, 4.0, 20, 7, rng_mode=O.RNG_WALKER)).all()
+
+
+def test_unsorted_rows_with_marks_write_nothing_outside_the_prepared_blob(rw):
+    """on a graph whose rows are NOT sorted the plan kernel makes no in-list segments -- and round 4's
+    scatter kernel then read its segment offsets from memory nobody had written, an 8-byte store per entry up to 32 GB past
+    the item array.  Rows of 9 .. 300 entries in random order, TRW_PREP_MARKS, the blob poisoned with 0x5A beforehand and
+    fenced by guard regions on both sides: the guards survive, every entry says "ask the edge set" (all ones + filter),
+    and the walk equals the oracle's."""
+    from torch_random_walk_amd import _native
+    L = _native.cabi()
+    rng = np.random.default_rng(4)
+    n = 5000
+    deg = rng.integers(9, 301, n)
+    deg[::7] = rng.integers(1, 9, deg[::7].size)
+    rp = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(deg, out=rp[1:])
+    ci = rng.integers(0, n, rp[-1]).astype(np.int64)        # unsorted rows, parallel edges
+    nnz = len(ci)
+    d_rp, d_ci = _dev(rp, ci)
+    stream = torch.cuda.current_stream().cuda_stream
+    guard = 1 << 20
+    for what in (6, 14):
+        pb = L.trw_prepare_csr_bytes(n, nnz, what)
+        pb_al = (pb + 255) // 256 * 256
+        buf = torch.full((guard + pb_al + guard,), 0x5A, dtype=torch.uint8, device=DEV)
+        blob = buf[guard:guard + pb_al]
+        assert L.trw_prepare_csr_hip(d_rp.data_ptr(), n, d_ci.data_ptr(), nnz, what, blob.data_ptr(), pb, stream) == 0
+        torch.cuda.synchronize()
+        assert bool((buf[:guard] == 0x5A).all()) and bool((buf[guard + pb_al:] == 0x5A).all()), "a write outside the blob"
+        hdr = blob[:256].cpu().numpy().view(np.int64)
+        assert hdr[8] != hdr[9]                              # descents inside rows: not sorted
+        assert hdr[16] == 0 and hdr[21] == 0 and hdr[20] == 0 and hdr[19] == 0      # no tasks, no items
+        off, size = ctypes.c_size_t(), ctypes.c_size_t()
+        assert L.trw_prepare_csr_region(n, nnz, what, 5, ctypes.byref(off), ctypes.byref(size)) == 0
+        ext = blob[off.value:off.value + size.value].cpu().numpy().view(np.uint32).reshape(nnz, 8)
+        assert (ext[:, 4:] == 0xFFFFFFFF).all() and (ext[:, 2] >> 31).all()
+        tg = rng.integers(0, n, 2000)
+        d_tg = torch.as_tensor(tg).to(DEV)
+        out = torch.empty((2000, 13), dtype=torch.int64, device=DEV)
+        wb = L.trw_walk_csr_prepared_workspace_bytes(2000, 12, 0.25, 4.0, 2)
+        ws = torch.empty(wb, dtype=torch.uint8, device=DEV)
+        assert L.trw_walk_csr_prepared_hip(blob.data_ptr(), pb, what, d_rp.data_ptr(), n, d_ci.data_ptr(), nnz,
+                                           d_tg.data_ptr(), 2000, 0, 0.25, 4.0, 12, 3, 2, out.data_ptr(), ws.data_ptr(), wb,
+                                           stream) == 0, L.trw_last_error()
+        assert (out.cpu().numpy() == O.walk(rp, ci, tg, 0.25, 4.0, 12, 3, rng_mode=O.RNG_WALKER)).all()
 
 
 def test_tile_pass_at_every_boundary_of_its_layout(rw):

@@ -432,9 +432,20 @@ def test_gpu_side_stream_lanes_capture_beside_another_thread():
     """the side stream of the window builders is a pool of lanes now -- while one thread captures a
     to_windows call into a HIP graph (its lane's stream is part of that capture until it ends), another thread's
     plain call gets ANOTHER lane: it neither fails with a capture-isolation error nor lands in the first thread's
-    graph, and the graph replays to the same windows afterwards."""
+    graph, and the graph replays to the same windows afterwards.  ADVICE r04: the captured calls really do get a
+    lane (an idle one joins the capture through the fork event), counted by the library."""
+    import ctypes
     import threading
     from torch_rw import rw
+    from torch_random_walk_amd import _native
+    lib = ctypes.CDLL(_native.HIP_LIB_PATH)
+    lib.trw_side_lane_counts.argtypes = [ctypes.POINTER(ctypes.c_int64)]
+    lib.trw_side_lane_counts.restype = None
+
+    def lane_counts():
+        c = (ctypes.c_int64 * 2)()
+        lib.trw_side_lane_counts(c)
+        return int(c[0]), int(c[1])
     n = 3000
     rp, ci = _small_graph(n, 24000, 9, DEV)
     tg = torch.arange(n, device=DEV).repeat(4)
@@ -461,13 +472,19 @@ def test_gpu_side_stream_lanes_capture_beside_another_thread():
         rw.to_windows(walks, 5, n, 5)                   # warm the allocator on the capture stream
     torch.cuda.current_stream().wait_stream(s)
     g = torch.cuda.CUDAGraph()
+    before = lane_counts()
     with torch.cuda.graph(g, capture_error_mode="thread_local"):
         cap = rw.to_windows(walks, 5, n, 5)
         t = threading.Thread(target=plain_call)         # runs while the capture is still open
         t.start()
         t.join()
         cap2 = rw.to_windows(walks, 5, n, 5)            # a second call of the SAME capture reuses the capture's lane
+    after = lane_counts()
     assert not errors, errors
+    # both captured calls forked onto a lane (the graph holds the negatives BESIDE the gather), and so did the
+    # other thread's three plain calls
+    assert after[1] - before[1] == 2, (before, after)
+    assert after[0] - before[0] == 5, (before, after)
     for got in got_other:
         assert all(torch.equal(a, b) for a, b in zip(got, other_ref))
     for _ in range(3):

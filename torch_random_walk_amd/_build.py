@@ -22,7 +22,7 @@ EXT_LIB = os.path.join(HERE, "torch_rw_native" + sysconfig.get_config_var("EXT_S
 
 HIP_SOURCES = [os.path.join(CSRC, "trw_hip.hip"), os.path.join(CSRC, "trw_cpu.cpp")]
 HIP_DEPS = HIP_SOURCES + [os.path.join(CSRC, f) for f in ("glibc_jump.hpp", "trw_kernels_wide.hpp",
-                                                           "trw_kernels_narrow.hpp", "trw_kernels_triples.hpp", "trw_kernels_edgelist.hpp", "trw_kernels_windows.hpp",
+                                                           "trw_kernels_narrow.hpp", "trw_kernels_marks.hpp", "trw_kernels_triples.hpp", "trw_kernels_edgelist.hpp", "trw_kernels_windows.hpp",
                                                            "trw_kernels_wire.hpp")] + [os.path.join(INCLUDE, "trw.h")]
 EXT_SOURCES = [os.path.join(CSRC, "torch_rw_native.cpp")]
 EXT_DEPS = EXT_SOURCES + [os.path.join(INCLUDE, "trw.h")]

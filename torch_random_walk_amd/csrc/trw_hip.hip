@@ -17,6 +17,7 @@
 // decides which of these a call shape gets and where their buffers live in the caller's workspace.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -30,6 +31,7 @@
 #include "glibc_jump.hpp"
 #include "trw_kernels_wide.hpp"
 #include "trw_kernels_narrow.hpp"
+#include "trw_kernels_marks.hpp"
 #include "trw_kernels_triples.hpp"
 #include "trw_kernels_edgelist.hpp"
 #include "trw_kernels_windows.hpp"
@@ -127,9 +129,9 @@ struct PrepLayout {
     bool marks = false;    // ... with the neighbourhood masks worked out for long rows too
     bool marks_full = false;  // ... for rows up to 1024 entries (TRW_PREP_MARKS_FULL) instead of 256
     uint32_t table_blocks = 0;  // the edge set: blocks of four 8-byte keys
-    uint32_t heavy_room = 0, task_room = 0;
+    uint32_t heavy_room = 0, task_room = 0, big_task_room = 0;  // items; tasks of short tile rows / of long ones
     size_t off_row32 = 0, off_col32 = 0, off_ext16 = 0, off_table = 0, off_ext32 = 0, off_heavy = 0, total = 0;
-    size_t off_incount = 0, off_inoff = 0, off_infill = 0, off_tasks = 0;  // the tile pass: per-node in-list counters / segments / fill marks, tasks
+    size_t off_incount = 0, off_inoff = 0, off_infill = 0, off_tasks = 0, off_tasks_big = 0;  // the tile pass: per-node in-list counters / segments / fill marks, tasks
 };
 
 bool graph_fits_narrow(int64_t n_nodes, int64_t nnz)
@@ -174,27 +176,32 @@ PrepLayout make_prep_layout(int64_t n_nodes, int64_t nnz, int32_t what)
             pl.off_ext32 = off;
             off += align_up((size_t)nnz * 32 + 64, 256);
             if (pl.marks) {
-                // Scratch of the marking passes.  Items {entry, source node} of the in-lists (tile pass) or of the queue
-                // (wave-per-entry pass): the entries u -> v whose row of u is the shorter or equal one and longer than the
-                // inline cap -- about half of the entries at most; a pass that runs out of room leaves the rest of them
-                // their all-ones masks.
-                const uint64_t room = (uint64_t)nnz / 5 * 3 + 1024;
+                // Scratch of the marking passes.  Items {entry, source node} of the in-lists: the entries u -> v whose row of
+                // u is the shorter or equal one and longer than the inline cap -- about a third of the entries on a power-law
+                // graph, half on a regular one, ALL of them on a graph whose edges all point from shorter rows to longer
+                // ones.  Room for all of them: nothing is ever dropped (round 4 had room for 3/5 and left the rest their
+                // all-ones masks without a word).
+                const uint64_t room = (uint64_t)nnz + 64;
                 pl.heavy_room = room > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)room;
                 pl.off_heavy = off;
                 off += align_up((size_t)pl.heavy_room * 8, 256);
-                // the tile pass (heavy_tile_kernel): in-list size, segment and fill mark per node, and its 8-byte task
-                // records -- one per 128 entries of a tile row, one per 64 items of an in-list, so two at least per row
-                // longer than the inline cap
+                // the tile pass: in-list size, segment and fill mark per node, and its 8-byte task records
                 pl.off_incount = off;
                 off += align_up((size_t)(n_nodes + 1) * 4, 256);
                 pl.off_inoff = off;
                 off += align_up((size_t)(n_nodes + 1) * 4, 256);
                 pl.off_infill = off;
                 off += align_up((size_t)(n_nodes + 1) * 4, 256);
-                const uint64_t troom = (uint64_t)nnz / 5 + 4096;
+                // Task records (64 entries of the tile row / 64 items of its in-list each), worst case.  Rows of 9 .. 255
+                // entries: at most nnz/64 + nnz/64 + two per such row, of which there are fewer than nnz/9: 0.2535 nnz.
+                // Longer rows: nnz/64 + nnz/64 + two per such row, fewer than nnz/256 of them: 0.0391 nnz.
+                const uint64_t troom = (uint64_t)nnz / 4 + (uint64_t)nnz / 128 + 4096;
                 pl.task_room = troom > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)troom;
                 pl.off_tasks = off;
                 off += align_up((size_t)pl.task_room * 8, 256);
+                pl.big_task_room = (uint32_t)((uint64_t)nnz / 32 + (uint64_t)nnz / 128 + 4096);
+                pl.off_tasks_big = off;
+                off += align_up((size_t)pl.big_task_room * 8, 256);
             }
         }
     }
@@ -507,7 +514,7 @@ int trw_prepare_csr_region(int64_t n_nodes, int64_t nnz, int32_t what, int32_t w
     case TRW_REGION_EXT16: if (pl.ext16) { *offset = pl.off_ext16; *bytes = (size_t)nnz * 16; } break;
     case TRW_REGION_TABLE: if (pl.biased) { *offset = pl.off_table; *bytes = (size_t)pl.table_blocks * 32; } break;
     case TRW_REGION_EXT32: if (pl.biased) { *offset = pl.off_ext32; *bytes = (size_t)nnz * 32; } break;
-    case TRW_REGION_TASKS: if (pl.marks) { *offset = pl.off_tasks; *bytes = (size_t)pl.task_room * 8; } break;
+    case TRW_REGION_TASKS: if (pl.marks) { *offset = pl.off_tasks; *bytes = pl.off_tasks_big + (size_t)pl.big_task_room * 8 - pl.off_tasks; } break;
     default: return fail(TRW_E_ARG, "unknown region");
     }
     return TRW_OK;
@@ -547,52 +554,44 @@ int trw_prepare_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *
             device_fill(table, 0xFFFFFFFFu, (size_t)pl.table_blocks * 32 + 64, stream);
             edge_table_build_kernel<<<stream_grid((nnz + 7) / 8), kBlock, 0, stream>>>(row32, col32, n_nodes, nnz, table,
                                                                                      pl.table_blocks, header);
-            // Rows up to inline_cap are marked by the thread that owns the entry; with TRW_PREP_MARKS longer ones (up
-            // to heavy_cap) go through the wave-per-entry pass.  Measured on R-MAT 10M/110M (prepare ms -> walk ms of
-            // the 8e8-step batch): inline 8: 22 -> 101; inline 32: 36 -> 86; inline 64: 72 -> 72; inline 32 + heavy
-            // 256: 128 -> 58; + heavy 1024: 252 -> 52.5; + heavy 4096: 390 -> 52 with one random table probe per entry
-            // of the shorter row in both passes; the heavy pass bisects the (sorted, L2-resident) long rows instead
-            // since: inline 32 + heavy 256: 107 -> 58; + heavy 1024: 178 -> 52; + heavy 4096: 248 -> 53 (no better).
-            // (With the tile pass behind it the owning thread keeps only the rows up to 8: measured, full prepare, same walk:
-            // inline 32 / 16 / 12 / 8 / 4: 79.7 / 73.6 / 70.7 / 69.4 / 69.6 ms -- a probe of the edge set per entry of the
-            // shorter row costs more than the entry's share of a tile.  Without marks there is no tile pass: 32.)
-            const bool tile_pass = pl.marks && env_long("TRW_HEAVY_TILE", 0, 1, 1) == 1;
-            const uint32_t inline_cap = (uint32_t)env_long("TRW_COMMON_MAX", 0, 4096, tile_pass ? 8 : 32);
+            // The entries and their masks (trw_kernels_marks.hpp).  The owning thread settles the entries of rows of u of up
+            // to 8 entries (32 when no tile pass follows, and then also those whose row of v is that short); the tile pass -- a
+            // Bloom filter in front of the bisection -- everything else whose shorter row has up to 256 / 1 024 entries.
+            // Measured on R-MAT 10M/110M, full prepare: round 4's form (table probes for shorter rows <= 8, every element of
+            // the longer ones bisected into an 8 192-entry tile) 68.1 ms; with the filter and rows of v of any length riding
+            // along in u's tile 55.0 (profiles/r05_prepare_ab.txt).
+            const uint32_t inline_cap = (uint32_t)env_long("TRW_COMMON_MAX", 0, 4096, pl.marks ? 8 : 32);
             const uint32_t heavy_cap =
                 pl.marks ? (uint32_t)env_long("TRW_HEAVY_MAX", 0, 1 << 20, pl.marks_full ? 1024 : 256) : 0u;
-            HeavyItem *heavy = pl.marks ? (HeavyItem *)(ws + pl.off_heavy) : nullptr;
-            // The masks of entries whose shorter row is longer than inline_cap: the tile pass (heavy_tile_kernel: the
-            // longer row in LDS, the shorter rows streamed past it).  TRW_HEAVY_TILE=0: the wave-per-entry pass over
-            // a queue instead (round 3's form: every search a bisection in global memory).
-            const bool tiles = tile_pass && heavy_cap > inline_cap;
+            const bool tiles = pl.marks && heavy_cap > inline_cap;
             uint32_t *in_count = pl.marks ? (uint32_t *)(ws + pl.off_incount) : nullptr;
             uint32_t *in_off = pl.marks ? (uint32_t *)(ws + pl.off_inoff) : nullptr;
             uint32_t *in_fill = pl.marks ? (uint32_t *)(ws + pl.off_infill) : nullptr;
+            u32x4_a16 *ext32 = (u32x4_a16 *)(ws + pl.off_ext32);
             if (tiles) {
                 device_fill(in_count, 0u, align_up((size_t)(n_nodes + 1) * 4, 256), stream);
                 device_fill(in_fill, 0u, align_up((size_t)(n_nodes + 1) * 4, 256), stream);
             }
-            csr_ext32_kernel<<<stream_grid((nnz + 7) / 8), kBlock, 0, stream>>>(
-                row32, col32, n_nodes, nnz, table, pl.table_blocks, inline_cap, heavy_cap, tiles ? 1u : 0u,
-                (u32x4_a16 *)(ws + pl.off_ext32), heavy, pl.heavy_room, in_count, header);
+            entries_kernel<<<stream_grid((nnz + 7) / 8), kBlock, 0, stream>>>(row32, col32, n_nodes, nnz, table, pl.table_blocks,
+                                                                            inline_cap, heavy_cap, tiles ? 1u : 0u, ext32, in_count,
+                                                                            header);
             if (tiles) {
-                TileTask *tasks = (TileTask *)(ws + pl.off_tasks);
-                u32x4_a16 *ext32 = (u32x4_a16 *)(ws + pl.off_ext32);
-                heavy_plan_kernel<<<stream_grid(n_nodes), kBlock, 0, stream>>>(row32, n_nodes, in_count, in_off, tasks,
-                                                                               pl.task_room, pl.heavy_room, inline_cap, header);
-                heavy_scatter_kernel<<<stream_grid(n_nodes), kBlock, 0, stream>>>(row32, col32, n_nodes, inline_cap,
-                                                                                  heavy_cap, in_fill, in_off, heavy);
-                // 8 192 entries of LDS per tile, 8 waves per workgroup, 4 workgroups per CU.  Measured on R-MAT 10M/110M
-                // (full prepare): 16 384 x 8 waves (2 per CU) +8 ms; 8 192 x 4 waves +7; 4 096 x 4 waves +2; tiles of ONE
-                // wave for rows below 1 024 / 2 048 entries next to workgroup tiles for the rest (no barrier for
-                // 98 % of the rows) +6 / +10 -- the workgroup's waves hide each other's latencies better than they
-                // cost each other in barriers.
-                heavy_tile_kernel<8192, 512><<<(unsigned)device_cu_count() * 4, 512, 0, stream>>>(
-                    row32, col32, ext32, heavy, tasks, pl.task_room, in_count, in_off, inline_cap, heavy_cap, header);
+                TileTask *tasks = (TileTask *)(ws + pl.off_tasks), *tasks_big = (TileTask *)(ws + pl.off_tasks_big);
+                HeavyItem *items = (HeavyItem *)(ws + pl.off_heavy);
+                marks_plan_kernel<<<stream_grid(n_nodes), kBlock, 0, stream>>>(row32, n_nodes, in_count, in_off, tasks, pl.task_room,
+                                                                               tasks_big, pl.big_task_room, pl.heavy_room, inline_cap,
+                                                                               header);
+                marks_scatter_kernel<<<stream_grid(n_nodes), kBlock, 0, stream>>>(row32, ext32, n_nodes, inline_cap, heavy_cap, in_fill,
+                                                                                  in_off, items, header);
+                // long tile rows: 4 096 entries of tile + 64 Ki bits of filter + the waves' queues, 35.6 KB, four workgroups
+                // of 8 waves per CU; short ones (up to 255 entries): a workgroup of ONE wave, 4.6 KB
+                tile_bloom_kernel<TRW_TILE_CAP, TRW_BLOOM_WORDS, 512, 8, TRW_BIG_GRAB, kStBigCount, kStBigNext, false>
+                    <<<(unsigned)device_cu_count() * 4, 512, 0, stream>>>(row32, col32, ext32, items, tasks_big, pl.big_task_room,
+                                                                          in_count, in_off, inline_cap, heavy_cap, header);
+                tile_bloom_kernel<256, 256, 64, 8, TRW_SMALL_GRAB, kStTaskCount, kStTaskNext, true>
+                    <<<(unsigned)device_cu_count() * 32, 64, 0, stream>>>(row32, col32, ext32, items, tasks, pl.task_room, in_count,
+                                                                          in_off, inline_cap, heavy_cap, header);
             }
-            if (pl.marks && !tiles)
-                csr_ext32_heavy_kernel<<<(unsigned)(device_cu_count() * 8), kBlock, 0, stream>>>(
-                    row32, col32, (u32x4_a16 *)(ws + pl.off_ext32), heavy, pl.heavy_room, header);
         }
     }
     if (g_prof.on && g_prof.prep[0] && (g_prof.prep[1] || hipEventCreate(&g_prof.prep[1]) == hipSuccess)) {
@@ -605,9 +604,13 @@ int trw_prepare_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *
         long long h[32];
         (void)hipMemcpy(h, prepared, sizeof(h), hipMemcpyDeviceToHost);
         double tot = 0;
-        for (int k = 24; k < 29; ++k) tot += (double)h[k];
-        fprintf(stderr, "[TRW_TILE_CLOCKS] wave cycles: grab %.1f%% examine %.1f%% tile change %.1f%% items %.1f%% write-out %.1f%% (total %.3e over all waves; tasks %lld)\n",
-                100.0 * h[24] / tot, 100.0 * h[25] / tot, 100.0 * h[26] / tot, 100.0 * h[27] / tot, 100.0 * h[28] / tot, tot, h[16]);
+        for (int k = 24; k < 31; ++k) tot += (double)h[k];
+        fprintf(stderr, "[TRW_TILE_CLOCKS] wave cycles: grab %.1f%% examine %.1f%% tile change %.1f%% fetch %.1f%% write-out %.1f%% filter+push %.1f%% search %.1f%% (total %.3e over all waves of the clocked tile kernel; tasks %lld short rows + %lld long rows, in-list items %lld, dropped %lld)\n",
+                100.0 * h[24] / tot, 100.0 * h[25] / tot, 100.0 * h[26] / tot, 100.0 * h[27] / tot, 100.0 * h[28] / tot, 100.0 * h[29] / tot, 100.0 * h[30] / tot, tot, h[16], h[21], h[20], h[19]);
+        unsigned long long d[16] = {0};
+        (void)hipMemcpyFromSymbol(d, HIP_SYMBOL(g_tile_dbg), sizeof(d));
+        fprintf(stderr, "[TRW_TILE_CLOCKS] searches: whole-row tiles %llu (%llu survivors, %.0f cycles each), sampled tiles %llu (%llu survivors, %.0f cycles each); elements against whole-row tiles %.3e, against sampled ones %.3e; batches %.3e in %.3e wave-tasks\n",
+                d[0], d[2], d[0] ? (double)d[4] / d[0] : 0.0, d[1], d[3], d[1] ? (double)d[5] / d[1] : 0.0, (double)d[6], (double)d[7], (double)d[8], (double)d[9]);
     }
 #endif
 #ifdef TRW_PREP_COUNT
@@ -1219,8 +1222,10 @@ int trw_walk_edge_list_hip(const int64_t *edges, int64_t n_edges, const int64_t 
 // side_mark() to side_join(), so two host threads never share one.  A stream that a capture has pulled in stays in that
 // capture until it ends -- so a lane is only handed to a call whose own stream is in the SAME capture state (both not
 // capturing, or both in the capture with the same id): a thread that is not capturing never launches into somebody
-// else's graph.  A capturing call that finds no lane of its own capture and no idle one stays in line (the work is
-// queued on the caller's stream: same result, no overlap) rather than create a stream in the middle of a capture.
+// else's graph.  A capturing call takes a lane of its own capture or an idle one that is in no capture (it enters the
+// caller's capture through the fork event and leaves it with the join: the captured graph holds the fork, a replay
+// runs with the same overlap); only when the pool has neither does it stay in line (the work is queued on the caller's
+// stream: same result, no overlap) rather than create a stream in the middle of a capture.
 struct SideLane {
     hipStream_t stream = nullptr;
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
@@ -1248,6 +1253,8 @@ static unsigned long long capture_id_of(hipStream_t st, bool *capturing)
     return *capturing ? id : 0;
 }
 
+static std::atomic<long long> g_side_acquired{0}, g_side_acquired_capturing{0};  // (trw_side_lane_counts: tests)
+
 static SideLane *side_lane_acquire(hipStream_t main)
 {
     int dev = 0;
@@ -1255,14 +1262,26 @@ static SideLane *side_lane_acquire(hipStream_t main)
     bool main_capturing = false;
     const unsigned long long main_id = capture_id_of(main, &main_capturing);
     std::lock_guard<std::mutex> lock(g_side_mu);
+    // A lane of the caller's own capture first (it is in that graph already), then an idle one that is in no capture: it
+    // joins the caller's through the fork event's hipStreamWaitEvent and leaves it with the join.  Never a lane that
+    // sits in somebody else's capture, and a call that is not capturing never takes a capturing lane.
+    SideLane *idle = nullptr;
     for (SideLane *l : g_side_lanes[dev]) {
         if (l->held) continue;
         bool lane_capturing = false;
         const unsigned long long lane_id = capture_id_of(l->stream, &lane_capturing);
-        if (lane_capturing == main_capturing && lane_id == main_id) {
-            l->held = true;
-            return l;
+        if (lane_capturing) {
+            if (!main_capturing || lane_id != main_id) continue;
+            idle = l;
+            break;
         }
+        if (!idle) idle = l;
+    }
+    if (idle) {
+        idle->held = true;
+        ++g_side_acquired;
+        if (main_capturing) ++g_side_acquired_capturing;
+        return idle;
     }
     if (main_capturing || g_side_lanes[dev].size() >= 16) return nullptr;  // never make a stream inside a capture
     SideLane *l = new SideLane;
@@ -1278,6 +1297,7 @@ static SideLane *side_lane_acquire(hipStream_t main)
     }
     l->held = true;
     g_side_lanes[dev].push_back(l);
+    ++g_side_acquired;
     return l;
 }
 
@@ -1673,6 +1693,13 @@ int trw_to_windows_triples_cbow_hip(const int64_t *walks, int64_t num_walks, int
     e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "kernel launch");
     return TRW_OK;
+}
+
+void trw_side_lane_counts(int64_t counts[2])
+{
+    if (!counts) return;
+    counts[0] = g_side_acquired.load();
+    counts[1] = g_side_acquired_capturing.load();
 }
 
 int trw_profile_enable(int flags)

@@ -13,7 +13,7 @@
 //   uniform_glibc_rows_kernel reference-exact uniform walk; the wave writes its 64 rows one
 //                             aligned 64-byte line at a time through an LDS ring (WaveRows)
 //   edge_table_build_kernel   open-addressing set of the edges {u, v, first offset, multiplicity}
-//   csr_ext32_kernel (+heavy) 32-byte entries for the biased walk: the neighbour's row, where the node
+//   (trw_kernels_marks.hpp)   32-byte entries for the biased walk: the neighbour's row, where the node
 //                             being left sits in it, a 128-bit mask answering is_neighbor per offset
 //   biased_pool_kernel        node2vec rejection sampling on the per-walker stream, the default: a pool of
 //                             walkers per wave in LDS, lanes as executors (sorted rows, prepared entries)
@@ -834,11 +834,10 @@ edge_table_build_kernel(const uint32_t *__restrict__ row32, const uint32_t *__re
 // So a trial is decided from registers, and the graph is read once per STEP: the 32-byte entry of the
 // accepted offset, which carries the next step's row, rpos and mask.
 //
-// Cost of the mask: the common neighbours of u and v, found by walking the shorter of the two rows and
-// probing the edge table for the other (one probe per entry).  Rows up to `inline_cap` are done by the
-// thread that owns the entry; longer ones (up to `heavy_cap`) are queued for csr_ext32_heavy_kernel, one
-// wave per entry; beyond that, and for graphs whose rows are not sorted, the mask is all ones + filter
-// (every band trial asks the table, as the walk did before there were masks).
+// Cost of the mask: the common neighbours of u and v.  Who works them out for which entry -- the thread that owns
+// the entry, or the tile pass -- is in trw_kernels_marks.hpp; beyond `heavy_cap` entries in the shorter row, and for
+// graphs whose rows are not sorted, the mask is all ones + filter (every band trial asks the edge set, as the walk
+// did before there were masks).
 constexpr uint32_t kRposAbsent = 0u, kRposLookup = 1u;
 constexpr uint32_t kMaskIsFilter = 0x80000000u;  // top bit of the deg word (rows have fewer than 2^31 entries)
 constexpr uint32_t kNoCommon = kMaskIsFilter;    // (name used by the unsorted-rows kernel when it strips the bit)
@@ -857,9 +856,6 @@ __device__ __forceinline__ bool edge_table_find(const uint32_t *__restrict__ tab
     }
 }
 
-#ifndef TRW_HEAVY_PIVOTS
-#define TRW_HEAVY_PIVOTS 1
-#endif
 struct Mask128 {
     uint32_t w[4];
     __device__ __forceinline__ void clear() { w[0] = w[1] = w[2] = w[3] = 0u; }
@@ -902,7 +898,7 @@ __device__ __forceinline__ uint32_t row_find32(const uint32_t *__restrict__ col3
 }
 
 // row_find32 for the prepare pass's hits (a common neighbour / a reverse edge found in the edge set: 6 M of them on
-// R-MAT 10M/110M, 29 per wave of csr_ext32_kernel -- and a lane that bisects holds its whole wave for ten dependent
+// R-MAT 10M/110M, 29 per wave of the entries kernel -- and a lane that bisects holds its whole wave for ten dependent
 // round trips): FOUR pivots per round, loaded together, so a round trip divides the range by five -- four rounds
 // for a row of a thousand entries instead of ten.
 __device__ __forceinline__ uint32_t row_find32_wide(const uint32_t *__restrict__ col32, uint32_t start, uint32_t n, uint32_t x,
@@ -957,13 +953,9 @@ __device__ __attribute__((noinline)) bool edge_chain_cold(const uint32_t *table,
 }
 
 // Mask of the step after u -> v: offsets of v's row [v_start, v_start+v_deg) whose node is in u's row
-// [u_lo, u_hi).  Two ways to intersect, each where it measured faster (R-MAT 10M/110M):
-//   common_mask_table   walk the shorter row, one edge-table probe per entry: independent gathers, what a single
-//                       thread does best (rows up to 32 inline: 36 ms for the whole pass; the bisections: 62 ms)
-//   common_mask_bisect  walk the shorter row, bisect each entry into the longer one: reads only the two (sorted)
-//                       rows, and long rows are re-read by everyone and stay in L2 -- what the wave-per-entry pass
-//                       over long rows does best (rows up to 4096: 212 ms instead of 354 ms with table probes)
-// The caller's lane handles entries first, first+stride, ... of the shorter row.
+// [u_lo, u_hi), by walking the shorter row with one probe of the edge set per entry: independent gathers, what a single
+// thread does best (the owning thread's way for short rows; measured against bisections into the longer row: 36 vs 62 ms
+// for the whole pass with rows up to 32, round 2).
 #ifdef TRW_PREP_COUNT
 static __device__ unsigned long long g_cnt_hits_u = 0, g_cnt_rpos = 0, g_cnt_probes_u = 0;  // (debug counters)
 #endif
@@ -994,241 +986,30 @@ __device__ __forceinline__ void common_mask_table(const uint32_t *__restrict__ c
     }
 }
 
-__device__ __forceinline__ void common_mask_bisect(const uint32_t *__restrict__ col32, uint32_t u_lo, uint32_t u_hi,
-                                                   uint32_t v_start, uint32_t v_deg, uint32_t first, uint32_t stride,
-                                                   Mask128 &m)
-{
-    const uint32_t u_deg = u_hi - u_lo;
-    uint32_t run;
-    if (u_deg <= v_deg) {  // walk u's row: each distinct w in it, located in v's row
-        for (uint32_t i = first; i < u_deg; i += stride) {
-            const uint32_t w = col32[u_lo + i];
-            if (i > 0 && col32[u_lo + i - 1] == w) continue;  // a run of equal entries is one node
-            const uint32_t lo = row_find32(col32, v_start, v_deg, w, run);
-            if (run) m.set_run(lo, run);
-        }
-    } else {  // walk v's row: the node at each offset, located in u's row
-        for (uint32_t j = first; j < v_deg; j += stride) {
-            row_find32(col32, u_lo, u_deg, col32[v_start + j], run);
-            if (run) m.set(j);
-        }
-    }
-}
-
-// row_find32 for the wave-per-entry pass: every lane of the wave searches the SAME long row, so the top six levels of
-// the bisection are the same 63 entries for all of them.  The wave loads them once per entry into LDS (`piv[k]` = last
-// entry of the k-th sixty-fourth of the row), a lane finds its sixty-fourth there and bisects only inside it: six
-// global loads less per search (10 of 17 left for a 100 000-entry hub row, 4 of 10 for a 1 000-entry one).
-__device__ __forceinline__ uint32_t row_find32_pivots(const uint32_t *__restrict__ col32, uint32_t start, uint32_t n,
-                                                      const uint32_t *piv, uint32_t x, uint32_t &run)
-{
-    uint32_t k = 0;
-#pragma unroll
-    for (uint32_t s = 32; s; s >>= 1)
-        if (piv[k + s - 1] < x) k += s;
-    run = 0;
-    if (piv[k] < x) return n;  // beyond the row's last entry
-    uint32_t lo = (uint32_t)(((uint64_t)k * n) >> 6), len = (uint32_t)(((uint64_t)(k + 1) * n) >> 6) - lo;
-    while (len > 0) {
-        const uint32_t half = len >> 1;
-        if (col32[start + lo + half] < x) {
-            lo += half + 1;
-            len -= half + 1;
-        } else {
-            len = half;
-        }
-    }
-    while (lo + run < n && col32[start + lo + run] == x) ++run;
-    return lo;
-}
-
-// common_mask_bisect with the longer row's pivots in `piv` (64 words of LDS owned by the calling wave, filled here)
-__device__ __forceinline__ void common_mask_pivots(const uint32_t *__restrict__ col32, uint32_t u_lo, uint32_t u_hi,
-                                                   uint32_t v_start, uint32_t v_deg, int lane, uint32_t *piv, Mask128 &m)
-{
-    const uint32_t u_deg = u_hi - u_lo;
-    const bool walk_u = u_deg <= v_deg;
-    const uint32_t b_start = walk_u ? v_start : u_lo, b_n = walk_u ? v_deg : u_deg;  // the row searched (wave-uniform)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    piv[lane] = col32[b_start + (uint32_t)(((uint64_t)(lane + 1) * b_n) >> 6) - 1u];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    uint32_t run;
-    if (walk_u) {  // walk u's row: each distinct w in it, located in v's row
-        for (uint32_t i = (uint32_t)lane; i < u_deg; i += 64u) {
-            const uint32_t w = col32[u_lo + i];
-            if (i > 0 && col32[u_lo + i - 1] == w) continue;  // a run of equal entries is one node
-            const uint32_t lo = row_find32_pivots(col32, v_start, v_deg, piv, w, run);
-            if (run) m.set_run(lo, run);
-        }
-    } else {  // walk v's row: the node at each offset, located in u's row
-        for (uint32_t j = (uint32_t)lane; j < v_deg; j += 64u) {
-            row_find32_pivots(col32, u_lo, u_deg, piv, col32[v_start + j], run);
-            if (run) m.set(j);
-        }
-    }
-}
-
 struct HeavyItem {
     uint32_t e, u;
 };
 
-// Who works out the mask of entry u -> v (rows sorted), by the two rows' lengths:
-//   MK_INLINE  the thread that owns the entry, one table probe per entry of the shorter row (<= inline_cap)
-//   MK_TILE_A  the tile pass, u's row (the longer one) in LDS, v's row streamed past it -- found by u's entry range
-//   MK_TILE_B  the tile pass, v's row (longer or equal) in LDS, u's row streamed -- found through v's in-list
-//   MK_QUEUE   the wave-per-entry pass over the queue (longer row too long for a tile, or the tile pass is off)
-//   MK_NONE    nobody: the shorter row is beyond heavy_cap, the mask stays all ones + filter
-enum : uint32_t { MK_INLINE = 0, MK_TILE_A, MK_TILE_B, MK_QUEUE, MK_NONE };
-__device__ __forceinline__ uint32_t mask_route(uint32_t deg_u, uint32_t deg_v, uint32_t inline_cap, uint32_t heavy_cap,
-                                               uint32_t tile_cap)
-{
-    const uint32_t shorter = deg_u < deg_v ? deg_u : deg_v, longer = deg_u < deg_v ? deg_v : deg_u;
-    if (shorter <= inline_cap) return MK_INLINE;
-    if (shorter > heavy_cap) return MK_NONE;
-    (void)longer;
-    if (tile_cap == 0u) return MK_QUEUE;  // no tile pass
-    return deg_u > deg_v ? MK_TILE_A : MK_TILE_B;
-}
-
-__global__ void __launch_bounds__(kBlock)
-csr_ext32_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32, int64_t n_nodes,
-                 int64_t nnz, const uint32_t *__restrict__ table, uint32_t tnb, uint32_t inline_cap,
-                 uint32_t heavy_cap, uint32_t tile_cap, u32x4_a16 *__restrict__ ext, HeavyItem *__restrict__ heavy,
-                 uint32_t heavy_room, uint32_t *__restrict__ in_count, int64_t *__restrict__ header)
-{
-    constexpr int kPer = 8;
-    const bool sorted = header[kStDescents] == header[kStBoundary];
-    const uint32_t e_first = row32[0], e_last = row32[n_nodes];  // entries outside belong to no row
-    const int64_t chunks = (nnz + kPer - 1) / kPer;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x; c < chunks; c += stride) {
-        const uint32_t e0 = (uint32_t)(c * kPer);
-        uint32_t u = 0, n = (uint32_t)n_nodes;
-        while (n > 1) {  // the row that holds entry e0
-            const uint32_t half = n >> 1;
-            if (row32[u + half] <= e0) {
-                u += half;
-                n -= half;
-            } else {
-                n = half;
-            }
-        }
-        uint32_t row_lo = row32[u], row_hi = row32[u + 1];
-        for (int k = 0; k < kPer; ++k) {
-            const uint32_t e = e0 + k;
-            if (e >= (uint32_t)nnz) break;
-            while (e >= row_hi && u + 1 < (uint32_t)n_nodes) {
-                ++u;
-                row_lo = row_hi;
-                row_hi = row32[u + 1];
-            }
-            const uint32_t v = col32[e];
-            uint32_t start, deg;
-            load_row32(row32, v, start, deg);
-            Mask128 m;
-            m.fill();
-            uint32_t flag = kMaskIsFilter, rpos = kRposAbsent;
-            if (e >= e_first && e < e_last) {
-                if (edge_table_find(table, tnb, v, u)) {  // the reverse edge exists: where u sits in v's row
-#ifdef TRW_PREP_COUNT
-                    atomicAdd(&g_cnt_rpos, 1ull);
-#endif
-                    uint32_t cnt = 0;
-                    const uint32_t lo = sorted ? row_find32_wide(col32, start, deg, u, cnt) : 0u;
-                    rpos = (sorted && cnt <= 15u && lo < (1u << 28)) ? ((cnt << 28) | lo) : kRposLookup;
-                }
-                const uint32_t deg_u = row_hi - row_lo;
-                const uint32_t route = sorted ? mask_route(deg_u, deg, inline_cap, heavy ? heavy_cap : 0u, tile_cap) : MK_NONE;
-                if (route == MK_INLINE) {
-                    m.clear();
-                    common_mask_table(col32, table, tnb, u, row_lo, row_hi, v, start, deg, m);
-                    flag = deg > 128u ? kMaskIsFilter : 0u;
-                } else if (route == MK_QUEUE) {
-                    const uint32_t at = (uint32_t)atomicAdd((unsigned long long *)&header[kStHeavyCount], 1ull);
-                    if (at < heavy_room) heavy[at] = HeavyItem{e, u};
-                } else if (route == MK_TILE_B) {
-                    atomicAdd(in_count + v, 1u);  // v's in-list grows by this entry (heavy_scatter_kernel fills it)
-                }
-            }
-            u32x4_a16 o = {v, start, deg | flag, rpos};
-            u32x4_a16 mm = {m.w[0], m.w[1], m.w[2], m.w[3]};
-            ext[2 * (size_t)e] = o;
-            ext[2 * (size_t)e + 1] = mm;
-        }
-    }
-}
-
-// The queued entries, one wave each: 64 lanes stride over the shorter row, OR their masks together.
-__global__ void __launch_bounds__(kBlock)
-csr_ext32_heavy_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32,
-                       u32x4_a16 *__restrict__ ext,
-                       const HeavyItem *__restrict__ heavy, uint32_t heavy_room, const int64_t *__restrict__ header)
-{
-    __shared__ uint32_t piv_mem[kBlock / 64][64];
-    const uint64_t queued = (uint64_t)header[kStHeavyCount];
-    const uint32_t count = queued < heavy_room ? (uint32_t)queued : heavy_room;
-    const int lane = threadIdx.x & 63;
-    const uint32_t waves = gridDim.x * (kBlock / 64);
-    for (uint32_t it = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); it < count; it += waves) {
-        const HeavyItem h = heavy[it];
-        const uint32_t v = col32[h.e];
-        uint32_t start, deg;
-        load_row32(row32, v, start, deg);
-        Mask128 m;
-        m.clear();
-        const uint32_t u_lo = row32[h.u], u_hi = row32[h.u + 1];
-        const uint32_t longer = (u_hi - u_lo) <= deg ? deg : u_hi - u_lo;
-        if (TRW_HEAVY_PIVOTS && longer > 64u)
-            common_mask_pivots(col32, u_lo, u_hi, start, deg, lane, piv_mem[threadIdx.x >> 6], m);
-        else
-            common_mask_bisect(col32, u_lo, u_hi, start, deg, (uint32_t)lane, 64u, m);
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) m.w[k] |= __shfl_xor(m.w[k], off);
-        if (lane == 0) {
-            u32x4_a16 mm = {m.w[0], m.w[1], m.w[2], m.w[3]};
-            ext[2 * (size_t)h.e + 1] = mm;
-            if (deg <= 128u) reinterpret_cast<uint32_t *>(ext + 2 * (size_t)h.e)[2] = deg;  // exact: drop the filter bit
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------
-// The tile pass: neighbourhood masks of the entries whose shorter row has more than inline_cap entries
+// The tile pass (kernels: trw_kernels_marks.hpp): what its tasks and in-lists look like
 // ---------------------------------------------------------------------------
-// The mask of u -> v is the intersection of two sorted rows, written as positions of v's row.  The wave-per-entry pass
-// above walks the shorter row and bisects every element into the longer one in GLOBAL memory: 1e10 searches of 4-5
-// dependent loads each on R-MAT 10M/110M, 116 ms at the L2s' request rate.  97 % of those searches go
-// into a row of fewer than 16 384 entries -- 64 KB, a tile of LDS -- and the entries that share a longer row can share
-// the tile:
-//   * longer row = u's  (MK_TILE_A): u's entries are consecutive in the CSR.  A task is (u, 128 of its entries);
-//     v's row is streamed (coalesced), element j found in the tile sets bit j.
-//   * longer row = v's  (MK_TILE_B): the entries that point AT v are scattered, so they are collected first:
-//     csr_ext32_kernel counts them per v, heavy_plan_kernel hands every v a segment of the item array,
-//     heavy_scatter_kernel fills the segments with (e, u).  A task is (v, 64 items of its in-list); u's row is
-//     streamed, element w found at position lo of the tile sets bits lo .. lo+run-1 (run > 1: parallel edges).
-// A workgroup of 8 waves keeps one row in LDS (padded with 0xFFFFFFFF to a power of two, so the bisection is
-// branch-free: add, ds_read, compare, select per level), takes tasks from a device counter four at a time -- tasks of one
-// row are consecutive, the tile stays -- and each wave streams the shorter rows of its share of the task's items,
-// four elements per lane at a time.  Every global load is a coalesced stream; the only random accesses left are
-// LDS reads.
+// The mask of u -> v is the intersection of two sorted rows, written as positions of v's row.  The longer row is kept
+// in LDS (a tile) and the shorter ones are streamed past it; the entries that share a longer row share the tile:
+//   * longer row = u's: u's entries are consecutive in the CSR.  A task is (u, 128 or 64 of its entries); v's row is
+//     streamed (coalesced), element j found in the tile sets bit j.
+//   * longer row = v's: the entries that point AT v are scattered, so they are collected first: the entries kernel
+//     counts them per v, the plan kernel hands every v a segment of the item array, the scatter kernel fills the
+//     segments with (e, u).  A task is (v, 64 items of its in-list); u's row is streamed, element w found at position
+//     lo of the tile sets bits lo .. lo+run-1 (run > 1: parallel edges).
 #ifndef TRW_TASK_ENTRIES
 #define TRW_TASK_ENTRIES 128
 #endif
 #ifndef TRW_TASK_ITEMS
 #define TRW_TASK_ITEMS 64
 #endif
-constexpr uint32_t kTaskEntries = TRW_TASK_ENTRIES;   // MK_TILE_A: entries of the tile row per task
-constexpr uint32_t kTaskItems = TRW_TASK_ITEMS;      // MK_TILE_B: in-list items per task
-#ifndef TRW_TASK_GRAB
-#define TRW_TASK_GRAB 16
-#endif
-constexpr uint32_t kTaskGrab = TRW_TASK_GRAB;  // consecutive tasks a workgroup takes from the counter at a time
-constexpr int kStTaskCount = 16, kStSortedCursor = 17, kStTaskNext = 18;  // header slots
+constexpr uint32_t kTaskEntries = TRW_TASK_ENTRIES;   // long tile rows: entries of the tile row per task
+constexpr uint32_t kTaskItems = TRW_TASK_ITEMS;      // in-list items per task
+constexpr int kStTaskCount = 16, kStTaskNext = 18;  // header slots
 constexpr uint32_t kNoSegment = 0xFFFFFFFFu;
 
 struct TileTask {  // 8 bytes: what else a task needs (how many, of how many) the tile kernel has from row32 / the in-list arrays
@@ -1236,10 +1017,7 @@ struct TileTask {  // 8 bytes: what else a task needs (how many, of how many) th
     uint32_t start;      //                     mode 1: up to kTaskItems items of its in-list from items[start] on
 };
 
-// One lane per node, a wave per 64 nodes: tasks for the rows that can be a tile, and a segment of the item array for the
-// node's in-list.  The wave takes its segments and its task numbers with ONE atomic each (a prefix sum over the lanes:
-// one atomic per node serialised half a million of them on two addresses, 5 of the pass's 7 ms), and writes the
-// task records of a long row together (a hub's two thousand records were one lane's loop).
+// exclusive prefix sum of v over the wave's lanes; total = the sum
 __device__ __forceinline__ uint32_t wave_prefix_excl(uint32_t v, int lane, uint32_t &total)
 {
     uint32_t inc = v;
@@ -1248,391 +1026,12 @@ __device__ __forceinline__ uint32_t wave_prefix_excl(uint32_t v, int lane, uint3
         const uint32_t y = (uint32_t)__shfl_up((int)inc, d);
         if (lane >= d) inc += y;
     }
-    total = (uint32_t)__shfl((int)inc, 63);
+    total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);  // (a scalar: what is decided from it stays a scalar branch)
     return inc - v;
 }
 
-__global__ void __launch_bounds__(kBlock)
-heavy_plan_kernel(const uint32_t *__restrict__ row32, int64_t n_nodes, const uint32_t *__restrict__ in_count,
-                  uint32_t *__restrict__ in_off, TileTask *__restrict__ tasks, uint32_t task_room, uint32_t heavy_room,
-                  uint32_t inline_cap, int64_t *__restrict__ header)
-{
-    if (header[kStDescents] != header[kStBoundary]) return;  // rows not sorted: no masks, no tasks
-    const int lane = threadIdx.x & 63;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    const uint64_t queued = (uint64_t)header[kStHeavyCount];
-    const uint32_t base0 = queued < heavy_room ? (uint32_t)queued : heavy_room;  // the queue's items come first
-    for (int64_t x0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) & ~(int64_t)63; x0 < n_nodes; x0 += stride) {
-        const int64_t x = x0 + lane;
-        uint32_t start = 0, deg = 0;
-        if (x < n_nodes) load_row32(row32, (uint32_t)x, start, deg);
-        const bool tile = deg > inline_cap;  // (else: never the longer row of a tile item)
-        const uint32_t c = tile ? in_count[x] : 0u;
-        // segments of the item array
-        uint32_t c_total;
-        const uint32_t c_before = wave_prefix_excl(c, lane, c_total);
-        uint64_t seg_base = 0;
-        if (c_total) {
-            if (lane == 0) seg_base = atomicAdd((unsigned long long *)&header[kStSortedCursor], (unsigned long long)c_total);
-            seg_base = (uint64_t)__shfl((long long)seg_base, 0) + base0;
-        }
-        uint32_t seg = kNoSegment;
-        if (c) {
-            if (seg_base + c_before + c <= heavy_room) seg = (uint32_t)(seg_base + c_before);
-            in_off[x] = seg;  // kNoSegment: no room, these entries keep their all-ones masks
-        }
-        // tasks; MK_TILE_A needs deg > deg(v) > inline_cap
-        const uint32_t n_a = (tile && deg >= inline_cap + 2u) ? (deg + kTaskEntries - 1u) / kTaskEntries : 0u;
-        const uint32_t n_b = seg != kNoSegment ? (c + kTaskItems - 1u) / kTaskItems : 0u;
-        const uint32_t n_t = n_a + n_b;
-        uint32_t n_total;
-        const uint32_t n_before = wave_prefix_excl(n_t, lane, n_total);
-        uint64_t at0 = 0;
-        if (lane == 0 && n_total) at0 = atomicAdd((unsigned long long *)&header[kStTaskCount], (unsigned long long)n_total);
-        const uint64_t at = (uint64_t)__shfl((long long)at0, 0) + n_before;  // (a shuffle must not sit inside a select's arm)
-        auto record = [&](uint32_t node, uint32_t r_start, uint32_t r_seg, uint32_t r_na, uint32_t k) {
-            TileTask t;
-            if (k < r_na) {
-                t.node_mode = node;
-                t.start = r_start + k * kTaskEntries;
-            } else {
-                t.node_mode = node | 0x80000000u;
-                t.start = r_seg + (k - r_na) * kTaskItems;
-            }
-            return t;
-        };
-        // rows with many records: the whole wave writes them; the others: their own lane
-        uint64_t wide = __ballot(n_t > 16u);
-        while (wide) {
-            const int src = __builtin_ctzll(wide);
-            wide &= wide - 1;
-            const uint32_t w_n = (uint32_t)__shfl((int)n_t, src), w_na = (uint32_t)__shfl((int)n_a, src);
-            const uint32_t w_start = (uint32_t)__shfl((int)start, src), w_seg = (uint32_t)__shfl((int)seg, src);
-            const uint64_t w_at = (uint64_t)__shfl((long long)at, src);
-            for (uint32_t k = (uint32_t)lane; k < w_n; k += 64u)
-                if (w_at + k < task_room) tasks[w_at + k] = record((uint32_t)(x0 + src), w_start, w_seg, w_na, k);
-        }
-        if (n_t <= 16u)
-            for (uint32_t k = 0; k < n_t; ++k)
-                if (at + k < task_room) tasks[at + k] = record((uint32_t)x, start, seg, n_a, k);
-    }
-}
-
-// The in-lists: every MK_TILE_B entry u -> v goes into v's segment.  A wave takes 64 consecutive nodes; the rows that
-// can be the shorter side of such an entry (inline_cap < deg <= heavy_cap) are scanned by the whole wave.
-__global__ void __launch_bounds__(kBlock)
-heavy_scatter_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32, int64_t n_nodes,
-                     uint32_t inline_cap, uint32_t heavy_cap, uint32_t *__restrict__ in_fill,
-                     const uint32_t *__restrict__ in_off, HeavyItem *__restrict__ items)
-{
-    const int lane = threadIdx.x & 63;
-    const int64_t waves = (int64_t)gridDim.x * (kBlock / 64);
-    for (int64_t w = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); w * 64 < n_nodes; w += waves) {
-        const int64_t x = w * 64 + lane;
-        uint32_t start = 0, deg = 0;
-        if (x < n_nodes) load_row32(row32, (uint32_t)x, start, deg);
-        uint64_t todo = __ballot(deg > inline_cap && deg <= heavy_cap);
-        while (todo) {
-            const int src = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const uint32_t u = (uint32_t)(w * 64 + src);
-            const uint32_t u_start = __shfl(start, src), u_deg = __shfl(deg, src);
-            for (uint32_t i = (uint32_t)lane; i < u_deg; i += 64u) {
-                const uint32_t e = u_start + i, v = col32[e];
-                uint32_t v_start, v_deg;
-                load_row32(row32, v, v_start, v_deg);
-                if (mask_route(u_deg, v_deg, inline_cap, heavy_cap, 1u) != MK_TILE_B) continue;
-                const uint32_t seg = in_off[v];
-                if (seg == kNoSegment) continue;
-                const uint32_t k = atomicAdd(in_fill + v, 1u);  // (in_count stays: the tile pass reads a task's size from it)
-                items[seg + k] = HeavyItem{e, u};
-            }
-        }
-    }
-}
-
-// kCap: entries of LDS per tile (a power of two); kThreads: workgroup size.  A row of fewer than kCap entries is one
-// tile; a longer one is swept in chunks of kCap-1 entries, the workgroup's items streamed past every chunk and their
-// masks gathered in LDS in between (a dozen hub rows on R-MAT 10M/110M, 3 % of the searches -- which took the
-// wave-per-entry pass 10 ms).
 constexpr uint32_t kTileSentinel = 0x7FFFFFFFu;  // padding of a tile: above every node id (n_nodes < 2^31)
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
-
-// kCap: entries of LDS per tile (a power of two); kThreads: workgroup size.  A row of fewer than kCap entries is in the
-// tile whole.  Of a longer one (a few hundred rows of R-MAT 10M/110M, but 11 % of the searches) the tile holds every
-// m-th entry -- the last of each block of m = ceil(n / (kCap-1)) --, the bisection in LDS finds the block and the last
-// log2(m) levels read the block in global memory (L2 hits: 1 level for a row of 8-16 K entries, 5 for the longest).
-template <uint32_t kCap, int kThreads>
-__global__ void __launch_bounds__(kThreads, 8)  // (64 vector registers: four workgroups of 8 waves per CU)
-heavy_tile_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32, u32x4_a16 *__restrict__ ext,
-                  const HeavyItem *__restrict__ items, const TileTask *__restrict__ tasks, uint32_t task_room,
-                  const uint32_t *__restrict__ in_count, const uint32_t *__restrict__ in_off, uint32_t inline_cap,
-                  uint32_t heavy_cap, int64_t *__restrict__ header)
-{
-    constexpr uint32_t kWaves = kThreads / 64;
-    constexpr uint32_t kPerWave = (kTaskEntries > kTaskItems ? kTaskEntries : kTaskItems) / kWaves;  // items of a task per wave
-    constexpr int kCountSlot = kStTaskCount, kNextSlot = kStTaskNext;
-    static_assert(kPerWave <= 64 && (kCap & (kCap - 1)) == 0, "one lane per item; power-of-two tile");
-    static_assert((kPerWave & (kPerWave - 1)) == 0, "the items of a wave: a power of two (their prefix table is bisected)");
-    // words in front of the tile, per wave: its items' masks (4 each), where their elements start in the wave's flat
-    // numbering (+ the total), and where their rows start in col32; then `grabbed`
-    constexpr uint32_t kWaveWords = kPerWave * 6 + 4;
-    constexpr uint32_t kHead = kWaves * kWaveWords + 4;
-    __shared__ uint32_t lds[kHead + kCap];
-    uint32_t *const tile = lds + kHead;
-    uint32_t *const wave_lds = lds + (threadIdx.x >> 6) * kWaveWords;
-    uint32_t(*const acc)[4] = reinterpret_cast<uint32_t(*)[4]>(wave_lds);  // this wave's items' masks
-    uint32_t *const pfx = wave_lds + kPerWave * 4;                         // pfx[j]: first flat element of item j; pfx[kPerWave]: all
-    uint32_t *const row_at = pfx + kPerWave + 1;                           // row_at[j]: where item j's (shorter) row starts
-    uint32_t &grabbed = lds[kHead - 4];
-    // the tile as an LDS byte address (the low half of its flat address): the bisection below computes addresses itself
-    const uint32_t tile_lds = (uint32_t)reinterpret_cast<uintptr_t>(tile);
-    const int lane = threadIdx.x & 63;
-    const uint32_t wave = threadIdx.x >> 6;
-    const uint64_t made = (uint64_t)header[kCountSlot];
-    const uint32_t n_tasks = made < task_room ? (uint32_t)made : task_room;
-    // the tile holds cur_node's row [t_start, t_start + n): every m-th entry, nb of them; the bisection's first step is top4 bytes
-    uint32_t cur_node = 0xFFFFFFFFu, n = 0, t_start = 0, m = 1, nb = 0, top4 = 0, mtop = 0;
-#ifdef TRW_TILE_CLOCKS
-    unsigned long long ck[6] = {0, 0, 0, 0, 0, 0}, ck_t = clock64();
-#define TRW_LAP(k) do { const unsigned long long now_ = clock64(); ck[k] += now_ - ck_t; ck_t = now_; } while (0)
-#else
-#define TRW_LAP(k) do { } while (0)
-#endif
-    while (true) {
-        __syncthreads();  // (everyone has read `grabbed` of the last round)
-        if (threadIdx.x == 0) grabbed = (uint32_t)atomicAdd((unsigned long long *)&header[kNextSlot], (unsigned long long)kTaskGrab);
-        __syncthreads();
-        const uint32_t t0 = grabbed;
-        TRW_LAP(0);
-        if (t0 >= n_tasks) break;
-        const uint32_t t1 = t0 + kTaskGrab < n_tasks ? t0 + kTaskGrab : n_tasks;
-        for (uint32_t ti = t0; ti < t1; ++ti) {
-            const TileTask rec = tasks[ti];
-            struct {
-                uint32_t node, start, count, mode;
-            } task = {rec.node_mode & 0x7FFFFFFFu, rec.start, 0u, rec.node_mode >> 31};
-            const bool new_node = task.node != cur_node;  // (workgroup-uniform)
-            uint32_t n_new = n, start_new = t_start;
-            if (new_node) load_row32(row32, task.node, start_new, n_new);
-            if (task.mode == 0u) {  // what is left of the row / of the in-list from `start` on, a task's worth at most
-                const uint32_t rest_a = start_new + n_new - task.start;
-                task.count = rest_a < kTaskEntries ? rest_a : kTaskEntries;
-            } else {
-                const uint32_t rest_b = in_off[task.node] + in_count[task.node] - task.start;
-                task.count = rest_b < kTaskItems ? rest_b : kTaskItems;
-            }
-            // this wave's items of the task: lane j looks at item wave + kWaves * j
-            const uint32_t k = wave + kWaves * (uint32_t)lane;
-            uint32_t s_start = 0, s_len = 0, e = 0, deg_v = 0;
-            bool mine = false;
-            if (k < task.count) {
-                if (task.mode == 0u) {
-                    e = task.start + k;
-                    const uint32_t v = col32[e];
-                    load_row32(row32, v, s_start, s_len);
-                    deg_v = s_len;
-                    mine = mask_route(n_new, s_len, inline_cap, heavy_cap, kCap) == MK_TILE_A;
-                } else {
-                    const HeavyItem it = items[task.start + k];
-                    e = it.e;
-                    load_row32(row32, it.u, s_start, s_len);
-                    deg_v = n_new;
-                    mine = true;
-                }
-            }
-            const uint64_t todo = __ballot(mine);
-            TRW_LAP(1);
-            // Waves only meet when the tile changes (a barrier per task made every wave wait for the task's slowest:
-            // 72 % of the wave cycles were waits); between two changes each wave works through its share of the tasks
-            // at its own pace.
-            if (!new_node && todo == 0) continue;
-            if (new_node) {
-                // (a barrier: every wave is done with the old tile) nobody has anything to do in this task -- a
-                // hub's run of short rows?  Then the old tile stays.
-                if (!__syncthreads_or(todo != 0)) continue;
-                n = n_new;
-                t_start = start_new;
-                m = n < kCap ? 1u : (n + kCap - 2u) / (kCap - 1u);
-                nb = (n + m - 1u) / m;
-                uint32_t pow2 = 64u;
-                while (pow2 < nb + 1u) pow2 <<= 1;
-                for (uint32_t i = threadIdx.x; i < pow2; i += kThreads) {
-                    const uint32_t last = (i + 1u) * m < n ? (i + 1u) * m : n;  // one past block i's last entry
-                    tile[i] = i < nb ? col32[t_start + last - 1u] : kTileSentinel;
-                }
-                top4 = pow2 * 2u;  // bytes of the first bisection step: pow2/2 entries
-                mtop = 1u;
-                while (mtop < m) mtop <<= 1;  // first step inside a block (m > 1): covers offsets 0 .. m-1
-                cur_node = task.node;
-                __syncthreads();
-                if (todo == 0) continue;
-            }
-            TRW_LAP(2);
-            // The elements of the wave's items -- the entries of their shorter rows -- in ONE flat numbering, 256 of them
-            // (four per lane) at a time: a lane finds the item its element belongs to in the wave's prefix table (sixteen
-            // entries of LDS: four levels) and the element itself at row_at[item] + offset.  (Until late in round 4 the wave
-            // went item by item, 256 elements of ONE item at a time: a piece was 1.4 groups of 64 on average and carried
-            // ~115 issue slots of cursor, buffer descriptor, dispatch and hit check for the ~50 its levels need; the kernel
-            // issued three times the instructions of its bisections.)  The next 256 are on their way while these are searched.
-            const uint32_t len_j = mine ? s_len : 0u;
-            uint32_t total;
-            const uint32_t first_j = wave_prefix_excl(len_j, lane, total);
-            if (lane < (int)kPerWave) {
-                acc[lane][0] = acc[lane][1] = acc[lane][2] = acc[lane][3] = 0u;
-                pfx[lane] = first_j;   // (an item without elements shares its number with the next one: the search below
-                row_at[lane] = s_start;  // takes the LAST item that starts at or before the element)
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const bool odd_levels = (__builtin_clz(top4) & 1) != 0;  // top4 = 2^k bytes: k - 1 levels, odd iff k is even iff clz = 31 - k is odd
-            uint32_t xn[4], jn[4];
-            int cur = 0;  // (wave-uniform) the item that holds the first element of the batch being fetched
-            auto fetch = [&](uint32_t f0) {
-                uint32_t c_first = __builtin_amdgcn_readlane(first_j, cur), c_len = __builtin_amdgcn_readlane(len_j, cur);
-                while (c_first + c_len <= f0) {  // (f0 < total: there is such an item)
-                    ++cur;
-                    c_first = __builtin_amdgcn_readlane(first_j, cur);
-                    c_len = __builtin_amdgcn_readlane(len_j, cur);
-                }
-                const uint32_t last = f0 + 256u < total ? f0 + 255u : total - 1u;
-                if (last < c_first + c_len) {  // the whole batch is one item's (most elements belong to long rows): no search
-                    const uint32_t *const row = col32 + __builtin_amdgcn_readlane(s_start, cur) + (f0 - c_first);
-                    const uint32_t span = last - f0;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const uint32_t o = 64u * r + (uint32_t)lane;
-                        xn[r] = row[o < span ? o : span];  // (a lane beyond the end reads the last element again)
-                        jn[r] = (uint32_t)cur;
-                    }
-                    return;
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    uint32_t f = f0 + 64u * r + (uint32_t)lane;
-                    f = f < total ? f : total - 1u;  // (a lane beyond the end reads the last element again: no exec-mask region)
-                    uint32_t j = 0;
-#pragma unroll
-                    for (uint32_t step = kPerWave >> 1; step; step >>= 1) j = pfx[j + step] <= f ? j + step : j;
-                    xn[r] = col32[row_at[j] + (f - pfx[j])];
-                    jn[r] = j;
-                }
-            };
-            if (total) fetch(0u);
-            for (uint32_t f0 = 0; f0 < total; f0 += 256u) {
-                uint32_t x[4], item[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    x[r] = xn[r];
-                    item[r] = jn[r];
-                }
-                if (f0 + 256u < total) fetch(f0 + 256u);
-                const uint32_t rest = total - f0;  // (wave-uniform)
-                // A level of the bisection is add, ds_read, compare, select; `qa` = LDS address of the last tile entry
-                // known to be < x (tile[-1] to start with).  kSampled: the tile holds every m-th entry of the row, the
-                // block is finished in global memory -- separate code: the common form has no branch but "did any lane
-                // hit", a hit being rare.
-                auto search = [&](auto groups, auto sampled_row) {
-                    constexpr int kR = decltype(groups)::value;
-                    constexpr bool kSampled = decltype(sampled_row)::value;
-                    uint32_t qa[kR];
-#pragma unroll
-                    for (int r = 0; r < kR; ++r) qa[r] = tile_lds - 4u;
-                    // (two levels per trip; a tile has six levels at least, `odd_levels` says whether one goes first)
-                    auto level = [&](uint32_t s4) {
-#pragma unroll
-                        for (int r = 0; r < kR; ++r) {
-                            const uint32_t a = qa[r] + s4;
-                            const uint32_t t = *reinterpret_cast<const lds_u32 *>((uintptr_t)a);
-                            qa[r] = t < x[r] ? a : qa[r];
-                        }
-                    };
-                    uint32_t s4 = top4;
-                    if (odd_levels) {
-                        level(s4);
-                        s4 >>= 1;
-                    }
-                    for (; s4 >= 8u; s4 >>= 2) {
-                        level(s4);
-                        level(s4 >> 1);
-                    }
-                    uint32_t pos[kR];  // entries of the ROW < x
-                    bool hit[kR];
-                    bool any = false;
-#pragma unroll
-                    for (int r = 0; r < kR; ++r) {
-                        const bool live = 64u * r + (uint32_t)lane < rest;
-                        const uint32_t jb = (qa[r] + 4u - tile_lds) >> 2;  // tile entries < x
-                        if (!kSampled) {  // the tile is the row
-                            pos[r] = jb;
-                            hit[r] = live && *reinterpret_cast<const lds_u32 *>((uintptr_t)(qa[r] + 4u)) == x[r];
-                        } else {  // x can only be in block jb: its entries below the block's last one, in global memory
-                            const uint32_t lo = jb * m;
-                            const uint32_t len = (live && jb < nb) ? (n - lo < m ? n - lo : m) : 0u;
-                            uint32_t off = 0;
-                            for (uint32_t step = mtop >> 1; step; step >>= 1) {
-                                const uint32_t p = off + step;
-                                if (p <= len && col32[t_start + lo + p - 1u] < x[r]) off = p;
-                            }
-                            pos[r] = lo + off;
-                            hit[r] = off < len && col32[t_start + pos[r]] == x[r];
-                        }
-                        any = any || hit[r];
-                    }
-                    if (__ballot(any) == 0) return;
-#pragma unroll
-                    for (int r = 0; r < kR; ++r) {
-                        if (hit[r]) {
-                            uint32_t *const am = acc[item[r]];
-                            if (task.mode == 0u) {  // element idx of v's row is in u's row
-                                const uint32_t idx = f0 + 64u * r + (uint32_t)lane - pfx[item[r]];
-                                atomicOr(&am[(idx >> 5) & 3u], 1u << (idx & 31u));
-                            } else {  // this element of u's row sits at pos .. of v's row (a run: parallel edges)
-                                uint32_t at = pos[r];
-                                if (!kSampled) {
-                                    do {
-                                        atomicOr(&am[(at >> 5) & 3u], 1u << (at & 31u));
-                                        ++at;
-                                    } while (tile[at] == x[r]);  // (the padding ends every run)
-                                } else {
-                                    do {
-                                        atomicOr(&am[(at >> 5) & 3u], 1u << (at & 31u));
-                                        ++at;
-                                    } while (at < n && col32[t_start + at] == x[r]);
-                                }
-                            }
-                        }
-                    }
-                };
-                if (m == 1u) {  // (workgroup-uniform)
-                    if (rest <= 64u) search(std::integral_constant<int, 1>{}, std::false_type{});
-                    else if (rest <= 128u) search(std::integral_constant<int, 2>{}, std::false_type{});
-                    else search(std::integral_constant<int, 4>{}, std::false_type{});
-                } else {
-                    if (rest <= 128u) search(std::integral_constant<int, 2>{}, std::true_type{});
-                    else search(std::integral_constant<int, 4>{}, std::true_type{});
-                }
-            }
-            TRW_LAP(3);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (mine) {
-                u32x4_a16 mm = {acc[lane][0], acc[lane][1], acc[lane][2], acc[lane][3]};
-                ext[2 * (size_t)e + 1] = mm;
-                if (deg_v <= 128u) reinterpret_cast<uint32_t *>(ext + 2 * (size_t)e)[2] = deg_v;  // exact: drop the filter bit
-            }
-            __builtin_amdgcn_wave_barrier();  // (the next task clears acc)
-            TRW_LAP(4);
-        }
-    }
-#ifdef TRW_TILE_CLOCKS
-    if (lane == 0)
-        for (int k = 0; k < 5; ++k) atomicAdd((unsigned long long *)&header[24 + k], ck[k]);
-#endif
-#undef TRW_LAP
-}
 
 enum : uint32_t { LS_IDLE = 0, LS_START, LS_ROW, LS_POS, LS_TRIAL, LS_CAND, LS_MEMBER, LS_ACCEPT };
 
@@ -1988,7 +1387,7 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
 // ===========================================================================
 // Biased walk over the 32-byte fat entries: trials decided in registers
 // ===========================================================================
-// The kernel for sorted graphs with a prepared table + fat entries (csr_ext32_kernel).  Same stream, same
+// The kernel for sorted graphs with a prepared edge set + fat entries (entries_kernel).  Same stream, same
 // decisions, same rows as biased_walker_kernel / biased_hash_kernel -- what changes is where the answers come
 // from.  With t = the node two steps back and prev = the node the walker stands on, a rejection trial draws an
 // OFFSET idx into prev's row and an acceptance value ru, and the reference (rw_cpu.cpp:166-195) accepts
