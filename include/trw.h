@@ -19,7 +19,6 @@
  * TRW_COMMON_MAX=k longest (shorter) row whose neighbourhood mask the thread that owns
  * the entry works out itself (default 32; 8 when the tile pass follows);
  * TRW_HEAVY_MAX=k longest (shorter) row the marking passes take (default 256 / 1024);
- * TRW_HEAVY_TILE=0 the wave-per-entry marking pass of rounds 2-3 instead of the tile pass;
  * TRW_PLAN_MARKS_AT / TRW_PLAN_FULL_AT=k steps per CSR entry from which ONE call is
  * planned with TRW_PREP_MARKS / _FULL (default 5 / 14).
  * None of them changes a result.
@@ -94,7 +93,8 @@ const char *trw_last_error(void);
  * (>= 256): status block, per-lane RNG windows (uniform walks), the uint32
  * shadow of the CSR (4*(n_nodes+1+nnz) bytes), and by call shape the fat
  * entries (16*nnz), or the edge set (20*nnz), the 32-byte entries (32*nnz) and, for a call that
- * makes 5 steps per entry or more, the marking passes' scratch (8*nnz): 64 bytes per entry at most. */
+ * makes 5 steps per entry or more, the marking passes' scratch (10.3*nnz + 8*n_nodes).  This function is
+ * the authority; the figures are for orientation (about 67 bytes per entry + 12 per node at most). */
 size_t trw_walk_csr_workspace_bytes(int64_t n_nodes, int64_t nnz, int64_t n_walkers,
                                     int32_t walk_length, double p, double q, int32_t rng_mode);
 
@@ -141,15 +141,17 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes,
  *
  *   what  OR of TRW_PREP_* bits (0 = validated uint32 shadow only):
  *     TRW_PREP_UNIFORM  + 16-byte fat entries {v, start(v), deg(v)}: the uniform walk is one gather per step
- *     TRW_PREP_BIASED   + edge hash table (16 B x 2^k slots, 2^k >= 3*nnz) and 32-byte fat entries {v, start(v),
- *                       deg(v), where-the-reverse-edge-sits, 128-bit "is the node at this offset a neighbour
- *                       of the node I came from" mask}: a node2vec rejection trial is decided in registers and
- *                       the graph is read once per step.  Masks are worked out for entries one of whose rows
- *                       has at most 32 entries; the rest ask the edge set.
+ *     TRW_PREP_BIASED   + the edge set (8-byte keys {u, v} in 32-byte blocks, 2.5 places per edge; TRW_HASH_SLACK
+ *                       = tenths of a place per edge, i.e. a load of 0.4 by default) and 32-byte fat entries {v,
+ *                       start(v), deg(v), where-the-reverse-edge-sits, 128-bit "is the node at this offset a
+ *                       neighbour of the node I came from" mask}: a node2vec rejection trial is decided in
+ *                       registers and the graph is read once per step.  Masks are worked out for entries one of
+ *                       whose rows has at most 32 entries; the rest ask the edge set.
  *     TRW_PREP_MARKS    (implies BIASED) masks for every entry one of whose rows has at most 256 entries (the
- *                       tile pass: the longer row in LDS): about 1.5x the prepare time, 45 % faster walks --
- *                       worth it for a single call of 5 steps per CSR entry (trw_prepare_plan asks for it then)
- *     TRW_PREP_MARKS_FULL (implies MARKS) ... at most 1024 entries: about 2x the prepare time, another 20 %
+ *                       tile pass: the longer row in LDS behind a Bloom filter): about 1.2x the prepare time, 40 %
+ *                       faster walks -- worth it for a single call of 5 steps per CSR entry (trw_prepare_plan asks
+ *                       for it then)
+ *     TRW_PREP_MARKS_FULL (implies MARKS) ... at most 1024 entries: about 1.5x the prepare time, another 20 %
  *                       (planned from 14 steps per entry on)
  *   or one of          TRW_PREP_ORDER_ONLY: no shadow, only the row-order probe the int64 biased kernels want;
  *                      TRW_PREP_NOTHING: header only (uniform walk on the per-walker stream)
@@ -169,6 +171,19 @@ int32_t trw_prepare_plan(int64_t n_nodes, int64_t nnz, int64_t n_walkers, int32_
 size_t trw_prepare_csr_bytes(int64_t n_nodes, int64_t nnz, int32_t what);
 int trw_prepare_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col_idx, int64_t nnz,
                         int32_t what, void *prepared, size_t prepared_bytes, void *hip_stream);
+/* The marking passes (TRW_PREP_MARKS*) need scratch -- the in-lists' items, the tile pass's task records, two words
+ * per node -- that no walk ever reads: trw_prepare_csr_bytes = trw_prepare_csr_persistent_bytes (what the walks read:
+ * shadow, edge set, entries; 56 bytes per entry + 4 per node) + trw_prepare_csr_scratch_bytes (about 10.3 per entry + 8
+ * per node; 0 without marks), and trw_prepare_csr_hip keeps both in the one buffer.  A caller that wants the scratch
+ * back hands it in separately: `prepared` then holds trw_prepare_csr_persistent_bytes, `scratch` (16-byte aligned) is
+ * free again once the stream has run the call's kernels.  scratch == NULL: as trw_prepare_csr_hip.  The arrays are
+ * sized for the worst case -- nothing a graph can look like makes a pass run out of room; header slot 19 of the prepared
+ * buffer (int64) counts what would have been dropped and stays 0. */
+size_t trw_prepare_csr_persistent_bytes(int64_t n_nodes, int64_t nnz, int32_t what);
+size_t trw_prepare_csr_scratch_bytes(int64_t n_nodes, int64_t nnz, int32_t what);
+int trw_prepare_csr_scratch_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col_idx, int64_t nnz,
+                                int32_t what, void *prepared, size_t prepared_bytes, void *scratch,
+                                size_t scratch_bytes, void *hip_stream);
 /* Where a part of the prepared buffer sits (diagnostics and tests: the layout is a function of the shapes alone).
  * *bytes == 0: this `what` has no such part. */
 #define TRW_REGION_HEADER 0
@@ -177,7 +192,8 @@ int trw_prepare_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *
 #define TRW_REGION_EXT16  3   /* 16-byte entries of the uniform walk */
 #define TRW_REGION_TABLE  4   /* edge set: blocks of four 8-byte keys {u, v} */
 #define TRW_REGION_EXT32  5   /* 32-byte entries of the node2vec walk: {v, start(v), deg(v)|filter, rpos} + 128-bit mask */
-#define TRW_REGION_TASKS  6   /* the tile pass's task records {node, start, count, mode} (scratch of the prepare pass) */
+#define TRW_REGION_TASKS  6   /* the tile pass's task records {node | mode, start} (scratch of the prepare pass; the offset is the
+                                 one inside a buffer that holds the scratch too) */
 int trw_prepare_csr_region(int64_t n_nodes, int64_t nnz, int32_t what, int32_t which, size_t *offset, size_t *bytes);
 size_t trw_walk_csr_prepared_workspace_bytes(int64_t n_walkers, int32_t walk_length, double p, double q,
                                              int32_t rng_mode);

@@ -130,8 +130,10 @@ struct PrepLayout {
     bool marks_full = false;  // ... for rows up to 1024 entries (TRW_PREP_MARKS_FULL) instead of 256
     uint32_t table_blocks = 0;  // the edge set: blocks of four 8-byte keys
     uint32_t heavy_room = 0, task_room = 0, big_task_room = 0;  // items; tasks of short tile rows / of long ones
-    size_t off_row32 = 0, off_col32 = 0, off_ext16 = 0, off_table = 0, off_ext32 = 0, off_heavy = 0, total = 0;
-    size_t off_incount = 0, off_inoff = 0, off_infill = 0, off_tasks = 0, off_tasks_big = 0;  // the tile pass: per-node in-list counters / segments / fill marks, tasks
+    size_t off_row32 = 0, off_col32 = 0, off_ext16 = 0, off_table = 0, off_ext32 = 0, total = 0;
+    // what a walk reads ends at `persistent`; behind it, scratch of the marking passes (offsets from the scratch's start)
+    size_t persistent = 0, scratch = 0, off_heavy = 0;
+    size_t off_incount = 0, off_inoff = 0, off_tasks = 0, off_tasks_big = 0;  // the tile pass: per-node in-list counters / segments, tasks
 };
 
 bool graph_fits_narrow(int64_t n_nodes, int64_t nnz)
@@ -176,36 +178,37 @@ PrepLayout make_prep_layout(int64_t n_nodes, int64_t nnz, int32_t what)
             pl.off_ext32 = off;
             off += align_up((size_t)nnz * 32 + 64, 256);
             if (pl.marks) {
-                // Scratch of the marking passes.  Items {entry, source node} of the in-lists: the entries u -> v whose row of
-                // u is the shorter or equal one and longer than the inline cap -- about a third of the entries on a power-law
-                // graph, half on a regular one, ALL of them on a graph whose edges all point from shorter rows to longer
-                // ones.  Room for all of them: nothing is ever dropped (round 4 had room for 3/5 and left the rest their
-                // all-ones masks without a word).
+                // Scratch of the marking passes (needed until trw_prepare_csr_hip's kernels have run, not by any walk).
+                // Items {entry, source node} of the in-lists: the entries u -> v whose row of u is the shorter or equal one
+                // and longer than the inline cap -- about a third of the entries on a power-law graph, half on a regular one,
+                // ALL of them on a graph whose edges all point from shorter rows to longer ones.  Room for all of them: nothing
+                // is ever dropped (round 4 had room for 3/5 and left the rest their all-ones masks without a word).
+                size_t sc = 0;
                 const uint64_t room = (uint64_t)nnz + 64;
                 pl.heavy_room = room > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)room;
-                pl.off_heavy = off;
-                off += align_up((size_t)pl.heavy_room * 8, 256);
-                // the tile pass: in-list size, segment and fill mark per node, and its 8-byte task records
-                pl.off_incount = off;
-                off += align_up((size_t)(n_nodes + 1) * 4, 256);
-                pl.off_inoff = off;
-                off += align_up((size_t)(n_nodes + 1) * 4, 256);
-                pl.off_infill = off;
-                off += align_up((size_t)(n_nodes + 1) * 4, 256);
+                pl.off_heavy = sc;
+                sc += align_up((size_t)pl.heavy_room * 8, 256);
+                // the tile pass: in-list size and segment per node, and its 8-byte task records
+                pl.off_incount = sc;
+                sc += align_up((size_t)(n_nodes + 1) * 4, 256);
+                pl.off_inoff = sc;
+                sc += align_up((size_t)(n_nodes + 1) * 4, 256);
                 // Task records (64 entries of the tile row / 64 items of its in-list each), worst case.  Rows of 9 .. 255
                 // entries: at most nnz/64 + nnz/64 + two per such row, of which there are fewer than nnz/9: 0.2535 nnz.
                 // Longer rows: nnz/64 + nnz/64 + two per such row, fewer than nnz/256 of them: 0.0391 nnz.
                 const uint64_t troom = (uint64_t)nnz / 4 + (uint64_t)nnz / 128 + 4096;
                 pl.task_room = troom > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)troom;
-                pl.off_tasks = off;
-                off += align_up((size_t)pl.task_room * 8, 256);
+                pl.off_tasks = sc;
+                sc += align_up((size_t)pl.task_room * 8, 256);
                 pl.big_task_room = (uint32_t)((uint64_t)nnz / 32 + (uint64_t)nnz / 128 + 4096);
-                pl.off_tasks_big = off;
-                off += align_up((size_t)pl.big_task_room * 8, 256);
+                pl.off_tasks_big = sc;
+                sc += align_up((size_t)pl.big_task_room * 8, 256);
+                pl.scratch = sc;
             }
         }
     }
-    pl.total = off;
+    pl.persistent = off;
+    pl.total = off + pl.scratch;
     return pl;
 }
 
@@ -514,14 +517,32 @@ int trw_prepare_csr_region(int64_t n_nodes, int64_t nnz, int32_t what, int32_t w
     case TRW_REGION_EXT16: if (pl.ext16) { *offset = pl.off_ext16; *bytes = (size_t)nnz * 16; } break;
     case TRW_REGION_TABLE: if (pl.biased) { *offset = pl.off_table; *bytes = (size_t)pl.table_blocks * 32; } break;
     case TRW_REGION_EXT32: if (pl.biased) { *offset = pl.off_ext32; *bytes = (size_t)nnz * 32; } break;
-    case TRW_REGION_TASKS: if (pl.marks) { *offset = pl.off_tasks; *bytes = pl.off_tasks_big + (size_t)pl.big_task_room * 8 - pl.off_tasks; } break;
+    case TRW_REGION_TASKS: if (pl.marks) { *offset = pl.persistent + pl.off_tasks; *bytes = pl.off_tasks_big + (size_t)pl.big_task_room * 8 - pl.off_tasks; } break;
     default: return fail(TRW_E_ARG, "unknown region");
     }
     return TRW_OK;
 }
 
+size_t trw_prepare_csr_persistent_bytes(int64_t n_nodes, int64_t nnz, int32_t what)
+{
+    if (n_nodes < 0 || nnz < 0) return kStatusBytes;
+    return make_prep_layout(n_nodes, nnz, what).persistent;
+}
+
+size_t trw_prepare_csr_scratch_bytes(int64_t n_nodes, int64_t nnz, int32_t what)
+{
+    if (n_nodes < 0 || nnz < 0) return 0;
+    return make_prep_layout(n_nodes, nnz, what).scratch;
+}
+
 int trw_prepare_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col_idx, int64_t nnz, int32_t what,
                         void *prepared, size_t prepared_bytes, void *hip_stream)
+{
+    return trw_prepare_csr_scratch_hip(row_ptr, n_nodes, col_idx, nnz, what, prepared, prepared_bytes, nullptr, 0, hip_stream);
+}
+
+int trw_prepare_csr_scratch_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col_idx, int64_t nnz, int32_t what,
+                                void *prepared, size_t prepared_bytes, void *scratch, size_t scratch_bytes, void *hip_stream)
 {
     t_last_error.clear();
     if (n_nodes < 0 || nnz < 0) return fail(TRW_E_ARG, "negative size argument");
@@ -529,9 +550,16 @@ int trw_prepare_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *
     if (nnz > 0 && !col_idx) return fail(TRW_E_ARG, "col_idx is null");
     if (!prepared || ((uintptr_t)prepared & 15u) != 0) return fail(TRW_E_WORKSPACE, "prepared buffer missing or not 16-byte aligned");
     const PrepLayout pl = make_prep_layout(n_nodes, nnz, what);
-    if (prepared_bytes < pl.total) return fail(TRW_E_WORKSPACE, "prepared buffer too small for this graph");
+    // the marking passes' scratch: the caller's, or the tail of the prepared buffer
+    if (scratch) {
+        if (((uintptr_t)scratch & 15u) != 0 || scratch_bytes < pl.scratch) return fail(TRW_E_WORKSPACE, "scratch misaligned or too small for this graph");
+        if (prepared_bytes < pl.persistent) return fail(TRW_E_WORKSPACE, "prepared buffer too small for this graph");
+    } else if (prepared_bytes < pl.total) {
+        return fail(TRW_E_WORKSPACE, "prepared buffer too small for this graph (it holds the marking passes' scratch too)");
+    }
     hipStream_t stream = (hipStream_t)hip_stream;
     char *ws = (char *)prepared;
+    char *sc = scratch ? (char *)scratch : ws + pl.persistent;
     int64_t *header = (int64_t *)ws;
     if (g_prof.on && (g_prof.prep[0] || hipEventCreate(&g_prof.prep[0]) == hipSuccess))
         (void)hipEventRecord(g_prof.prep[0], stream);
@@ -564,25 +592,21 @@ int trw_prepare_csr_hip(const int64_t *row_ptr, int64_t n_nodes, const int64_t *
             const uint32_t heavy_cap =
                 pl.marks ? (uint32_t)env_long("TRW_HEAVY_MAX", 0, 1 << 20, pl.marks_full ? 1024 : 256) : 0u;
             const bool tiles = pl.marks && heavy_cap > inline_cap;
-            uint32_t *in_count = pl.marks ? (uint32_t *)(ws + pl.off_incount) : nullptr;
-            uint32_t *in_off = pl.marks ? (uint32_t *)(ws + pl.off_inoff) : nullptr;
-            uint32_t *in_fill = pl.marks ? (uint32_t *)(ws + pl.off_infill) : nullptr;
+            uint32_t *in_count = pl.marks ? (uint32_t *)(sc + pl.off_incount) : nullptr;
+            uint32_t *in_off = pl.marks ? (uint32_t *)(sc + pl.off_inoff) : nullptr;
             u32x4_a16 *ext32 = (u32x4_a16 *)(ws + pl.off_ext32);
-            if (tiles) {
-                device_fill(in_count, 0u, align_up((size_t)(n_nodes + 1) * 4, 256), stream);
-                device_fill(in_fill, 0u, align_up((size_t)(n_nodes + 1) * 4, 256), stream);
-            }
+            if (tiles) device_fill(in_count, 0u, align_up((size_t)(n_nodes + 1) * 4, 256), stream);
             entries_kernel<<<stream_grid((nnz + 7) / 8), kBlock, 0, stream>>>(row32, col32, n_nodes, nnz, table, pl.table_blocks,
                                                                             inline_cap, heavy_cap, tiles ? 1u : 0u, ext32, in_count,
                                                                             header);
             if (tiles) {
-                TileTask *tasks = (TileTask *)(ws + pl.off_tasks), *tasks_big = (TileTask *)(ws + pl.off_tasks_big);
-                HeavyItem *items = (HeavyItem *)(ws + pl.off_heavy);
+                TileTask *tasks = (TileTask *)(sc + pl.off_tasks), *tasks_big = (TileTask *)(sc + pl.off_tasks_big);
+                HeavyItem *items = (HeavyItem *)(sc + pl.off_heavy);
                 marks_plan_kernel<<<stream_grid(n_nodes), kBlock, 0, stream>>>(row32, n_nodes, in_count, in_off, tasks, pl.task_room,
                                                                                tasks_big, pl.big_task_room, pl.heavy_room, inline_cap,
                                                                                header);
-                marks_scatter_kernel<<<stream_grid(n_nodes), kBlock, 0, stream>>>(row32, ext32, n_nodes, inline_cap, heavy_cap, in_fill,
-                                                                                  in_off, items, header);
+                marks_scatter_kernel<<<stream_grid(n_nodes), kBlock, 0, stream>>>(row32, ext32, n_nodes, inline_cap, heavy_cap, in_off,
+                                                                                  items, header);
                 // long tile rows: 4 096 entries of tile + 64 Ki bits of filter + the waves' queues, 35.6 KB, four workgroups
                 // of 8 waves per CU; short ones (up to 255 entries): a workgroup of ONE wave, 4.6 KB
                 tile_bloom_kernel<TRW_TILE_CAP, TRW_BLOOM_WORDS, 512, 8, TRW_BIG_GRAB, kStBigCount, kStBigNext, false>
@@ -687,7 +711,7 @@ static int walk_prepared(const void *prepared, size_t prepared_bytes, int32_t wh
                                  workspace, workspace_bytes, fused != nullptr))
         return rc;
     const PrepLayout pl = make_prep_layout(n_nodes, nnz, what);
-    if (!prepared || prepared_bytes < pl.total || ((uintptr_t)prepared & 15u) != 0)
+    if (!prepared || prepared_bytes < pl.persistent || ((uintptr_t)prepared & 15u) != 0)
         return fail(TRW_E_WORKSPACE, "prepared graph missing, misaligned or smaller than its layout");
 
     const bool uniform = (p == 1.0 && q == 1.0);  // rw_cpu.cpp:220

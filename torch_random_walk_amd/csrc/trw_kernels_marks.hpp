@@ -131,12 +131,16 @@ entries_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ 
                         common_mask_table(col32, table, tnb, u, row_lo, row_hi, v, start, deg, m);
                     }
                 } else if (route == RT_TILE_B) {
-                    atomicAdd(in_count + v, 1u);  // v's in-list grows by this entry (scatter kernel fills it)
+                    // v's in-list grows by this entry; its place in it travels in the rpos word until the tile pass, which
+                    // works out the real one (and the mask), overwrites the entry
+                    rpos = atomicAdd(in_count + v, 1u);
                     flag = deg > 128u ? kMaskIsFilter : 0u;
                     write_mask = false;
+                    rpos_known = true;
                 } else if (route == RT_TILE_A) {
                     flag = deg > 128u ? kMaskIsFilter : 0u;
                     write_mask = false;
+                    rpos_known = true;  // (the tile pass: u's own id in v's row as it streams past)
                 }
                 if (!rpos_known && edge_table_find(table, tnb, v, u)) {  // the reverse edge exists: where u sits in v's row
                     uint32_t cnt = 0;
@@ -256,12 +260,13 @@ marks_plan_kernel(const uint32_t *__restrict__ row32, int64_t n_nodes, const uin
 
 // The in-lists: every RT_TILE_B entry u -> v goes into v's segment.  A wave takes 64 consecutive nodes; the rows that can
 // be the shorter side of such an entry (inline_cap < deg <= heavy_cap) are scanned by the whole wave.  What the entry
-// points at -- v and the length of its row -- is read from the entry itself, which the entries kernel has just written
-// (a coalesced stream; round 4 gathered row32[v] again: one random request per scanned entry).
+// points at -- v, the length of its row -- and its place in v's in-list are read from the entry itself, which the entries
+// kernel has just written (a coalesced stream; round 4 gathered row32[v] again and took the place with a second atomic:
+// two random requests per entry more).
 __global__ void __launch_bounds__(kBlock)
 marks_scatter_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__restrict__ ext, int64_t n_nodes,
-                     uint32_t inline_cap, uint32_t heavy_cap, uint32_t *__restrict__ in_fill,
-                     const uint32_t *__restrict__ in_off, HeavyItem *__restrict__ items, const int64_t *__restrict__ header)
+                     uint32_t inline_cap, uint32_t heavy_cap, const uint32_t *__restrict__ in_off,
+                     HeavyItem *__restrict__ items, const int64_t *__restrict__ header)
 {
     if (header[kStDescents] != header[kStBoundary]) return;  // rows not sorted: the plan made no segments
     const int lane = threadIdx.x & 63;
@@ -283,8 +288,7 @@ marks_scatter_kernel(const uint32_t *__restrict__ row32, const u32x4_a16 *__rest
                 if (route2(u, v, u_deg, v_deg, inline_cap, heavy_cap) != RT_TILE_B) continue;
                 const uint32_t seg = in_off[v];
                 if (seg == kNoSegment) continue;
-                const uint32_t k = atomicAdd(in_fill + v, 1u);  // (in_count stays: the tile pass reads a task's size from it)
-                items[seg + k] = HeavyItem{e, u};
+                items[seg + o.w] = HeavyItem{e, u};  // (o.w: the entry's place in v's in-list, handed out by the entries kernel's count)
             }
         }
     }
@@ -343,11 +347,11 @@ tile_bloom_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
 {
     constexpr uint32_t kWaves = kThreads / 64;
     constexpr uint32_t kItems = kTileTaskItems;  // items of a task: one per lane
-    constexpr uint32_t kQueue = 192;  // survivors waiting for a search, per wave (a stack: fewer than 64 wait when 128 elements arrive)
+    constexpr uint32_t kQueue = 128;  // survivors waiting for a search, per wave (a stack: fewer than 64 wait when 64 elements arrive)
     static_assert(kItems == 64 && kGrab <= 64 && (kCap & (kCap - 1)) == 0 && (kBloomWords & (kBloomWords - 1)) == 0, "layout");
     // per wave: its items' masks (4 words each), where their elements start in the wave's flat numbering (+ a sentinel),
-    // where their rows start in col32, and the stack of survivors {element, its flat number}
-    constexpr uint32_t kWaveWords = kItems * 6 + 4 + 2 * kQueue;
+    // where their rows start in col32, where the tile's node sits in them, and the stack of survivors {element, its flat number}
+    constexpr uint32_t kWaveWords = kItems * 8 + 4 + 2 * kQueue;
     constexpr uint32_t kHead = kWaves * kWaveWords + 4;
     __shared__ uint32_t lds[kHead + kBloomWords + kCap];
     uint32_t *const bloom = lds + kHead;
@@ -356,8 +360,10 @@ tile_bloom_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
     uint32_t(*const acc)[4] = reinterpret_cast<uint32_t(*)[4]>(wave_lds);
     uint32_t *const pfx = wave_lds + kItems * 4;
     uint32_t *const row_at = pfx + kItems + 1;
-    uint32_t *const queue = wave_lds + kItems * 6 + 4;  // (8-byte aligned: kWaveWords and the offset are even)
-    uint32_t &grabbed = lds[kHead - 4];
+    uint32_t *const rp_first = row_at + kItems + 1;  // (tile row = u's) where u first sits in item j's row of v, and how often:
+    uint32_t *const rp_cnt = rp_first + kItems;      // rpos of the entry, found while v's row streams past
+    uint32_t *const queue = wave_lds + kItems * 8 + 4;  // (8-byte aligned: kWaveWords and the offset are even)
+    uint32_t &grabbed = lds[kHead - 4], &next_task = lds[kHead - 3];
     const uint32_t tile_lds = (uint32_t)reinterpret_cast<uintptr_t>(tile);
     const int lane = threadIdx.x & 63;
     const uint32_t wave = uni(threadIdx.x >> 6);
@@ -418,8 +424,11 @@ tile_bloom_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
             turn += gridDim.x;
             t0 = at < n_tasks ? (uint32_t)at : n_tasks;
         } else {
-            __syncthreads();  // (everyone has read `grabbed` of the last round)
-            if (threadIdx.x == 0) grabbed = (uint32_t)atomicAdd((unsigned long long *)&header[kNextSlot], (unsigned long long)kGrab);
+            __syncthreads();  // (everyone has read `grabbed` of the last round and taken its last task)
+            if (threadIdx.x == 0) {
+                grabbed = (uint32_t)atomicAdd((unsigned long long *)&header[kNextSlot], (unsigned long long)kGrab);
+                next_task = 0u;
+            }
             __syncthreads();
             t0 = uni(grabbed);
         }
@@ -430,6 +439,16 @@ tile_bloom_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
         TileTask rec_l = {0xFFFFFFFFu, 0u};
         if ((uint32_t)lane < g_cnt) rec_l = tasks[t0 + lane];
         const uint32_t node_l = rec_l.node_mode & 0x7FFFFFFFu;
+        // The waves of a workgroup take the tasks of a run one at a time from a counter in LDS (in turn -- wave w the tasks
+        // w, w + 8, ... -- a wave with two long tasks kept the other seven waiting at the next tile change: the waits at
+        // the workgroup's barriers were 28 % of the wave cycles).  `mine_t`: the task this wave has taken and not yet worked
+        // on; one that belongs to a later run waits with it for that run's tile.
+        auto take = [&]() {
+            uint32_t t = 0;
+            if (lane == 0) t = atomicAdd(&next_task, 1u);
+            return uni(t);
+        };
+        uint32_t mine_t = kWaves > 1 ? take() : 0u;
         uint32_t i0 = 0;
         while (i0 < g_cnt) {
             const uint32_t node = (uint32_t)__builtin_amdgcn_readlane((int)node_l, (int)i0);
@@ -444,7 +463,7 @@ tile_bloom_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
                 if (kWaves > 1) load_tile();
             }
             TRW_LAP(2);
-            for (uint32_t ti = i0 + wave; ti < i1; ti += kWaves) {
+            for (uint32_t ti = mine_t; ti < i1; ti = mine_t = (kWaves > 1 ? take() : ti + 1u)) {
                 struct {
                     uint32_t start, count, mode;
                 } task = {(uint32_t)__builtin_amdgcn_readlane((int)rec_l.start, (int)ti), 0u,
@@ -457,18 +476,19 @@ tile_bloom_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
                     task.count = uni(rest_b < kItems ? rest_b : kItems);
                 }
                 // the task's items, one per lane
-                uint32_t s_start = 0, s_len = 0, e = 0;
+                uint32_t s_start = 0, s_len = 0, e = 0, other = 0;  // other: v (tile row = u's) / u (tile row = v's)
                 bool mine = false;
                 if ((uint32_t)lane < task.count) {
                     if (task.mode == 0u) {
                         e = task.start + (uint32_t)lane;
-                        const uint32_t v = col32[e];
-                        load_row32(row32, v, s_start, s_len);
-                        mine = route2(node, v, n, s_len, inline_cap, heavy_cap) == RT_TILE_A;
+                        other = col32[e];
+                        load_row32(row32, other, s_start, s_len);
+                        mine = route2(node, other, n, s_len, inline_cap, heavy_cap) == RT_TILE_A;
                     } else {
                         const HeavyItem it = items[task.start + (uint32_t)lane];
                         e = it.e;
-                        load_row32(row32, it.u, s_start, s_len);
+                        other = it.u;
+                        load_row32(row32, other, s_start, s_len);
                         mine = true;
                     }
                 }
@@ -493,6 +513,8 @@ tile_bloom_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
                 const uint64_t ne = __builtin_amdgcn_ballot_w64(len_j != 0u);
                 const uint32_t d_j = __builtin_amdgcn_mbcnt_hi((uint32_t)(ne >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ne, 0u));
                 acc[lane][0] = acc[lane][1] = acc[lane][2] = acc[lane][3] = 0u;
+                rp_first[lane] = 0xFFFFFFFFu;
+                rp_cnt[lane] = 0u;
                 pfx[lane] = 0xFFFFFFFFu;  // (behind the last item: beyond every element)
                 if (lane == 0) pfx[kItems] = 0xFFFFFFFFu;
                 if (len_j != 0u) {
@@ -580,13 +602,9 @@ tile_bloom_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
                 // The survivors of the filter wait on the wave's stack; 64 of them (or what is left at the end of the task) are
                 // bisected into the tile together.  A level is add, ds_read, compare, select; `qa` = LDS address of the last tile
                 // entry known to be < x (tile[-1] to start with).
-                uint32_t q_n = 0;  // (wave-uniform) survivors on the stack
-                auto search = [&](uint32_t cnt, auto whole_row) {  // the top `cnt` (<= 64) of them
+                // Where x sits in the tile row: `pos` = entries of the row below x, `run` = how many equal it (0: not there).
+                auto locate = [&](uint32_t x, bool live, bool want_run, uint32_t &pos, uint32_t &run, auto whole_row) {
                     constexpr bool kWhole = decltype(whole_row)::value;
-                    q_n -= cnt;
-                    const uint32_t at = (q_n + (uint32_t)lane) * 2u;
-                    const uint32_t x = queue[at], f = queue[at + 1u];  // the element and its flat number
-                    const bool live = (uint32_t)lane < cnt;
                     uint32_t qa = tile_lds - 4u;
                     auto level = [&](uint32_t s4) {
                         const uint32_t a = qa + s4;
@@ -611,11 +629,14 @@ tile_bloom_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
                     }
                     for (; s4 >= 8u; s4 >>= 2) level2(s4);
                     const uint32_t jb = (qa + 4u - tile_lds) >> 2;  // tile entries < x
-                    uint32_t pos, run = 0;
-                    bool hit;
+                    run = 0;
                     if (kWhole) {  // the tile is the row
                         pos = jb;
-                        hit = live && *reinterpret_cast<const lds_u32 *>((uintptr_t)(qa + 4u)) == x;
+                        if (live && *reinterpret_cast<const lds_u32 *>((uintptr_t)(qa + 4u)) == x) {
+                            run = 1u;
+                            if (want_run)
+                                while (tile[pos + run] == x) ++run;  // (the padding ends every run)
+                        }
                     } else {  // x can only be in block jb of the row: its entries below the block's last one, in global memory
                         // (one load a level, up to six levels.  Tried: the block's entries loaded together when m <= 8 -- one round
                         // trip, seven loads a lane --, and four pivots + eight entries (row_find32_wide) for longer blocks: 12 200
@@ -629,13 +650,31 @@ tile_bloom_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
                             if (p <= len && col32[t_start + lo + p - 1u] < x) off = p;
                         }
                         pos = lo + off;
-                        hit = off < len && col32[t_start + pos] == x;
-                        if (hit) {
+                        if (off < len && col32[t_start + pos] == x) {
                             uint32_t p = pos + 1u;
-                            while (p < n && col32[t_start + p] == x) ++p;
+                            if (want_run)  // (wave-uniform: a load more for every lane that hit)
+                                while (p < n && col32[t_start + p] == x) ++p;
                             run = p - pos;
                         }
                     }
+                };
+                // rpos of the items of a task whose tile row is v's: where u sits in it -- one search a task, 64 lanes wide
+                uint32_t rpos_b = kRposAbsent;
+                if (task.mode != 0u) {
+                    uint32_t pos, run;
+                    if (whole) locate(other, mine, true, pos, run, std::true_type{});
+                    else locate(other, mine, true, pos, run, std::false_type{});
+                    if (run) rpos_b = (run <= 15u && pos < (1u << 28)) ? ((run << 28) | pos) : kRposLookup;
+                }
+                uint32_t q_n = 0;  // (wave-uniform) survivors on the stack
+                auto search = [&](uint32_t cnt, auto whole_row) {  // the top `cnt` (<= 64) of them
+                    q_n -= cnt;
+                    const uint32_t at = (q_n + (uint32_t)lane) * 2u;
+                    const uint32_t x = queue[at], f = queue[at + 1u];  // the element and its flat number
+                    const bool live = (uint32_t)lane < cnt;
+                    uint32_t pos, run;
+                    locate(x, live, task.mode != 0u, pos, run, whole_row);  // (tile row = u's: is it there; = v's: where, how often)
+                    const bool hit = run != 0u;
                     if (__builtin_amdgcn_ballot_w64(hit) == 0) return;
                     if (hit) {
                         uint32_t j = 0;  // the item of element f: the last one that starts at or before it (hits are rare: 2 %)
@@ -647,14 +686,7 @@ tile_bloom_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
                             atomicOr(&am[(idx >> 5) & 3u], 1u << (idx & 31u));
                         } else {  // this element of u's row sits at pos .. of v's row (a run: parallel edges)
                             uint32_t p = pos;
-                            if (kWhole) {
-                                do {
-                                    atomicOr(&am[(p >> 5) & 3u], 1u << (p & 31u));
-                                    ++p;
-                                } while (tile[p] == x);  // (the padding ends every run)
-                            } else {
-                                for (uint32_t k = 0; k < run && k < 128u; ++k, ++p) atomicOr(&am[(p >> 5) & 3u], 1u << (p & 31u));
-                            }
+                            for (uint32_t k = 0; k < run && k < 128u; ++k, ++p) atomicOr(&am[(p >> 5) & 3u], 1u << (p & 31u));
                         }
                     }
                 };
@@ -690,6 +722,21 @@ tile_bloom_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
                         const uint32_t bits = bloom_bits(h);
                         bw[r] = (bloom[__umulhi(h, bwords)] & bits) ^ bits;  // 0: both bits are set
                     }
+                    if (task.mode == 0u) {  // v's row streams past: the tile's own node in it is rpos of the entry (rare: 1.5 %)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const bool me = x[r] == node && (kFull || 64u * r + (uint32_t)lane < rest);
+                            if (__builtin_amdgcn_ballot_w64(me) == 0) continue;
+                            if (me) {
+                                const uint32_t f = f0 + 64u * r + (uint32_t)lane;
+                                uint32_t j = 0;
+#pragma unroll
+                                for (uint32_t step = kItems >> 1; step; step >>= 1) j = pfx[j + step] <= f ? j + step : j;
+                                atomicMin(&rp_first[j], f - pfx[j]);
+                                atomicAdd(&rp_cnt[j], 1u);
+                            }
+                        }
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         if (!kFull && 64u * r >= rest) break;  // (wave-uniform)
@@ -704,8 +751,7 @@ tile_bloom_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
                             }
                             q_n += (uint32_t)__popcll(b);
                         }
-                        if (r == 1 || r == 3)
-                            while (q_n >= 64u) drain(64u);
+                        if (q_n >= 64u) drain(64u);
                     }
                 };
                 // two sets of registers take turns: one is tested while the other's loads are on their way.  (Three sets -- two
@@ -740,9 +786,18 @@ tile_bloom_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (mine) {  // (an item without elements -- a dead end's empty row -- has an empty mask)
-                    u32x4_a16 mm = {0u, 0u, 0u, 0u};
-                    if (len_j != 0u) mm = u32x4_a16{acc[d_j][0], acc[d_j][1], acc[d_j][2], acc[d_j][3]};
+                if (mine) {  // the whole entry: {v, start(v), deg(v) | filter bit, rpos} + the mask
+                    u32x4_a16 mm = {0u, 0u, 0u, 0u};  // (an item without elements -- a dead end's empty row -- has an empty mask)
+                    uint32_t rpos = rpos_b;
+                    if (len_j != 0u) {
+                        mm = u32x4_a16{acc[d_j][0], acc[d_j][1], acc[d_j][2], acc[d_j][3]};
+                        if (task.mode == 0u) {
+                            const uint32_t cnt = rp_cnt[d_j], first = rp_first[d_j];
+                            rpos = cnt ? ((cnt <= 15u && first < (1u << 28)) ? ((cnt << 28) | first) : kRposLookup) : kRposAbsent;
+                        }
+                    }
+                    const uint32_t v_start = task.mode == 0u ? s_start : t_start, v_deg = task.mode == 0u ? s_len : n;
+                    ext[2 * (size_t)e] = u32x4_a16{task.mode == 0u ? other : node, v_start, v_deg | (v_deg > 128u ? kMaskIsFilter : 0u), rpos};
                     ext[2 * (size_t)e + 1] = mm;
                 }
                 __builtin_amdgcn_wave_barrier();  // (the next task clears acc)
