@@ -579,16 +579,21 @@ def main():
         lib.trw_profile_enable(0)
         assert torch.equal(out, walks), "counting variant of the kernel produced different walks"
         trials, fetches, tests, probes = (int(x) for x in c)
+        # the prepared graph proper (what the walks read) and the marking passes' scratch, which the torch layer gives back
+        # to the allocator when the prepare call returns
+        keep_bytes = int(lib.trw_prepare_csr_persistent_bytes(n, nnz, what))
         counters = dict(trials=trials, candidate_loads=fetches, membership_tests=tests, table_or_bisect_entries=probes,
-                        prepared_what=what, prepared_bytes=int(pbytes),
-                        prepared_bytes_per_edge=round(int(pbytes) / max(1, int(nnz)), 2))
+                        prepared_what=what, prepared_bytes=keep_bytes,
+                        prepared_bytes_per_edge=round(keep_bytes / max(1, int(nnz)), 2),
+                        prepare_scratch_bytes=int(lib.trw_prepare_csr_scratch_bytes(n, nnz, what)))
         if family in (4, 5):
             # biased_pool_kernel / biased_mask_kernel, bytes the algorithm as run must move: per walker 8 B target + 8 B row32 pair; per
             # column 8 B stored; 32 B per fat entry gathered (every accepted offset, plus candidates the table is
-            # asked about); 16 B per probe of the edge set (a probe reads a block of four 8-byte keys, 32 B of one line;
-            # half of it is counted, as when a probe was an aligned pair of 16-byte slots: the figure stays comparable
-            # with the earlier rounds' and does not grow with a layout change).
-            alg_bytes = B * 16 + 8 * B * (L + 1) + 32 * fetches + 16 * probes
+            # asked about); 32 B per probe of the edge set (a probe reads a block of four 8-byte keys, an aligned half of
+            # one line).  (Rounds 2-4 counted 16 B per probe, from when a probe was a pair of 16-byte slots: that figure is
+            # kept beside it as alg_bytes_r04_convention.)
+            alg_bytes = B * 16 + 8 * B * (L + 1) + 32 * fetches + 32 * probes
+            counters["alg_bytes_r04_convention"] = B * 16 + 8 * B * (L + 1) + 32 * fetches + 16 * probes
         else:
             # int64-API-layout bytes (with this kernel's own counts): per walker 8 B target + 8 B column 0
             # + 32 B first step; per later step 16 B row_ptr pair + 8 B stored column; 8 B per candidate entry loaded

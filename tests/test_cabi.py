@@ -100,9 +100,14 @@ def test_workspace_bytes():
     # 2^32-slot, 69 GB table until round 4)
     big = g(111_000_000, 1_711_000_000, 2)
     assert 56 * 1_711_000_000 < big < 56 * 1_711_000_000 + 10**9
-    full = g(111_000_000, 1_711_000_000, 2 | 4 | 8)
-    assert full < 64 * 1_711_000_000                                  # <= 64 bytes per edge with every mask built
-    assert g(10_000_000, 110_000_000, 2 | 4 | 8) < 64 * 110_000_000   # ... on the headline graph too
+    # with every mask built: what the walks read stays 56 bytes per edge + 4 per node; the marking passes' scratch (items
+    # for EVERY entry, the worst case, and the task records) is apart from it and can be handed in separately
+    keep, scratch = lib.trw_prepare_csr_persistent_bytes, lib.trw_prepare_csr_scratch_bytes
+    for nn, ee in ((111_000_000, 1_711_000_000), (10_000_000, 110_000_000)):
+        assert keep(nn, ee, 2 | 4 | 8) == keep(nn, ee, 2) == g(nn, ee, 2) and scratch(nn, ee, 2) == 0
+        assert g(nn, ee, 2 | 4 | 8) == keep(nn, ee, 2 | 4 | 8) + scratch(nn, ee, 2 | 4 | 8)
+        assert 8 * ee < scratch(nn, ee, 2 | 4 | 8) < 11 * ee + 8 * nn + 10**6
+        assert keep(nn, ee, 2 | 4 | 8) < 57 * ee + 4 * nn
 
 
 def test_prepared_graph_regions_are_disjoint_and_inside_the_blob():
@@ -124,6 +129,8 @@ def test_prepared_graph_regions_are_disjoint_and_inside_the_blob():
             assert (spans[3][1] == 16 * nnz) == bool(what & 1)
             assert (spans[5][1] == 32 * nnz) == bool(what & 14) and (spans[4][1] > 0) == bool(what & 14)
             assert (spans[6][1] > 0) == bool(what & 12)
+            if what & 12:                                           # the task records: scratch, behind what the walks read
+                assert spans[6][0] >= lib.trw_prepare_csr_persistent_bytes(n, nnz, what)
             live = sorted(v for v in spans.values() if v[1])
             assert all(a[0] + a[1] <= b[0] for a, b in zip(live, live[1:])), (n, nnz, what, live)
             if what & 14:

@@ -55,6 +55,12 @@ def cabi():
         L.trw_prepare_csr_bytes.restype = ctypes.c_size_t
         L.trw_prepare_csr_hip.argtypes = [vp, i64, vp, i64, i32, vp, ctypes.c_size_t, vp]
         L.trw_prepare_csr_hip.restype = ctypes.c_int
+        L.trw_prepare_csr_persistent_bytes.argtypes = [i64, i64, i32]
+        L.trw_prepare_csr_persistent_bytes.restype = ctypes.c_size_t
+        L.trw_prepare_csr_scratch_bytes.argtypes = [i64, i64, i32]
+        L.trw_prepare_csr_scratch_bytes.restype = ctypes.c_size_t
+        L.trw_prepare_csr_scratch_hip.argtypes = [vp, i64, vp, i64, i32, vp, ctypes.c_size_t, vp, ctypes.c_size_t, vp]
+        L.trw_prepare_csr_scratch_hip.restype = ctypes.c_int
         L.trw_prepare_csr_region.argtypes = [i64, i64, i32, i32, ctypes.POINTER(ctypes.c_size_t),
                                              ctypes.POINTER(ctypes.c_size_t)]
         L.trw_prepare_csr_region.restype = ctypes.c_int

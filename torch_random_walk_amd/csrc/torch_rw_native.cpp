@@ -235,19 +235,24 @@ void build_blob(PreparedGraph &entry, const torch::Tensor &rp, const torch::Tens
     for (int k = 0; k < 4; ++k) {
         const int32_t w = ladder[k];
         if (k > 0 && w == ladder[k - 1]) continue;
+        // What the walks read is kept; the marking passes' scratch (the in-lists' items, the tile pass's task records: 10 bytes
+        // per entry) is a temporary of this call -- it goes back to the allocator when the call returns, in stream order.
         const size_t bytes = elist ? trw_prepare_edge_list_bytes(nnz, n_nodes, entry.pad, w)
-                                   : trw_prepare_csr_bytes(n_nodes, nnz, w);
-        torch::Tensor blob;
+                                   : trw_prepare_csr_persistent_bytes(n_nodes, nnz, w);
+        const size_t scratch_bytes = elist ? 0 : trw_prepare_csr_scratch_bytes(n_nodes, nnz, w);
+        torch::Tensor blob, scratch;
         try {
             blob = torch::empty({(int64_t)bytes}, rp.options().dtype(torch::kUInt8));
+            if (scratch_bytes) scratch = torch::empty({(int64_t)scratch_bytes}, rp.options().dtype(torch::kUInt8));
         } catch (const c10::OutOfMemoryError &) {
             if (k == 3) throw;
             continue;  // (the allocator has already given its cached blocks back before throwing)
         }
         const int rc = elist ? trw_prepare_edge_list_hip(rp.data_ptr<int64_t>(), nnz, ci.data_ptr<int64_t>(), n_nodes,
                                                          entry.pad, w, blob.data_ptr(), bytes, stream)
-                             : trw_prepare_csr_hip(rp.data_ptr<int64_t>(), n_nodes, ci.data_ptr<int64_t>(), nnz, w,
-                                                   blob.data_ptr(), bytes, stream);
+                             : trw_prepare_csr_scratch_hip(rp.data_ptr<int64_t>(), n_nodes, ci.data_ptr<int64_t>(), nnz, w,
+                                                           blob.data_ptr(), bytes, scratch_bytes ? scratch.data_ptr() : nullptr,
+                                                           scratch_bytes, stream);
         TORCH_CHECK(rc == TRW_OK, "torch_rw prepare failed (", rc, "): ", trw_last_error());
         trw_event_destroy(entry.ready);
         entry.ready = trw_event_record(stream);
@@ -433,13 +438,16 @@ torch::Tensor walk_ex(const torch::Tensor &row_ptr, const torch::Tensor &col_idx
         const size_t call_bytes =
             trw_walk_csr_prepared_workspace_bytes(n_walkers, (int32_t)walk_length, p, q, (int32_t)rng_mode);
         const int32_t ladder[3] = {needed, needed > 0 ? 0 : needed, needed >= 0 ? TRW_PREP_ORDER_ONLY : needed};
-        torch::Tensor blob;
+        torch::Tensor blob, scratch;
         int32_t what = needed;
+        size_t scratch_bytes = 0;
         for (int k = 0; k < 3; ++k) {
             if (k > 0 && ladder[k] == ladder[k - 1]) continue;
             what = ladder[k];
             try {
-                blob = torch::empty({(int64_t)trw_prepare_csr_bytes(n_nodes, nnz, what)}, rp.options().dtype(torch::kUInt8));
+                blob = torch::empty({(int64_t)trw_prepare_csr_persistent_bytes(n_nodes, nnz, what)}, rp.options().dtype(torch::kUInt8));
+                scratch_bytes = trw_prepare_csr_scratch_bytes(n_nodes, nnz, what);
+                if (scratch_bytes) scratch = torch::empty({(int64_t)scratch_bytes}, rp.options().dtype(torch::kUInt8));
                 break;
             } catch (const c10::OutOfMemoryError &) {
                 if (k == 2) throw;
@@ -447,8 +455,8 @@ torch::Tensor walk_ex(const torch::Tensor &row_ptr, const torch::Tensor &col_idx
         }
         workspace = torch::empty({(int64_t)call_bytes}, rp.options().dtype(torch::kUInt8));
         pybind11::gil_scoped_release nogil;
-        rc = trw_prepare_csr_hip(rp.data_ptr<int64_t>(), n_nodes, ci.data_ptr<int64_t>(), nnz, what, blob.data_ptr(),
-                                 (size_t)blob.numel(), hs);
+        rc = trw_prepare_csr_scratch_hip(rp.data_ptr<int64_t>(), n_nodes, ci.data_ptr<int64_t>(), nnz, what, blob.data_ptr(),
+                                         (size_t)blob.numel(), scratch_bytes ? scratch.data_ptr() : nullptr, scratch_bytes, hs);
         if (rc == TRW_OK)
             rc = trw_walk_csr_prepared_hip(blob.data_ptr(), (size_t)blob.numel(), what, rp.data_ptr<int64_t>(), n_nodes,
                                            ci.data_ptr<int64_t>(), nnz, tg.data_ptr<int64_t>(), n_walkers, walker_base, p,
