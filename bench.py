@@ -99,6 +99,10 @@ def main():
                     help="N>1, CSR walks: row chunks per step; each chunk's transfer starts when its walk is done")
     ap.add_argument("--wire", default="auto", choices=["auto", "int64"],
                     help="N>1: what the row blocks travel as (auto: uint32 while node ids fit, widened on arrival)")
+    ap.add_argument("--result", default="int64", choices=["int64", "int32"],
+                    help="N>1, CSR walks: dtype of the gathered [N, L+1] result on the root.  int32 (uint32 bit patterns: node "
+                         "ids are < 2^32) = narrow rows end to end: every rank's walk kernel writes them, the peers' blocks land "
+                         "in the result, nothing is widened.  The N = 1 line is always int64 (the reference's rows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo is a dry-run aid for the N>1 control flow on a single-GPU box (all ranks share "
@@ -234,15 +238,20 @@ def main():
     # transport as soon as it is enqueued: the gather of a step overlaps the rest of the SAME step's walk, and the
     # next step's.  Two sets of buffers alternate because step k's blocks are still landing while step k+1 walks.
     chunks = max(1, args.gather_chunks) if (gather and csr) else 1
+    # narrow rows end to end (--result int32): the root's result is int32, its own walk writes narrow rows into it and the
+    # peers' blocks land in it -- no widening pass on the root (22.7 GB in, 45.4 GB out per step at N = 8, beside its walk)
+    result32 = gather and csr and wire32 and args.result == "int32"
+    # a peer's CSR walk writes its wire rows itself (walk_ex(out=<int32>)): no int64 block, no narrowing pass
+    direct32 = gather and csr and wire32
     side = torch.cuda.Stream(device=dev) if gather else None
     if gather and rank == 0:
-        fulls = [torch.empty((world * B, cols), dtype=torch.int64, device=dev) for _ in range(2)]
-        if wire32 or dry:
+        fulls = [torch.empty((world * B, cols), dtype=torch.int32 if result32 else torch.int64, device=dev) for _ in range(2)]
+        if (wire32 and not result32) or dry:
             lands = [torch.empty((world * B, cols), dtype=torch.int32 if wire32 else torch.int64,
                                  device="cpu" if dry else dev) for _ in range(2)]
         full = fulls[0]
     elif gather:
-        if csr:
+        if csr and not direct32:
             fulls = [torch.empty((B, cols), dtype=torch.int64, device=dev) for _ in range(2)]
         if wire32:
             wires = [torch.empty((B, cols), dtype=torch.int32, device=dev) for _ in range(2)]
@@ -286,7 +295,7 @@ def main():
                     if land is None:
                         continue
                     got = land[lo_:hi_].to(dev, non_blocking=True) if dry else land[lo_:hi_]
-                    if wire32:
+                    if wire32 and not result32:
                         rw.widen_rows(got, out=dst[lo_:hi_])
                     else:
                         dst[lo_:hi_].copy_(got)
@@ -309,7 +318,7 @@ def main():
         if rank == 0:
             full = fulls[k % 2]
             main.wait_stream(side)   # step k-2's blocks were widened out of / into these two buffers on the side stream
-        mine = fulls[k % 2][:B] if (csr or rank == 0) else None
+        mine = (wires[k % 2] if (direct32 and rank != 0) else fulls[k % 2][:B]) if (csr or rank == 0) else None
         for c in range(chunks):
             c_lo, c_hi = chunk_bounds(0, B, chunks, c)
             if c_hi <= c_lo:
@@ -337,7 +346,7 @@ def main():
                     pend.ev_first = ev1
                 pend.ev_walked = ev1
             else:
-                w = rw.narrow_rows(blk, out=wires[k % 2][c_lo:c_hi]) if wire32 else blk
+                w = blk if (direct32 or not wire32) else rw.narrow_rows(blk, out=wires[k % 2][c_lo:c_hi])
                 if dry:
                     w = w.cpu()
                 pend.keep.append(w)
@@ -434,7 +443,9 @@ def main():
         kernel_ms = [per_step[k] for k in sorted(per_step)]
         g_ms = [w.ev_first.elapsed_time(w.ev_done) for w in timed_steps] if rank == 0 else []
         g_tail = [max(0.0, w.ev_walked.elapsed_time(w.ev_done)) for w in timed_steps] if rank == 0 else []
-        multi = dict(wire_dtype="uint32" if wire32 else "int64", bytes_per_rank=B * cols * wire_bytes,
+        multi = dict(wire_dtype="uint32" if wire32 else "int64", result_dtype="int32" if result32 else "int64",
+                     rows_narrowed_by="walk kernel" if direct32 else ("narrowing pass" if wire32 else None),
+                     bytes_per_rank=B * cols * wire_bytes,
                      gather_chunks=chunks, backend=args.backend,
                      gather_ms=sum(g_ms) / max(1, len(g_ms)),
                      gather_after_root_walk_ms=sum(g_tail) / max(1, len(g_tail)),
@@ -448,14 +459,16 @@ def main():
         multi["walk_kernel_ms"] = float(t[1].item())   # max over ranks of the mean walk time per step
 
     # ---- device-side status of the last step (validity of what was timed) -------------------
+    def as_int64(t):   # narrow rows (uint32 bit patterns in an int32 tensor) as the reference's int64 rows
+        return rw.widen_rows(t.contiguous()) if t.dtype == torch.int32 else t
     if not args.steady:
         chk = walk(targets[:1024], walker_base, True)
-        assert torch.equal(chk, walks[:1024]), "timed output differs from a checked re-run"
+        assert torch.equal(chk, as_int64(walks[:1024])), "timed output differs from a checked re-run"
     if gather and rank == 0:
         # the gathered blocks are exactly what each rank's global walker indices produce
         for r in range(world):
             blk = walk(targets[:256], r * B, True)
-            assert torch.equal(blk.to(full.device), full[r * B: r * B + 256]), "gathered block %d is wrong" % r
+            assert torch.equal(blk.to(full.device), as_int64(full[r * B: r * B + 256])), "gathered block %d is wrong" % r
 
     # ---- algorithmic bytes of one launch ----------------------------------------
     counters = None
@@ -488,7 +501,10 @@ def main():
         stw = (ctypes.c_int64 * 4)()
         assert lib.trw_walk_status(ws.data_ptr(), stream, stw) == 0
         lib.trw_profile_enable(0)
-        assert torch.equal(out, walks), "counting variant of the kernel produced different walks"
+        if not torch.equal(out, as_int64(walks)):
+            bad = (out != as_int64(walks)).any(1).nonzero().flatten()
+            raise AssertionError("counting variant of the kernel produced different walks: %d rows differ, first %s"
+                                 % (bad.numel(), bad[:8].tolist()))
         trials, fetches, tests, probes = (int(x) for x in c)
         if int(stw[3]) == 5:
             kernel_name = "elist_pool_kernel"
@@ -543,7 +559,7 @@ def main():
         counters = dict(prepared_what=what)
         stw = (ctypes.c_int64 * 4)()
         assert lib.trw_walk_status(ws.data_ptr(), stream, stw) == 0 and stw[0] == 0
-        assert torch.equal(out, walks), "direct C-ABI call produced different walks"
+        assert torch.equal(out, as_int64(walks)), "direct C-ABI call produced different walks"
         kernel_name = {0: "uniform_glibc_wide_kernel", 1: "uniform_glibc_rows_kernel<false>",
                        3: "uniform_glibc_rows_kernel<true>"}[int(stw[3])]
         blob = None
@@ -577,7 +593,10 @@ def main():
         kernel_name = {0: "biased_walker_wide_kernel", 1: "biased_walker_kernel", 2: "biased_hash_kernel",
                        4: "biased_mask_kernel", 5: "biased_pool_kernel"}[family]
         lib.trw_profile_enable(0)
-        assert torch.equal(out, walks), "counting variant of the kernel produced different walks"
+        if not torch.equal(out, as_int64(walks)):
+            bad = (out != as_int64(walks)).any(1).nonzero().flatten()
+            raise AssertionError("counting variant of the kernel produced different walks: %d rows differ, first %s"
+                                 % (bad.numel(), bad[:8].tolist()))
         trials, fetches, tests, probes = (int(x) for x in c)
         # the prepared graph proper (what the walks read) and the marking passes' scratch, which the torch layer gives back
         # to the allocator when the prepare call returns
@@ -743,7 +762,7 @@ def main():
         elif uniform:
             ref_w = O.walk(rp_h, ci_h, tg_cpu[:m].numpy(), p, q, L, args.seed, rng_mode=O.RNG_GLIBC_INDEXED,
                            walker_base=walker_base)
-            assert (ref_w == walks[:m].cpu().numpy()).all(), "GPU rows differ from the oracle"
+            assert (ref_w == as_int64(walks[:m]).cpu().numpy()).all(), "GPU rows differ from the oracle"
         else:
             # SURVEY 8(d) accounting: what the REFERENCE's loop reads for the same walks (a candidate on every
             # trial, is_neighbor on every candidate != t), from the oracle's counters on walkers 0..m-1 -- the
@@ -751,7 +770,7 @@ def main():
             import numpy as np
             ref_w, cnt = O.walk(rp_h, ci_h, tg_cpu[:m].numpy(), p, q, L, args.seed, rng_mode=O.RNG_WALKER,
                                 walker_base=walker_base, return_counters=True)
-            assert (ref_w == walks[:m].cpu().numpy()).all(), "GPU rows differ from the oracle"
+            assert (ref_w == as_int64(walks[:m]).cpu().numpy()).all(), "GPU rows differ from the oracle"
             scale = B / m
             deg_h = (rp_h[1:] - rp_h[:-1])
             t_nodes = ref_w[:, :-2].reshape(-1)            # the `t` of every step >= 2

@@ -83,6 +83,7 @@ extern "C" {
 #define TRW_ST_TRIAL_CAP  8    /* 2^20 consecutive rejections at one step; the
                                   candidate was force-accepted (the reference
                                   would still be spinning, rw_cpu.cpp:166)         */
+#define TRW_E_UNSUPPORTED (-7) /* narrow rows asked of a call shape whose kernel family writes int64 only */
 
 int trw_version(void);
 
@@ -203,6 +204,22 @@ int trw_walk_csr_prepared_hip(const void *prepared, size_t prepared_bytes, int32
                               const int64_t *targets, int64_t n_walkers, int64_t walker_base,
                               double p, double q, int32_t walk_length, int32_t seed, int32_t rng_mode,
                               int64_t *out, void *workspace, size_t workspace_bytes, void *hip_stream);
+
+/*
+ * The same walk with NARROW rows: out32 [n_walkers][walk_length+1] uint32 row-major -- the wire format of the multi-GPU
+ * gather (node ids are < n_nodes <= 2^32), written by the walk kernel itself instead of by a pass over int64
+ * rows (trw_rows_narrow_hip).  Same walks, value for value.  Only the production kernels write them: the reference-exact
+ * uniform walk over the uint32 shadow, and the node2vec walk on the per-walker stream over a graph prepared with
+ * TRW_PREP_BIASED (sorted or unsorted rows); any other call shape -- the serial replay, the uniform walk on the
+ * per-walker stream, graphs on the int64 kernels, 2^32 walkers or more -- returns TRW_E_UNSUPPORTED and writes no row: the
+ * caller walks int64 rows and narrows them.
+ */
+int trw_walk_csr_prepared_u32_hip(const void *prepared, size_t prepared_bytes, int32_t what,
+                                  const int64_t *row_ptr, int64_t n_nodes,
+                                  const int64_t *col_idx, int64_t nnz,
+                                  const int64_t *targets, int64_t n_walkers, int64_t walker_base,
+                                  double p, double q, int32_t walk_length, int32_t seed, int32_t rng_mode,
+                                  uint32_t *out32, void *workspace, size_t workspace_bytes, void *hip_stream);
 
 /*
  * The host leg of the same walk.  Replaces the reference's

@@ -163,3 +163,20 @@ def test_c_abi_direct_call():
     rc = L.trw_walk_csr_cpu(rp0.ctypes.data, 2, ci0.ctypes.data, 1, tg0.ctypes.data, 2, 5, 0.5, 2.0, 4, 1, 1,
                             out.ctypes.data, 1)
     assert rc == -4                                                  # a serial chain has no shards
+
+
+def test_narrow_rows_from_the_cpu_leg():
+    """walk_ex(out=<int32 tensor>): narrow rows -- the uint32 bit patterns of the same node ids -- on CPU tensors too
+    (walked as int64, narrowed on the way out), and dist.wire-format round trip gives the int64 rows back."""
+    from torch_rw import rw
+    rp, ci = random_graph(300, 5, 2)
+    tg = np.random.default_rng(2).integers(0, 300, 123)
+    t_rp, t_ci, t_tg = (torch.as_tensor(a) for a in (rp, ci, tg))
+    for p, q, mode in ((1.0, 1.0, rw.RNG_GLIBC), (0.25, 4.0, rw.RNG_WALKER)):
+        wide = rw.walk_ex(t_rp, t_ci, t_tg, p, q, 9, 3, rng_mode=mode)
+        out = torch.empty((123, 10), dtype=torch.int32)
+        got = rw.walk_ex(t_rp, t_ci, t_tg, p, q, 9, 3, rng_mode=mode, out=out)
+        assert got.data_ptr() == out.data_ptr() and got.dtype == torch.int32
+        assert torch.equal(rw.widen_rows(got), wide) and torch.equal(got, rw.narrow_rows(wide))
+    with pytest.raises(RuntimeError):
+        rw.walk_ex(t_rp, t_ci, t_tg, 1.0, 1.0, 9, 3, out=torch.empty((123, 10), dtype=torch.int16))

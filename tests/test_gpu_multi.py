@@ -33,14 +33,19 @@ sys.path.insert(0, {root!r})
 rank, world, port, gather, p, q, outdir = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], \
     float(sys.argv[5]), float(sys.argv[6]), sys.argv[7]
 wire, chunks = sys.argv[8], int(sys.argv[9])
+narrow_result = wire == "narrow"
 from torch_random_walk_amd import graphs
 from torch_random_walk_amd.dist import walk_sharded
 torch.cuda.set_device(0)                      # one card on this box: both ranks share it
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
 rp, ci = graphs.rmat(3000, 30000, seed=4, device="cuda:0")
 tg = torch.arange(3000, device="cuda:0").repeat(7)[:20001]        # not divisible by the world size
-res = walk_sharded(rp, ci, tg, p, q, 33, 42, gather=gather, wire=wire, chunks=chunks)   # walk_fn=None: the HIP path
-assert res.is_cuda and res.dtype == torch.int64
+res = walk_sharded(rp, ci, tg, p, q, 33, 42, gather=gather, wire="auto" if narrow_result else wire, chunks=chunks,
+                   result_dtype=torch.int32 if narrow_result else torch.int64)   # walk_fn=None: the HIP path
+assert res.is_cuda and res.dtype == (torch.int32 if narrow_result else torch.int64)
+if narrow_result:          # narrow rows end to end (written by the walk kernels, landed in the result): the same ids
+    from torch_rw import rw
+    res = rw.widen_rows(res.contiguous())
 torch.save(res.cpu(), os.path.join(outdir, "r%d.pt" % rank))
 dist.barrier()
 dist.destroy_process_group()
@@ -48,13 +53,15 @@ dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("gather,wire,chunks", [("root", "auto", 1), ("all", "auto", 1), ("root", "int64", 1),
-                                                ("root", "uint32", 4), ("all", "int64", 1)])
+                                                ("root", "uint32", 4), ("all", "int64", 1),
+                                                ("root", "narrow", 1), ("root", "narrow", 4), ("all", "narrow", 1)])
 @pytest.mark.parametrize("p,q", [(1.0, 1.0), (0.25, 4.0)])
 def test_sharded_walk_two_ranks_on_the_hip_path(tmp_path, gather, wire, chunks, p, q):
     """world_size 2, both ranks on cuda:0 with the HIP kernels doing the walking (the gloo transport
     stages the blocks through the host; under RCCL the same code hands device tensors over): the assembled
     result equals the single call and the oracle -- whether the blocks travel as int64 or in the uint32 wire
-    format (narrowed and widened by the library's kernels), in one piece or in four row chunks."""
+    format (narrowed and widened by the library's kernels), in one piece or in four row chunks -- or, "narrow"
+    (result_dtype=torch.int32), as narrow rows end to end: written by the walk kernels, landed in an int32 result."""
     from torch_random_walk_amd import graphs
     from torch_rw import rw
     script = tmp_path / "worker.py"

@@ -611,3 +611,62 @@ def test_walk_into_a_callers_tensor(rw):
         rw.walk_ex(d_rp, d_ci, d_tg, 1.0, 1.0, 20, 10, out=torch.empty((3000, 20), dtype=torch.int64, device=DEV))
     with pytest.raises(RuntimeError, match="out must be"):
         rw.walk_ex(d_rp, d_ci, d_tg, 1.0, 1.0, 20, 10, out=torch.empty((3000, 42), dtype=torch.int64, device=DEV)[:, ::2])
+
+
+def test_narrow_rows_from_every_kernel_family():
+    """walk_ex(out=<int32 tensor>): the uint32 bit patterns of the SAME node ids the int64 call returns.  The production
+    kernels write them themselves -- the reference-exact uniform walk (compact shadow and 16-byte entries), the walker
+    pool (sorted rows), the state machine (unsorted rows) --; the families that write int64 only (the serial replay, the
+    uniform walk on the per-walker stream, an unprepared small batch) go through a narrowing pass.  Start nodes out of
+    range fill their row and report, as in the int64 call."""
+    from torch_rw import rw
+    from torch_random_walk_amd import _native
+    rng = np.random.default_rng(12)
+    rp, ci = hub_graph(4000, 3)
+    urp, uci = random_graph(4000, 6, 3, sort_rows=False)
+    cases = []
+    for name, (a, b) in (("sorted", (rp, ci)), ("unsorted", (urp, uci))):
+        d_rp, d_ci = (torch.as_tensor(x).to(DEV) for x in (a, b))
+        for N, L, p, q, mode in ((50000, 30, 1.0, 1.0, rw.RNG_GLIBC),      # uniform rows kernel (fat entries: steps > nnz)
+                                 (777, 13, 1.0, 1.0, rw.RNG_GLIBC),        # ... compact shadow, ragged tail
+                                 (50000, 30, 0.25, 4.0, rw.RNG_WALKER),    # pool kernel / state machine on unsorted rows
+                                 (300, 9, 0.25, 4.0, rw.RNG_WALKER),       # small batch, unprepared: bisection kernel
+                                 (100, 20, 0.7, 0.5, rw.RNG_GLIBC),        # serial replay
+                                 (5000, 8, 1.0, 1.0, rw.RNG_WALKER)):      # uniform on the per-walker stream
+            cases.append((name, d_rp, d_ci, N, L, p, q, mode))
+    for name, d_rp, d_ci, N, L, p, q, mode in cases:
+        rw.clear_cache()
+        tg = torch.as_tensor(rng.integers(0, 4000, N)).to(DEV)
+        for rep in range(2):                        # (second pass: over the cached prepared graph)
+            wide = rw.walk_ex(d_rp, d_ci, tg, p, q, L, 5, walker_base=rep * 1000 if mode == rw.RNG_WALKER or p == 1.0 else 0,
+                              rng_mode=mode)
+            out = torch.full((N, L + 1), -7, dtype=torch.int32, device=DEV)
+            got = rw.walk_ex(d_rp, d_ci, tg, p, q, L, 5, walker_base=rep * 1000 if mode == rw.RNG_WALKER or p == 1.0 else 0,
+                             rng_mode=mode, out=out)
+            assert got.data_ptr() == out.data_ptr()
+            assert torch.equal(rw.widen_rows(got), wide), (name, N, L, p, q, mode, rep)
+    # the C ABI says which call shapes the walk kernel itself writes narrow rows for
+    L_ = _native.cabi()
+    L_.trw_walk_csr_prepared_u32_hip.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64,
+                                                 ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                                 ctypes.c_double, ctypes.c_double, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    d_rp, d_ci = (torch.as_tensor(x).to(DEV) for x in (rp, ci))
+    n, nnz = 4000, len(ci)
+    stream = torch.cuda.current_stream().cuda_stream
+    tg = torch.arange(2000, device=DEV)
+    out32 = torch.empty((2000, 11), dtype=torch.int32, device=DEV)
+    for what, p, q, mode, want in ((2, 0.25, 4.0, 2, 0), (0, 1.0, 1.0, 1, 0), (1, 1.0, 1.0, 1, 0),
+                                   (0, 0.25, 4.0, 2, -7), (2, 0.25, 4.0, 1, -7), (0, 1.0, 1.0, 2, -7), (-1, 0.25, 4.0, 2, -7)):
+        pb = L_.trw_prepare_csr_bytes(n, nnz, what)
+        blob = torch.empty(pb, dtype=torch.uint8, device=DEV)
+        assert L_.trw_prepare_csr_hip(d_rp.data_ptr(), n, d_ci.data_ptr(), nnz, what, blob.data_ptr(), pb, stream) == 0
+        N = 2000 if mode != 1 or p == 1.0 else 50          # (the serial replay: a small batch, walker_base 0)
+        wb = L_.trw_walk_csr_prepared_workspace_bytes(N, 10, p, q, mode)
+        ws = torch.empty(wb, dtype=torch.uint8, device=DEV)
+        rc = L_.trw_walk_csr_prepared_u32_hip(blob.data_ptr(), pb, what, d_rp.data_ptr(), n, d_ci.data_ptr(), nnz, tg.data_ptr(), N, 0,
+                                              p, q, 10, 3, mode, out32.data_ptr(), ws.data_ptr(), wb, stream)
+        assert rc == want, (what, p, q, mode, rc, L_.trw_last_error())
+        if rc == 0:
+            wide = rw.walk_ex(d_rp, d_ci, tg[:N], p, q, 10, 3, rng_mode=mode)
+            assert torch.equal(rw.widen_rows(out32[:N].contiguous()), wide)

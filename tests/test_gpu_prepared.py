@@ -535,6 +535,35 @@ def test_unsorted_rows_with_marks_write_nothing_outside_the_prepared_blob(rw):
         assert (out.cpu().numpy() == O.walk(rp, ci, tg, 0.25, 4.0, 12, 3, rng_mode=O.RNG_WALKER)).all()
 
 
+def test_prepare_is_repeatable_entry_for_entry(rw):
+    """The marking passes take their tasks and in-list places in whatever order the hardware hands them out; the 32-byte
+    entries must not notice.  Five prepares of one graph -- hubs on both sides of the 4 096-entry tile, so that whole-row
+    tiles, sampled ones and the one-wave kernel all run -- into buffers poisoned differently each time: identical
+    entries.  (Round 5 caught a survivor-search that took a lane beyond the survivors for a hit when the LDS it read
+    happened to hold 0xFFFFFFFF: one wrong mask bit in a prepare out of a dozen, found by bench.py's re-walk check.)"""
+    from torch_random_walk_amd import _native
+    L = _native.cabi()
+    n = 60000
+    rp, ci = _skewed_graph(n, 900_000, 9, hubs=((2, 30000), (5, 9000), (9, 4300), (10, 4200), (31, 4100), (50, 2000), (64, 600)))
+    nnz = len(ci)
+    d_rp, d_ci = _dev(rp, ci)
+    stream = torch.cuda.current_stream().cuda_stream
+    off, size = ctypes.c_size_t(), ctypes.c_size_t()
+    assert L.trw_prepare_csr_region(n, nnz, 14, 5, ctypes.byref(off), ctypes.byref(size)) == 0
+    pb = L.trw_prepare_csr_bytes(n, nnz, 14)
+    ref = None
+    for r in range(5):
+        blob = torch.full((pb,), (0x33 * (r + 1)) & 0xFF, dtype=torch.uint8, device=DEV)
+        assert L.trw_prepare_csr_hip(d_rp.data_ptr(), n, d_ci.data_ptr(), nnz, 14, blob.data_ptr(), pb, stream) == 0
+        torch.cuda.synchronize()
+        ext = blob[off.value:off.value + size.value].view(torch.int32).view(nnz, 8).clone()
+        if ref is None:
+            ref = ext
+        else:
+            bad = (ext != ref).any(1).nonzero().flatten()
+            assert bad.numel() == 0, (r, bad[:5].tolist(), ext[bad[:2]].tolist(), ref[bad[:2]].tolist())
+
+
 def test_tile_pass_at_every_boundary_of_its_layout(rw):
     """Rows of exactly the lengths at which the marking passes change their ways -- 8 | 9 (the owning thread / the tile pass),
     32 | 33, 63..65 (one group of lanes / two), 127..129 (exact mask / filter), 255..257 and 1 023..1 025 (the caps),

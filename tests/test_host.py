@@ -98,7 +98,7 @@ def _free_port():
     return port
 
 
-def _gloo_worker(rank, world, port, gather, p, q, outdir, wire="auto", chunks=1):
+def _gloo_worker(rank, world, port, gather, p, q, outdir, wire="auto", chunks=1, narrow_result=False):
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
     from torch_random_walk_amd import graphs
@@ -112,25 +112,32 @@ def _gloo_worker(rank, world, port, gather, p, q, outdir, wire="auto", chunks=1)
         return torch.from_numpy(O.walk(row_ptr.numpy(), col_idx.numpy(), targets.numpy(), p, q, walk_length, seed,
                                        rng_mode=mode, walker_base=walker_base))
 
-    res = walk_sharded(rp, ci, tg, p, q, 11, 42, gather=gather, walk_fn=oracle_walk, wire=wire, chunks=chunks)
-    assert res.dtype == torch.int64
+    res = walk_sharded(rp, ci, tg, p, q, 11, 42, gather=gather, walk_fn=oracle_walk, wire=wire, chunks=chunks,
+                       result_dtype=torch.int32 if narrow_result else torch.int64)
+    assert res.dtype == (torch.int32 if narrow_result else torch.int64)
+    if narrow_result:      # narrow rows end to end: the uint32 bit patterns of the same node ids
+        from torch_rw import rw
+        res = rw.widen_rows(res.contiguous())
     torch.save(res, os.path.join(outdir, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("gather,wire,chunks", [("root", "auto", 1), ("all", "auto", 1), ("root", "int64", 1),
-                                                ("root", "uint32", 3), ("all", "int64", 1), ("root", "int64", 300)])
+                                                ("root", "uint32", 3), ("all", "int64", 1), ("root", "int64", 300),
+                                                ("root", "narrow", 1), ("root", "narrow", 3), ("all", "narrow", 1)])
 @pytest.mark.parametrize("p,q", [(1.0, 1.0), (0.25, 4.0)])
 def test_sharded_walk_equals_single_shot_gloo(tmp_path, gather, wire, chunks, p, q):
     """world_size-2 gloo run of the shard + gather logic -- both wire formats (uint32 narrowed / widened by the
     library's host legs here, int64), the gather in one piece and in row chunks (300 chunks of a 258-row block: some
     are empty) -- the per-shard compute is the oracle here (no GPU in this tier); the same test runs on the HIP path
-    under -m gpu."""
+    under -m gpu.  "narrow": result_dtype=torch.int32 -- narrow rows end to end, nothing widened on the way."""
     import torch.multiprocessing as mp
     from torch_random_walk_amd import graphs
     port = _free_port()
-    mp.spawn(_gloo_worker, args=(2, port, gather, p, q, str(tmp_path), wire, chunks), nprocs=2, join=True)
+    narrow_result = wire == "narrow"
+    mp.spawn(_gloo_worker, args=(2, port, gather, p, q, str(tmp_path), "auto" if narrow_result else wire, chunks, narrow_result),
+             nprocs=2, join=True)
     rp, ci = graphs.rmat(300, 2000, seed=4)
     tg = torch.arange(300).repeat(2)[:517]
     mode = O.RNG_GLIBC_SEQ if (p == 1.0 and q == 1.0) else O.RNG_WALKER

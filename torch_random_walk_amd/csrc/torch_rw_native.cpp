@@ -104,12 +104,19 @@ torch::Tensor walk_cpu_leg(const torch::Tensor &row_ptr, const torch::Tensor &co
     const auto ci = col_idx.contiguous();
     const auto tg = target_nodes.contiguous();
     const int64_t n_walkers = tg.numel();
-    torch::Tensor walks;
+    torch::Tensor walks, narrow;  // (an int32 `out`: narrow rows -- walked as int64 rows here, narrowed on the way out)
     if (out.has_value() && out->defined()) {
         walks = *out;
-        TORCH_CHECK(walks.scalar_type() == torch::kInt64 && !walks.is_cuda() && walks.is_contiguous() &&
-                        walks.dim() == 2 && walks.size(0) == n_walkers && walks.size(1) == walk_length + 1,
-                    "out must be a contiguous int64 [len(target_nodes), walk_length + 1] tensor on the inputs' device");
+        TORCH_CHECK((walks.scalar_type() == torch::kInt64 || walks.scalar_type() == torch::kInt32) && !walks.is_cuda() &&
+                        walks.is_contiguous() && walks.dim() == 2 && walks.size(0) == n_walkers &&
+                        walks.size(1) == walk_length + 1,
+                    "out must be a contiguous int64 (or, for narrow rows, int32) [len(target_nodes), walk_length + 1] tensor "
+                    "on the inputs' device");
+        if (walks.scalar_type() == torch::kInt32) {
+            TORCH_CHECK(rp.numel() - 1 <= (int64_t(1) << 32), "narrow rows hold node ids below 2^32");
+            narrow = walks;
+            walks = torch::empty({n_walkers, walk_length + 1}, rp.options());
+        }
     } else {
         walks = torch::empty({n_walkers, walk_length + 1}, rp.options());  // rw_cpu.cpp:216-217
     }
@@ -122,6 +129,12 @@ torch::Tensor walk_cpu_leg(const torch::Tensor &row_ptr, const torch::Tensor &co
                               (int32_t)seed, (int32_t)rng_mode, walks.data_ptr<int64_t>(), threads);
     }
     TORCH_CHECK(rc == TRW_OK, "torch_rw walk failed (", rc, "): ", trw_last_error());
+    if (narrow.defined()) {
+        int64_t overflow = 0;
+        rc = trw_rows_narrow_cpu(walks.data_ptr<int64_t>(), walks.numel(), (uint32_t *)narrow.data_ptr<int32_t>(), &overflow);
+        TORCH_CHECK(rc == TRW_OK, "torch_rw narrow_rows failed (", rc, "): ", trw_last_error());
+        return narrow;
+    }
     return walks;
 }
 
@@ -394,15 +407,23 @@ torch::Tensor walk_ex(const torch::Tensor &row_ptr, const torch::Tensor &col_idx
     const int64_t n_walkers = tg.numel();
 
     // rw_cuda.cu:201-203: a fresh [N, L+1] int64 tensor on the inputs' device, unless the caller brought one
+    // ... or NARROW rows: an int32 `out` takes the uint32 bit patterns of the node ids (the wire format of the multi-GPU
+    // gather), written by the walk kernel itself where the production kernels run, by a narrowing pass over int64 rows
+    // otherwise -- the same values either way.
     torch::Tensor walks;
+    const bool narrow_out = out.has_value() && out->defined() && out->scalar_type() == torch::kInt32;
     if (out.has_value() && out->defined()) {
         walks = *out;
-        TORCH_CHECK(walks.scalar_type() == torch::kInt64 && walks.device() == rp.device() && walks.is_contiguous() &&
-                        walks.dim() == 2 && walks.size(0) == n_walkers && walks.size(1) == walk_length + 1,
-                    "out must be a contiguous int64 [len(target_nodes), walk_length + 1] tensor on the inputs' device");
+        TORCH_CHECK((walks.scalar_type() == torch::kInt64 || narrow_out) && walks.device() == rp.device() &&
+                        walks.is_contiguous() && walks.dim() == 2 && walks.size(0) == n_walkers &&
+                        walks.size(1) == walk_length + 1,
+                    "out must be a contiguous int64 (or, for narrow rows, int32) [len(target_nodes), walk_length + 1] tensor "
+                    "on the inputs' device");
+        TORCH_CHECK(!narrow_out || n_nodes <= (int64_t(1) << 32), "narrow rows hold node ids below 2^32");
     } else {
         walks = torch::empty({n_walkers, walk_length + 1}, rp.options());
     }
+    if (narrow_out && n_walkers == 0) return walks;
 
     void *const hs = (void *)stream.stream();
     // what a call of this shape is worth preparing; < 0: it runs the int64 kernels and wants no shadow at all
@@ -419,6 +440,26 @@ torch::Tensor walk_ex(const torch::Tensor &row_ptr, const torch::Tensor &col_idx
         prepared = prepared_for(rp, ci, needed, biased_parallel, false, stream, 0, 0,
                                 uniform_exact ? n_walkers * walk_length : 0, biased_parallel ? n_walkers * walk_length : 0);
 
+    // the walk over a prepared graph, into `walks`: narrow rows from the kernel where its family writes them, from a
+    // narrowing pass over int64 rows where it does not (the serial replay, graphs on the int64 kernels, ...)
+    torch::Tensor wide;
+    auto run_walk = [&](const void *blob_ptr, size_t blob_bytes, int32_t what_built, void *ws_ptr, size_t ws_size) {
+        int r = TRW_E_UNSUPPORTED;
+        if (narrow_out)
+            r = trw_walk_csr_prepared_u32_hip(blob_ptr, blob_bytes, what_built, rp.data_ptr<int64_t>(), n_nodes,
+                                              ci.data_ptr<int64_t>(), nnz, tg.data_ptr<int64_t>(), n_walkers, walker_base, p, q,
+                                              (int32_t)walk_length, (int32_t)seed, (int32_t)rng_mode,
+                                              (uint32_t *)walks.data_ptr<int32_t>(), ws_ptr, ws_size, hs);
+        if (r != TRW_E_UNSUPPORTED) return r;
+        if (narrow_out) wide = torch::empty({n_walkers, walk_length + 1}, rp.options());
+        r = trw_walk_csr_prepared_hip(blob_ptr, blob_bytes, what_built, rp.data_ptr<int64_t>(), n_nodes, ci.data_ptr<int64_t>(),
+                                      nnz, tg.data_ptr<int64_t>(), n_walkers, walker_base, p, q, (int32_t)walk_length,
+                                      (int32_t)seed, (int32_t)rng_mode,
+                                      narrow_out ? wide.data_ptr<int64_t>() : walks.data_ptr<int64_t>(), ws_ptr, ws_size, hs);
+        if (r == TRW_OK && narrow_out)
+            r = trw_rows_narrow_hip(wide.data_ptr<int64_t>(), wide.numel(), (uint32_t *)walks.data_ptr<int32_t>(), nullptr, hs);
+        return r;
+    };
     torch::Tensor workspace;
     int rc;
     if (prepared.valid) {
@@ -426,11 +467,7 @@ torch::Tensor walk_ex(const torch::Tensor &row_ptr, const torch::Tensor &col_idx
             trw_walk_csr_prepared_workspace_bytes(n_walkers, (int32_t)walk_length, p, q, (int32_t)rng_mode);
         workspace = torch::empty({(int64_t)ws_bytes}, rp.options().dtype(torch::kUInt8));
         pybind11::gil_scoped_release nogil;
-        rc = trw_walk_csr_prepared_hip(prepared.blob.data_ptr(), (size_t)prepared.blob.numel(), prepared.what,
-                                       rp.data_ptr<int64_t>(), n_nodes, ci.data_ptr<int64_t>(), nnz,
-                                       tg.data_ptr<int64_t>(), n_walkers, walker_base, p, q, (int32_t)walk_length,
-                                       (int32_t)seed, (int32_t)rng_mode, walks.data_ptr<int64_t>(),
-                                       workspace.data_ptr(), ws_bytes, hs);
+        rc = run_walk(prepared.blob.data_ptr(), (size_t)prepared.blob.numel(), prepared.what, workspace.data_ptr(), ws_bytes);
     } else {
         // self-contained call (cache off, capture in progress, temporaries): prepare into this call's own scratch.
         // When the device is short of memory the prepared part is retried leaner -- the edge table and the fat entries
@@ -457,11 +494,7 @@ torch::Tensor walk_ex(const torch::Tensor &row_ptr, const torch::Tensor &col_idx
         pybind11::gil_scoped_release nogil;
         rc = trw_prepare_csr_scratch_hip(rp.data_ptr<int64_t>(), n_nodes, ci.data_ptr<int64_t>(), nnz, what, blob.data_ptr(),
                                          (size_t)blob.numel(), scratch_bytes ? scratch.data_ptr() : nullptr, scratch_bytes, hs);
-        if (rc == TRW_OK)
-            rc = trw_walk_csr_prepared_hip(blob.data_ptr(), (size_t)blob.numel(), what, rp.data_ptr<int64_t>(), n_nodes,
-                                           ci.data_ptr<int64_t>(), nnz, tg.data_ptr<int64_t>(), n_walkers, walker_base, p,
-                                           q, (int32_t)walk_length, (int32_t)seed, (int32_t)rng_mode,
-                                           walks.data_ptr<int64_t>(), workspace.data_ptr(), call_bytes, hs);
+        if (rc == TRW_OK) rc = run_walk(blob.data_ptr(), (size_t)blob.numel(), what, workspace.data_ptr(), call_bytes);
     }
     TORCH_CHECK(rc == TRW_OK, "torch_rw walk failed (", rc, "): ", trw_last_error());
     finish_status(workspace, hs, check_mode, "walk");

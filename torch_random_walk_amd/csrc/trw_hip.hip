@@ -667,7 +667,7 @@ static int walk_prepared(const void *prepared, size_t prepared_bytes, int32_t wh
                          int64_t n_nodes, const int64_t *col_idx, int64_t nnz, const int64_t *targets,
                          int64_t n_walkers, int64_t walker_base, double p, double q, int32_t walk_length, int32_t seed,
                          int32_t rng_mode, int64_t *out, void *workspace, size_t workspace_bytes, void *hip_stream,
-                         bool mark_prepare, const FusedWindows *fused = nullptr);
+                         bool mark_prepare, const FusedWindows *fused = nullptr, uint32_t *out32 = nullptr);
 
 static int check_walk_args(const int64_t *row_ptr, int64_t n_nodes, const int64_t *col_idx, int64_t nnz,
                            const int64_t *targets, int64_t n_walkers, int64_t walker_base, double p, double q,
@@ -700,16 +700,30 @@ int trw_walk_csr_prepared_hip(const void *prepared, size_t prepared_bytes, int32
                          true);
 }
 
+int trw_walk_csr_prepared_u32_hip(const void *prepared, size_t prepared_bytes, int32_t what, const int64_t *row_ptr,
+                                  int64_t n_nodes, const int64_t *col_idx, int64_t nnz, const int64_t *targets,
+                                  int64_t n_walkers, int64_t walker_base, double p, double q, int32_t walk_length,
+                                  int32_t seed, int32_t rng_mode, uint32_t *out32, void *workspace, size_t workspace_bytes,
+                                  void *hip_stream)
+{
+    if (n_walkers > 0 && !out32) return fail(TRW_E_ARG, "out32 is null");
+    if (n_nodes > ((int64_t)1 << 32)) return fail(TRW_E_UNSUPPORTED, "narrow rows: node ids beyond 2^32");
+    return walk_prepared(prepared, prepared_bytes, what, row_ptr, n_nodes, col_idx, nnz, targets, n_walkers,
+                         walker_base, p, q, walk_length, seed, rng_mode, nullptr, workspace, workspace_bytes, hip_stream,
+                         true, nullptr, n_walkers > 0 ? out32 : (uint32_t *)workspace);
+}
+
 static int walk_prepared(const void *prepared, size_t prepared_bytes, int32_t what, const int64_t *row_ptr,
                          int64_t n_nodes, const int64_t *col_idx, int64_t nnz, const int64_t *targets,
                          int64_t n_walkers, int64_t walker_base, double p, double q, int32_t walk_length, int32_t seed,
                          int32_t rng_mode, int64_t *out, void *workspace, size_t workspace_bytes, void *hip_stream,
-                         bool mark_prepare, const FusedWindows *fused)
+                         bool mark_prepare, const FusedWindows *fused, uint32_t *out32)
 {
     t_last_error.clear();
     if (int rc = check_walk_args(row_ptr, n_nodes, col_idx, nnz, targets, n_walkers, walker_base, p, q, walk_length, out,
-                                 workspace, workspace_bytes, fused != nullptr))
+                                 workspace, workspace_bytes, fused != nullptr || out32 != nullptr))
         return rc;
+    if (out32 && (out || fused)) return fail(TRW_E_ARG, "narrow rows: one output only");
     const PrepLayout pl = make_prep_layout(n_nodes, nnz, what);
     if (!prepared || prepared_bytes < pl.persistent || ((uintptr_t)prepared & 15u) != 0)
         return fail(TRW_E_WORKSPACE, "prepared graph missing, misaligned or smaller than its layout");
@@ -789,6 +803,16 @@ static int walk_prepared(const void *prepared, size_t prepared_bytes, int32_t wh
                     uniform_glibc_rows_kernel<false, true><<<lane_grid, kBlock, 0, stream>>>(
                         row32, col32, nullptr, targets, n_nodes, n_walkers, walk_length, cl.G, cl.nlanes, win, out,
                         status, fused->window_size, fused->centre, fused->pos);
+            } else if (out32) {  // narrow rows straight from the walk: the row-tile kernels only
+                if (!(pl.narrow && rows_fit)) return fail(TRW_E_UNSUPPORTED, "narrow rows: this graph runs the int64 kernels");
+                if (use_fat)
+                    uniform_glibc_rows_kernel<true, false, uint32_t><<<lane_grid, kBlock, 0, stream>>>(
+                        row32, col32, (const u32x4_a16 *)(pw + pl.off_ext16), targets, n_nodes, n_walkers, walk_length,
+                        cl.G, cl.nlanes, win, out32, status, 0, nullptr, nullptr);
+                else
+                    uniform_glibc_rows_kernel<false, false, uint32_t><<<lane_grid, kBlock, 0, stream>>>(
+                        row32, col32, nullptr, targets, n_nodes, n_walkers, walk_length, cl.G, cl.nlanes, win, out32, status,
+                        0, nullptr, nullptr);
             } else if (pl.narrow && rows_fit && use_fat)
                 uniform_glibc_rows_kernel<true, false><<<lane_grid, kBlock, 0, stream>>>(
                     row32, col32, (const u32x4_a16 *)(pw + pl.off_ext16), targets, n_nodes, n_walkers, walk_length,
@@ -802,11 +826,13 @@ static int walk_prepared(const void *prepared, size_t prepared_bytes, int32_t wh
                                                                            n_walkers, walk_length, cl.G, cl.nlanes,
                                                                            win, out, status);
         } else {
+            if (out32) return fail(TRW_E_UNSUPPORTED, "narrow rows: not from the uniform walk on the per-walker stream");
             uniform_walker_kernel<<<walker_grid, kBlock, 0, stream>>>(row_ptr, col_idx, targets, n_nodes, nnz,
                                                                      n_walkers, walker_base, walk_length,
                                                                      (uint32_t)seed, out, status);
         }
     } else if (mode == TRW_RNG_GLIBC) {
+        if (out32) return fail(TRW_E_UNSUPPORTED, "narrow rows: not from the serial replay");
         SeedWindow sw;
         trw::seed_window(seed, sw.w);
         // sorted graph with a table and fat entries: the whole wave replays the chain (64 speculative trials at a
@@ -832,6 +858,7 @@ static int walk_prepared(const void *prepared, size_t prepared_bytes, int32_t wh
         // walker pool (lanes as executors over walker state in LDS) unless switched off or the batch does not fit its
         // 32-bit walker numbers; TRW_POOL_KERNEL=0 runs the lane-per-walker mask kernel instead
         const bool pool_kernel = mask_kernel && n_walkers < ((int64_t)1 << 32) && env_long("TRW_POOL_KERNEL", 0, 1, 1) == 1;
+        if (out32 && !pool_kernel) return fail(TRW_E_UNSUPPORTED, "narrow rows: only the walker-pool kernel writes them");
         if (pool_kernel) {
             // 4 workgroups per CU: a wave's pool is 9.9 KB of LDS (kPoolSlots walkers x 19 words), 39.5 KB per workgroup
             // (a batch that does not even give every CU one workgroup of 64-walker waves is bound by latency: its grid is
@@ -847,7 +874,11 @@ static int walk_prepared(const void *prepared, size_t prepared_bytes, int32_t wh
                                 env_long("TRW_POOL_SPARE_BLOCKS", 0, 512, 0);
             if (president < 1) president = 1;
             if (pblocks > president) pblocks = president;
-            if (g_prof.count)
+            if (out32)
+                biased_pool_kernel<false, uint32_t><<<(unsigned)pblocks, kBlock, 0, stream>>>(
+                    row32, col32, ext32, table, pl.table_blocks, targets, n_nodes, n_walkers, walker_base, walk_length,
+                    (uint32_t)seed, bp, out32, status);
+            else if (g_prof.count)
                 biased_pool_kernel<true><<<(unsigned)pblocks, kBlock, 0, stream>>>(
                     row32, col32, ext32, table, pl.table_blocks, targets, n_nodes, n_walkers, walker_base, walk_length,
                     (uint32_t)seed, bp, out, status);
@@ -866,7 +897,11 @@ static int walk_prepared(const void *prepared, size_t prepared_bytes, int32_t wh
                     (uint32_t)seed, bp, out, status);
         }
         const int32_t want_pos = (bp.t0 > bp.hi && env_long("TRW_NO_POS", 0, 1, 0) == 0) ? 1 : 0;
-        if (g_prof.count)
+        if (out32)
+            biased_hash_kernel<false, uint32_t><<<(unsigned)blocks, kBlock, 0, stream>>>(
+                row32, col32, (const uint32_t *)ext32, table, pl.table_blocks, targets, n_nodes, n_walkers, walker_base,
+                walk_length, (uint32_t)seed, bp, want_pos, mask_kernel ? 1 : 0, out32, status);
+        else if (g_prof.count)
             biased_hash_kernel<true><<<(unsigned)blocks, kBlock, 0, stream>>>(
                 row32, col32, (const uint32_t *)ext32, table, pl.table_blocks, targets, n_nodes, n_walkers, walker_base,
                 walk_length, (uint32_t)seed, bp, want_pos, mask_kernel ? 1 : 0, out, status);
@@ -874,6 +909,8 @@ static int walk_prepared(const void *prepared, size_t prepared_bytes, int32_t wh
             biased_hash_kernel<false><<<(unsigned)blocks, kBlock, 0, stream>>>(
                 row32, col32, (const uint32_t *)ext32, table, pl.table_blocks, targets, n_nodes, n_walkers, walker_base,
                 walk_length, (uint32_t)seed, bp, want_pos, mask_kernel ? 1 : 0, out, status);
+    } else if (out32) {
+        return fail(TRW_E_UNSUPPORTED, "narrow rows: a biased walk writes them over a graph prepared with TRW_PREP_BIASED only");
     } else if (pl.narrow) {
         // Locating t inside prev's row once per step (a bisection here) pays when at least half of the trials
         // draw above `hi` and can then be decided from the candidate's offset alone.

@@ -183,22 +183,39 @@ marks_plan_kernel(const uint32_t *__restrict__ row32, int64_t n_nodes, const uin
                   int64_t *__restrict__ header)
 {
     if (header[kStDescents] != header[kStBoundary]) return;  // rows not sorted: no masks, no tasks
-    const int lane = threadIdx.x & 63;
+    // The segments and the task numbers come from three device counters: a prefix sum over the wave, then over the
+    // workgroup's four waves (LDS), and ONE atomic per workgroup and counter (one per wave was 470 000 atomics on three
+    // addresses: 1.7 of the kernel's 2.3 ms).
+    __shared__ uint32_t w_tot[3][kBlock / 64];
+    __shared__ unsigned long long blk_base[3];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t x0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) & ~(int64_t)63; x0 < n_nodes; x0 += stride) {
+    auto block_take = [&](int which, uint32_t mine_total, int64_t *counter, uint32_t &before_waves, uint32_t &all) {
+        if (lane == 0) w_tot[which][wv] = mine_total;
+        __syncthreads();
+        before_waves = 0;
+        all = 0;
+#pragma unroll
+        for (int k = 0; k < kBlock / 64; ++k) {
+            const uint32_t t = w_tot[which][k];
+            before_waves += k < wv ? t : 0u;
+            all += t;
+        }
+        if (threadIdx.x == 0 && all) blk_base[which] = atomicAdd((unsigned long long *)counter, (unsigned long long)all);
+        __syncthreads();
+        return all ? blk_base[which] : 0ull;
+    };
+    for (int64_t base = (int64_t)blockIdx.x * kBlock; base < n_nodes; base += stride) {  // (workgroup-uniform trip count)
+        const int64_t x0 = base + (wv << 6);
         const int64_t x = x0 + lane;
         uint32_t start = 0, deg = 0;
         if (x < n_nodes) load_row32(row32, (uint32_t)x, start, deg);
         const bool tile = deg > inline_cap;  // (a row of up to inline_cap entries is never the tile: RT_INLINE takes its entries)
         const bool small = deg <= kSmallRow;
         const uint32_t c = tile ? in_count[x] : 0u;
-        uint32_t c_total;
+        uint32_t c_total, c_waves, c_all;
         const uint32_t c_before = wave_prefix_excl(c, lane, c_total);
-        uint64_t seg_base = 0;
-        if (c_total) {
-            if (lane == 0) seg_base = atomicAdd((unsigned long long *)&header[kStItemCount], (unsigned long long)c_total);
-            seg_base = (uint64_t)__shfl((long long)seg_base, 0);
-        }
+        const uint64_t seg_base = block_take(0, c_total, &header[kStItemCount], c_waves, c_all) + c_waves;
         uint32_t seg = kNoSegment;
         if (c) {
             if (seg_base + c_before + c <= item_room) seg = (uint32_t)(seg_base + c_before);
@@ -209,19 +226,17 @@ marks_plan_kernel(const uint32_t *__restrict__ row32, int64_t n_nodes, const uin
         const uint32_t n_a = tile ? (deg + per_a - 1u) / per_a : 0u;
         const uint32_t n_b = seg != kNoSegment ? (c + per_b - 1u) / per_b : 0u;
         const uint32_t n_t = n_a + n_b;
-        // the wave's small tasks and its big ones: a prefix sum and one atomic each
-        uint32_t s_total, b_total;
+        // the workgroup's small tasks and its big ones
+        uint32_t s_total, b_total, s_waves, b_waves, s_all, b_all;
         const uint32_t s_before = wave_prefix_excl(small ? n_t : 0u, lane, s_total);
         const uint32_t b_before = wave_prefix_excl(small ? 0u : n_t, lane, b_total);
-        uint64_t s_at0 = 0, b_at0 = 0;
-        if (lane == 0 && s_total) s_at0 = atomicAdd((unsigned long long *)&header[kStTaskCount], (unsigned long long)s_total);
-        if (lane == 0 && b_total) b_at0 = atomicAdd((unsigned long long *)&header[kStBigCount], (unsigned long long)b_total);
-        s_at0 = (uint64_t)__shfl((long long)s_at0, 0);
-        b_at0 = (uint64_t)__shfl((long long)b_at0, 0);
-        if (lane == 0 && s_at0 + s_total > small_room)
-            atomicAdd((unsigned long long *)&header[kStDropped], (unsigned long long)(s_at0 + s_total - small_room));  // (cannot happen)
-        if (lane == 0 && b_at0 + b_total > big_room)
-            atomicAdd((unsigned long long *)&header[kStDropped], (unsigned long long)(b_at0 + b_total - big_room));  // (cannot happen)
+        const uint64_t s_blk = block_take(1, s_total, &header[kStTaskCount], s_waves, s_all);
+        const uint64_t b_blk = block_take(2, b_total, &header[kStBigCount], b_waves, b_all);
+        const uint64_t s_at0 = s_blk + s_waves, b_at0 = b_blk + b_waves;
+        if (threadIdx.x == 0 && s_blk + s_all > small_room)
+            atomicAdd((unsigned long long *)&header[kStDropped], (unsigned long long)(s_blk + s_all - small_room));  // (cannot happen)
+        if (threadIdx.x == 0 && b_blk + b_all > big_room)
+            atomicAdd((unsigned long long *)&header[kStDropped], (unsigned long long)(b_blk + b_all - big_room));  // (cannot happen)
         const uint64_t at = small ? s_at0 + s_before : b_at0 + b_before;
         TileTask *const tasks = small ? tasks_small : tasks_big;
         const uint32_t room = small ? small_room : big_room;
@@ -363,7 +378,7 @@ tile_bloom_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
     uint32_t *const rp_first = row_at + kItems + 1;  // (tile row = u's) where u first sits in item j's row of v, and how often:
     uint32_t *const rp_cnt = rp_first + kItems;      // rpos of the entry, found while v's row streams past
     uint32_t *const queue = wave_lds + kItems * 8 + 4;  // (8-byte aligned: kWaveWords and the offset are even)
-    uint32_t &grabbed = lds[kHead - 4], &next_task = lds[kHead - 3];
+    uint32_t &grabbed = lds[kHead - 4], &next_task = lds[kHead - 3], &grab_len = lds[kHead - 2];
     const uint32_t tile_lds = (uint32_t)reinterpret_cast<uintptr_t>(tile);
     const int lane = threadIdx.x & 63;
     const uint32_t wave = uni(threadIdx.x >> 6);
@@ -426,7 +441,13 @@ tile_bloom_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
         } else {
             __syncthreads();  // (everyone has read `grabbed` of the last round and taken its last task)
             if (threadIdx.x == 0) {
-                grabbed = (uint32_t)atomicAdd((unsigned long long *)&header[kNextSlot], (unsigned long long)kGrab);
+                // (kGrab = 16 tasks a turn.  64 -- fewer meetings of the workgroup's waves -- left the last turns running 8 ms
+                // behind the rest; so did turns sized by what is left, 64 down to 8: the longest tasks, the hubs' in-lists of
+                // 64 rows of up to 1 024 entries against a filter that lets most of them through, come FIRST in the array,
+                // and sixty-four of them in one turn are a workgroup's whole run.)
+                const uint64_t g = kGrab;
+                grabbed = (uint32_t)atomicAdd((unsigned long long *)&header[kNextSlot], (unsigned long long)g);
+                grab_len = (uint32_t)g;
                 next_task = 0u;
             }
             __syncthreads();
@@ -434,7 +455,8 @@ tile_bloom_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
         }
         TRW_LAP(0);
         if (t0 >= n_tasks) break;
-        const uint32_t g_cnt = (t0 + kGrab < n_tasks ? t0 + kGrab : n_tasks) - t0;
+        const uint32_t g_len = kStaticGrab ? kGrab : uni(grab_len);
+        const uint32_t g_cnt = (t0 + g_len < n_tasks ? t0 + g_len : n_tasks) - t0;
         // the grab's records, one per lane; its tasks come in RUNS of one row's (the plan kernel writes a row's together)
         TileTask rec_l = {0xFFFFFFFFu, 0u};
         if ((uint32_t)lane < g_cnt) rec_l = tasks[t0 + lane];
@@ -448,7 +470,11 @@ tile_bloom_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
             if (lane == 0) t = atomicAdd(&next_task, 1u);
             return uni(t);
         };
+#ifdef TRW_DBG_STATIC_TASKS
+        uint32_t mine_t = wave;
+#else
         uint32_t mine_t = kWaves > 1 ? take() : 0u;
+#endif
         uint32_t i0 = 0;
         while (i0 < g_cnt) {
             const uint32_t node = (uint32_t)__builtin_amdgcn_readlane((int)node_l, (int)i0);
@@ -463,7 +489,11 @@ tile_bloom_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
                 if (kWaves > 1) load_tile();
             }
             TRW_LAP(2);
+#ifdef TRW_DBG_STATIC_TASKS
+            for (uint32_t ti = mine_t; ti < i1; ti = mine_t = ti + kWaves) {
+#else
             for (uint32_t ti = mine_t; ti < i1; ti = mine_t = (kWaves > 1 ? take() : ti + 1u)) {
+#endif
                 struct {
                     uint32_t start, count, mode;
                 } task = {(uint32_t)__builtin_amdgcn_readlane((int)rec_l.start, (int)ti), 0u,
@@ -637,24 +667,41 @@ tile_bloom_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
                             if (want_run)
                                 while (tile[pos + run] == x) ++run;  // (the padding ends every run)
                         }
-                    } else {  // x can only be in block jb of the row: its entries below the block's last one, in global memory
-                        // (one load a level, up to six levels.  Tried: the block's entries loaded together when m <= 8 -- one round
-                        // trip, seven loads a lane --, and four pivots + eight entries (row_find32_wide) for longer blocks: 12 200
-                        // and 14 300 cycles a search against 8 900 -- what a search of these rows costs is the NUMBER of its
-                        // scattered loads, not their depth.)
+                    } else {  // x can only be in block jb of the row, whose last entry (>= x) the tile holds; the others: global memory
+                        // One load a level, up to six levels, and NO load to look at what was found: the search is for the last
+                        // entry <= x, which one of its own probes has read.  (Tried: the block's entries loaded together when
+                        // m <= 8 -- one round trip, seven loads a lane --, and four pivots + eight entries (row_find32_wide) for
+                        // longer blocks: 12 200 and 14 300 cycles a search against 8 900 -- what a search of these rows costs is
+                        // the NUMBER of its scattered loads, not their depth.)
                         const uint32_t lo = jb * m;
                         const uint32_t len = (live && jb < nb) ? (n - lo < m ? n - lo : m) : 0u;
-                        uint32_t off = 0;
+                        const uint32_t last = *reinterpret_cast<const lds_u32 *>((uintptr_t)(qa + 4u));  // entry lo + len - 1
+                        uint32_t le = 0, val = 0;  // entries of the block's first len - 1 that are <= x; the largest of them (le > 0)
                         for (uint32_t step = mtop >> 1; step; step >>= 1) {
-                            const uint32_t p = off + step;
-                            if (p <= len && col32[t_start + lo + p - 1u] < x) off = p;
+                            const uint32_t p = le + step;
+                            if (p < len) {
+                                const uint32_t ev = col32[t_start + lo + p - 1u];
+                                if (ev <= x) {
+                                    le = p;
+                                    val = ev;
+                                }
+                            }
                         }
-                        pos = lo + off;
-                        if (off < len && col32[t_start + pos] == x) {
-                            uint32_t p = pos + 1u;
-                            if (want_run)  // (wave-uniform: a load more for every lane that hit)
-                                while (p < n && col32[t_start + p] == x) ++p;
-                            run = p - pos;
+                        const bool at_last = len != 0u && last == x;
+                        // (le != 0: a lane beyond the survivors reads whatever the stack's memory holds for x -- 0xFFFFFFFF, a
+                        // sentinel of this kernel's own tables left in LDS by an earlier launch, once passed for "found")
+                        const bool at_val = le != 0u && val == x;
+                        if (at_val || at_last) {  // entries lo .. lo + le - 1 are <= x, and the last of them (or the block's last) is x
+                            uint32_t first = at_val ? lo + le - 1u : lo + len - 1u, end = first + 1u;
+                            if (want_run) {  // (wave-uniform) the whole run: parallel edges are rare, one load either way
+                                if (at_val && at_last) end = lo + len;
+                                while (first > 0u && col32[t_start + first - 1u] == x) --first;
+                                while (end < n && col32[t_start + end] == x) ++end;
+                            }
+                            pos = first;
+                            run = end - first;
+                        } else {
+                            pos = lo + le;
                         }
                     }
                 };

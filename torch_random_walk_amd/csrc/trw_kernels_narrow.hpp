@@ -133,8 +133,11 @@ struct WaveRows {
     // Rows: walker `walker0 + r * walker_stride` for wave lane r.  Everything but the lane's offset inside
     // the wave's block of rows is wave-uniform and lives in scalar registers (the host guarantees
     // 64 * walker_stride * cols * 8 < 2^32, so that offset is a 32-bit byte offset).
+    // OutT: int64_t (the reference's rows) or uint32_t (narrow rows for the multi-GPU gather: node ids < 2^32); a "line"
+    // is 8 columns either way -- 64 bytes of int64, an aligned 32-byte half line of uint32.
+    template <class OutT>
     __device__ __forceinline__ void flush(int64_t walker0, int32_t walker_stride, int64_t n_walkers, int32_t cols,
-                                          int32_t c, int64_t *__restrict__ out) const
+                                          int32_t c, OutT *__restrict__ out) const
     {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -142,8 +145,8 @@ struct WaveRows {
         int64_t left = n_walkers - w0;  // rows of this wave that exist: those with r * stride < left
         left = left < 0 ? 0 : (left + walker_stride - 1) / walker_stride;
         const int nrows = left > 64 ? 64 : (int)left;
-        int64_t *base = out + w0 * cols;
-        const uint32_t phase0 = (uint32_t)((uintptr_t)base >> 3);  // low 3 bits: where row 0 starts in its line
+        OutT *base = out + w0 * cols;
+        const uint32_t phase0 = (uint32_t)((uintptr_t)base / sizeof(OutT));  // low 3 bits: where row 0 starts in its line
         const uint32_t row_elems = (uint32_t)walker_stride * (uint32_t)cols;
         // (opaque copy: keeps the compiler from hoisting every pass's per-lane offsets out of the walk loop
         // into registers that the 31-word generator window needs)
@@ -162,7 +165,7 @@ struct WaveRows {
                 const int32_t col = 8 * j - (int32_t)((phase0 + off0) & 7u) + e;
                 if (col >= 0 && col <= c && row < nrows) {
                     const uint32_t v = t[row * kTileStride + (col & (kTileCols - 1))];
-                    if (v != kTileSkip) base[off0 + (uint32_t)col] = (int64_t)v;
+                    if (v != kTileSkip) base[off0 + (uint32_t)col] = (OutT)v;
                 }
             }
         }
@@ -282,12 +285,15 @@ struct WaveWindows {
 // For kernels whose lanes advance at their own pace (the biased walks): the last (up to) four columns of
 // the lane's row wait in registers until they fill a 32-byte-aligned group of the caller's row, the
 // granule a partial HBM write costs anyway (one write request per four columns instead of one per column).
-struct RowCombiner {
-    int64_t *sp;  // where the next column goes
+typedef uint32_t u32x4_o16 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_a8 __attribute__((ext_vector_type(2)));
+template <class OutT>
+struct RowCombinerT {
+    OutT *sp;  // where the next column goes
     uint32_t wb0, wb1, wb2, wb3;
     __device__ __forceinline__ void emit(uint32_t v, int32_t col, int32_t last_col)
     {
-        const uint32_t k = (uint32_t)((uintptr_t)sp >> 3) & 3u;
+        const uint32_t k = (uint32_t)((uintptr_t)sp / sizeof(OutT)) & 3u;
         wb0 = k == 0u ? v : wb0;
         wb1 = k == 1u ? v : wb1;
         wb2 = k == 2u ? v : wb2;
@@ -295,21 +301,26 @@ struct RowCombiner {
         ++sp;
         if (k == 3u || col == last_col) {
             const uint32_t have = min(k + 1u, (uint32_t)col + 1u);  // columns of THIS row in the group
-            int64_t *grp = sp - (k + 1u);
+            OutT *grp = sp - (k + 1u);
             if (have == 4u) {
-                const i64x2_a16 lo2 = {(int64_t)wb0, (int64_t)wb1}, hi2 = {(int64_t)wb2, (int64_t)wb3};
-                *reinterpret_cast<i64x2_a16 *>(grp) = lo2;
-                *reinterpret_cast<i64x2_a16 *>(grp + 2) = hi2;
+                if (sizeof(OutT) == 8) {
+                    const i64x2_a16 lo2 = {(int64_t)wb0, (int64_t)wb1}, hi2 = {(int64_t)wb2, (int64_t)wb3};
+                    *reinterpret_cast<i64x2_a16 *>(grp) = lo2;
+                    *reinterpret_cast<i64x2_a16 *>(grp + 2) = hi2;
+                } else {
+                    *reinterpret_cast<u32x4_o16 *>(grp) = u32x4_o16{wb0, wb1, wb2, wb3};  // (16-byte aligned: k == 3)
+                }
             } else {
                 const uint32_t first = k + 1u - have;
-                if (first == 0u) grp[0] = (int64_t)wb0;
-                if (first <= 1u && k >= 1u) grp[1] = (int64_t)wb1;
-                if (first <= 2u && k >= 2u) grp[2] = (int64_t)wb2;
-                if (k >= 3u) grp[3] = (int64_t)wb3;
+                if (first == 0u) grp[0] = (OutT)wb0;
+                if (first <= 1u && k >= 1u) grp[1] = (OutT)wb1;
+                if (first <= 2u && k >= 2u) grp[2] = (OutT)wb2;
+                if (k >= 3u) grp[3] = (OutT)wb3;
             }
         }
     }
 };
+typedef RowCombinerT<int64_t> RowCombiner;
 
 // ---------------------------------------------------------------------------
 // Uniform walk, reference-exact draws (uniform_walk, rw_cpu.cpp:58-107)
@@ -334,12 +345,12 @@ struct RowCombiner {
 // waves per SIMD than with 8 (measured 16.3 vs 17.3 ms on R-MAT 10M/110M, and no better with 2-4; the compact walk
 // does not care).
 // kWin: the fused walk + to_windows (WaveWindows above); `out` may then be null (the rows themselves are not wanted).
-template <bool kFat, bool kWin>
+template <bool kFat, bool kWin, class OutT = int64_t>
 __global__ void __launch_bounds__(kBlock, (kFat || kWin) ? 4 : 8)
 uniform_glibc_rows_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32,
                           const u32x4_a16 *__restrict__ ext, const int64_t *__restrict__ targets, int64_t n_nodes,
                           int64_t n_walkers, int32_t L, int32_t G, int64_t nlanes, const uint32_t *__restrict__ win,
-                          int64_t *__restrict__ out, int64_t *__restrict__ status, int32_t window_size,
+                          OutT *__restrict__ out, int64_t *__restrict__ status, int32_t window_size,
                           int64_t *__restrict__ centre, int64_t *__restrict__ pos)
 {
     __shared__ uint32_t tiles[(kBlock / 64) * 64 * kTileStride];
@@ -376,7 +387,7 @@ uniform_glibc_rows_kernel(const uint32_t *__restrict__ row32, const uint32_t *__
                     st |= TRW_ST_NODE_RANGE;
                     live = false;
                     if (out)
-                        for (int32_t c = 0; c <= L; ++c) out[walker * (int64_t)(L + 1) + c] = tg;
+                        for (int32_t c = 0; c <= L; ++c) out[walker * (int64_t)(L + 1) + c] = (OutT)tg;
                     if (kWin) {  // ... and so are its windows
                         for (int64_t k = walker * wins.step_end; k < (walker + 1) * wins.step_end; ++k) {
                             centre[k] = tg;
@@ -1055,12 +1066,12 @@ constexpr int kTrialsPerIter = TRW_TRIALS_PER_ITER;
 #define TRW_VOTE_TICK 7
 #endif
 
-template <bool kCount>
+template <bool kCount, class OutT = int64_t>
 __global__ void __launch_bounds__(kBlock)
 biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32,
                    const uint32_t *__restrict__ ext, const uint32_t *__restrict__ table, uint32_t tnb, const int64_t *__restrict__ targets,
                    int64_t n_nodes, int64_t n_walkers, int64_t walker_base, int32_t L, uint32_t seed,
-                   BiasedParams bp, int32_t want_pos, int32_t only_unsorted, int64_t *__restrict__ out,
+                   BiasedParams bp, int32_t want_pos, int32_t only_unsorted, OutT *__restrict__ out,
                    int64_t *__restrict__ status)
 {
     // Sorted graphs are walked by biased_mask_kernel; the host cannot see which kind it has without a
@@ -1111,7 +1122,7 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
     bool fresh = false;             // a gather state was entered (or its probe moved on): issue the load
     uint32_t acc_cand = 0, iter = 0;
     bool acc_known = false;
-    RowCombiner row = {out, 0u, 0u, 0u, 0u};  // the caller's int64 row, four columns per store
+    RowCombinerT<OutT> row = {out, 0u, 0u, 0u, 0u};  // the caller's row, four columns per store
 
     while (true) {
         // ---- hand out walkers to the lanes that need one (one atomic per wave) ----
@@ -1134,7 +1145,7 @@ biased_hash_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                     row.sp = out + walker * (int64_t)(L + 1);
                     if ((uint64_t)tg >= (uint64_t)n_nodes) {
                         st |= TRW_ST_NODE_RANGE;  // reported; the row is filled with the bad id
-                        for (int32_t c = 0; c <= L; ++c) row.sp[c] = tg;
+                        for (int32_t c = 0; c <= L; ++c) row.sp[c] = (OutT)tg;
                     } else {
                         row.emit((uint32_t)tg, 0, L);  // column 0
                         gw = (uint64_t)walker_base + (uint64_t)walker;
@@ -1798,12 +1809,12 @@ enum : int {
     PF_COUNT
 };
 
-template <bool kCount>
+template <bool kCount, class OutT = int64_t>
 __global__ void __launch_bounds__(kBlock)
 biased_pool_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict__ col32,
                    const u32x4_a16 *__restrict__ ext, const uint32_t *__restrict__ table, uint32_t tnb,
                    const int64_t *__restrict__ targets, int64_t n_nodes, int64_t n_walkers, int64_t walker_base, int32_t L,
-                   uint32_t seed, BiasedParams bp, int64_t *__restrict__ out, int64_t *__restrict__ status)
+                   uint32_t seed, BiasedParams bp, OutT *__restrict__ out, int64_t *__restrict__ status)
 {
     if (status[kStDescents] != status[kStBoundary]) return;  // unsorted rows: biased_hash_kernel's job
     __shared__ uint32_t pool_mem[kPoolWaves][PF_COUNT][kPoolSlots];
@@ -1884,19 +1895,24 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                     const uint32_t x = e0.x;
                     int32_t s = (int32_t)P[PF_S][slot];
                     const uint32_t prev = P[PF_PREV][slot];
-                    int64_t *r = row_of(slot);
+                    OutT *r = row_of(slot);
 #if TRW_POOL_PAIR_STORES
                     // Columns leave in 16-byte ALIGNED pairs: column s together with column s-1 (the node being left, in
                     // the slot anyway) when its address is the upper half of a pair, not at all when it is the lower half
                     // (the next step stores it) -- half the store requests of a kernel that runs at the memory system's
                     // request rate.  (Round 2 paired by step parity: rows are 8-byte aligned, every other walker's pairs
                     // straddled and were split again.)
-                    if (((uintptr_t)(r + s) >> 3) & 1u)
-                        *reinterpret_cast<i64x2_a16 *>(r + s - 1) = i64x2_a16{(int64_t)prev, (int64_t)x};
-                    else if (s == L)
-                        r[s] = (int64_t)x;  // (the last column has no partner to wait for)
+                    // (uint32 rows -- the multi-GPU gather's wire format, straight from the walk: pairs of 8 bytes)
+                    if (((uintptr_t)(r + s) / sizeof(OutT)) & 1u) {
+                        if (sizeof(OutT) == 8)
+                            *reinterpret_cast<i64x2_a16 *>(r + s - 1) = i64x2_a16{(int64_t)prev, (int64_t)x};
+                        else
+                            *reinterpret_cast<u32x2_a8 *>(r + s - 1) = u32x2_a8{prev, x};
+                    } else if (s == L) {
+                        r[s] = (OutT)x;  // (the last column has no partner to wait for)
+                    }
 #else
-                    r[s] = (int64_t)x;
+                    r[s] = (OutT)x;
 #endif
                     ++s;
                     const uint32_t deg = e0.z & ~kMaskIsFilter;
@@ -1904,7 +1920,7 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                         to_free = true;
                     } else if (deg == 0) {  // dead end: reported, the walker stays
                         st |= TRW_ST_DEGREE0;
-                        for (int32_t c = s - 1; c <= L; ++c) r[c] = (int64_t)x;
+                        for (int32_t c = s - 1; c <= L; ++c) r[c] = (OutT)x;
                         to_free = true;
                     } else {
                         FastMod fm;
@@ -2043,14 +2059,14 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
             bool to_issue = false, back = false;
             if ((uint32_t)lane < take) {
                 const int64_t walker = rs_walker0 + (int64_t)src;
-                int64_t *rowp = out + walker * cols;
+                OutT *rowp = out + walker * cols;
                 if (why) {  // reported; a bad id fills its row, a dead end at the start node stays there
                     st |= (why & 1u) ? TRW_ST_NODE_RANGE : TRW_ST_DEGREE0;
-                    for (int32_t c = 0; c <= L; ++c) rowp[c] = tg;
+                    for (int32_t c = 0; c <= L; ++c) rowp[c] = (OutT)tg;
                     back = true;
                 } else {
                     P[PF_WALKER][slot] = (uint32_t)walker;
-                    rowp[0] = tg;  // column 0
+                    rowp[0] = (OutT)tg;  // column 0
                     P[PF_PREV][slot] = (uint32_t)tg;  // step 1 leaves the start node
                     P[PF_T][slot] = (uint32_t)tg;
                     P[PF_S][slot] = 1u;

@@ -48,7 +48,7 @@ def _host_staged(group, tensor):
 
 
 def walk_sharded(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, group=None, gather="root",
-                 rng_mode=None, walk_fn=None, wire="auto", chunks=1):
+                 rng_mode=None, walk_fn=None, wire="auto", chunks=1, result_dtype=torch.int64):
     """Walk ``target_nodes`` (the full batch, same on every rank) across the ranks of ``group``.
 
     gather: "root"  -> rank 0 returns the full ``[N, L+1]`` tensor, other ranks return their block
@@ -66,6 +66,11 @@ def walk_sharded(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, group=
     chunks: gather="root": a rank walks its block in this many row sub-blocks and posts each one's transfer as
             soon as its walk is enqueued, so the gather overlaps the rest of the same call's walk instead of
             starting when the whole block is done.
+    result_dtype: ``torch.int64`` (the reference's rows) or ``torch.int32`` = NARROW rows end to end: what is returned
+            -- the gathered tensor and every rank's own block -- holds the node ids as uint32 bit patterns in an int32
+            tensor (``rw.widen_rows`` turns them into int64).  Every rank's walk kernel writes them itself
+            (``rw.walk_ex(out=<int32 tensor>)``), the peers' blocks land in the result, nothing is narrowed or widened
+            on the way: half the bytes to write, to send and to keep.  Needs node ids below 2^32 (the uint32 wire).
     walk_fn: override of ``rw.walk_ex`` (the CPU tests plug the oracle in here).
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -81,6 +86,11 @@ def walk_sharded(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, group=
     if gather not in ("root", "all", "none"):
         raise ValueError("gather must be 'root', 'all' or 'none'")
     narrow = wire_dtype_for(int(row_ptr.numel()) - 1, wire) == "uint32"
+    if result_dtype not in (torch.int64, torch.int32):
+        raise ValueError("result_dtype must be torch.int64 or torch.int32")
+    res32 = result_dtype == torch.int32
+    if res32 and not narrow:
+        raise ValueError("result_dtype=torch.int32 holds node ids below 2^32 and travels as uint32: wire must not be 'int64'")
     chunks = max(1, int(chunks)) if (world > 1 and gather == "root") else 1
     cols = walk_length + 1
     dev = target_nodes.device
@@ -101,8 +111,9 @@ def walk_sharded(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, group=
                 rw.walk_ex(row_ptr, col_idx, target_nodes[c_lo:c_hi], p, q, walk_length, seed, walker_base=c_lo,
                            rng_mode=rng_mode, check="deferred", out=dst)
             else:
-                dst.copy_(walk_fn(row_ptr, col_idx, target_nodes[c_lo:c_hi], p, q, walk_length, seed,
-                                  walker_base=c_lo, rng_mode=rng_mode))
+                rows = walk_fn(row_ptr, col_idx, target_nodes[c_lo:c_hi], p, q, walk_length, seed,
+                               walker_base=c_lo, rng_mode=rng_mode)
+                dst.copy_(rw.narrow_rows(rows.contiguous()) if res32 else rows)
         except Exception as e:  # noqa: BLE001 -- see above: kept, raised by settle()
             if not fault:
                 fault.append(e)
@@ -135,17 +146,17 @@ def walk_sharded(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, group=
 
     def to_wire(rows):
         """what travels for a block of rows: the rows themselves, or their uint32 form; on the host under gloo"""
-        w = rw.narrow_rows(rows) if narrow else rows
+        w = rw.narrow_rows(rows) if (narrow and not res32) else rows   # (res32: the rows ARE the wire form)
         return w.cpu() if staged else w
 
     root_gather = world > 1 and gather == "root"
     if root_gather and rank == 0:
         # the root walks straight into its slice of the result: no copy of its own block
-        full = torch.empty((world * block, cols), dtype=torch.int64, device=dev)
+        full = torch.empty((world * block, cols), dtype=result_dtype, device=dev)
         mine = full[lo:hi]
     else:
         full = None
-        mine = torch.empty((hi - lo, cols), dtype=torch.int64, device=dev)
+        mine = torch.empty((hi - lo, cols), dtype=result_dtype, device=dev)
 
     if not root_gather:
         walk_into(mine, lo, hi)
@@ -162,7 +173,7 @@ def walk_sharded(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, group=
         got = got[:n]
         if staged:
             got = got.to(dev)
-        return settle(rw.widen_rows(got.contiguous()) if narrow else got)
+        return settle(rw.widen_rows(got.contiguous()) if (narrow and not res32) else got)
 
     # gather == "root": a gather on xGMI is world-1 independent peer -> root transfers; issued as groups of
     # point-to-point operations they land directly in the root's buffers, chunk by chunk
@@ -183,7 +194,7 @@ def walk_sharded(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, group=
 
     wire_dtype = torch.int32 if narrow else torch.int64
     land = None
-    if narrow or staged:   # where the peers' blocks arrive before they are widened / copied into `full`
+    if (narrow and not res32) or staged:   # where the peers' blocks arrive before they are widened / copied into `full`
         land = torch.empty((world * block, cols), dtype=wire_dtype, device="cpu" if staged else dev)
     pending = []
     for c in range(chunks):
@@ -209,7 +220,7 @@ def walk_sharded(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, group=
             continue
         for c_lo, c_hi in pieces:
             got = land[c_lo:c_hi].to(dev) if staged else land[c_lo:c_hi]
-            if narrow:
+            if narrow and not res32:
                 rw.widen_rows(got, out=full[c_lo:c_hi])
             else:
                 full[c_lo:c_hi].copy_(got)

@@ -49,7 +49,11 @@ def walk_ex(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, walker_base
     A shard that passes the global offset of its slice reproduces exactly the rows
     the unsharded call would have produced (include/trw.h, TRW_RNG_*).  ``out``: a contiguous
     int64 ``[len(target_nodes), walk_length + 1]`` tensor to walk into (e.g. the shard's slice of
-    the gathered result) instead of a fresh one.
+    the gathered result) instead of a fresh one -- or an **int32** one for NARROW rows: the node ids as
+    uint32 bit patterns (``widen_rows`` gives the int64 rows back), the wire format of the multi-GPU
+    gather, written by the walk kernel itself where the production kernels run (the reference-exact
+    uniform walk; the node2vec walk on the per-walker stream over a prepared graph) and by a narrowing
+    pass behind an int64 walk elsewhere: the same values either way.  GPU tensors, node ids below 2^32.
     """
     return torch_rw_native.walk_ex(row_ptr, col_idx, target_nodes, p, q, walk_length, seed, walker_base,
                                    rng_mode, _check_code(check), out)
