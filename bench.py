@@ -385,6 +385,10 @@ def main():
         torch.cuda.synchronize()
         cold["prepare_call_ms"] = (time.perf_counter() - t_c) * 1e3
         cold["prepare_marks"] = args.marks
+        # where a prepare call's time goes: the allocator (prepared graph + scratch), enqueueing, the kernels
+        pt = rw.prepare_timing()
+        cold["prepare_alloc_ms"], cold["prepare_launch_ms"] = pt["alloc_ms"], pt["launch_ms"]
+        cold["prepare_alloc_bytes"] = pt["prepared_bytes"] + pt["scratch_bytes"]
         if lib.trw_profile_prepare_last(ctypes.byref(pm)) == 0:
             cold["prepare_kernels_ms"] = pm.value
     for _ in range(args.warmup):

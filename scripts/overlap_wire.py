@@ -67,3 +67,33 @@ for spare in ("0", "64"):
     print("wire stream priority %d, spare slots %2s: walk alone %.1f ms, widening %d blocks (%.0f GB moved) alone %.1f ms; together, walk queued first: "
           "walk %.1f widen %.1f whole %.1f ms; widening queued first: walk %.1f widen %.1f whole %.1f ms" % (
               prio, spare, w_alone, peers, gb, x_alone, w_both, x_both, whole, w_both2, x_both2, whole2), flush=True)
+
+# ---- round 5: narrow rows end to end.  The root's result is int32; its own walk writes narrow rows into its slice and the
+# peers' blocks LAND in theirs -- nothing is widened.  What shares the memory system with the walk is then only the
+# ingest: 7 x 3.24 GB written per step (rehearsed as a device copy on another stream: it READS as much as it writes, so it is
+# heavier than the links' DMA writes).
+del full
+torch.cuda.empty_cache()
+res32 = torch.empty(((peers + 1) * n, L + 1), dtype=torch.int32, device=dev)
+
+
+def walk32():
+    rw.walk_ex(rp, ci, tg, 0.25, 4.0, L, 10, rng_mode=rw.RNG_WALKER, check=False, out=res32[:n])
+
+
+def ingest():
+    res32[n:].copy_(land)
+
+
+os.environ["TRW_POOL_SPARE_BLOCKS"] = "64"
+for _ in range(2):
+    walk32()
+    ingest()
+(w64,), _ = timed([(s_walk, walk)])
+(w32,), _ = timed([(s_walk, walk32)])
+(i_alone,), _ = timed([(s_wire, ingest)])
+(w32_both, i_both), whole = timed([(s_walk, walk32), (s_wire, ingest)])
+assert torch.equal(rw.widen_rows(res32[:n].contiguous()), out), "narrow rows differ from the int64 walk"
+print("narrow rows end to end (spare slots 64): walk writing int64 rows alone %.1f ms, writing uint32 rows alone %.1f ms; ingest of %d peer "
+      "blocks (%.1f GB copied in) alone %.1f ms; together: walk %.1f ingest %.1f whole %.1f ms -- nothing to widen" % (
+          w64, w32, peers, peers * n * (L + 1) * 4 / 1e9, i_alone, w32_both, i_both, whole), flush=True)

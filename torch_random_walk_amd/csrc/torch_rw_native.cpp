@@ -16,6 +16,8 @@
 // asynchronously and the error is raised by the NEXT torch_rw call (or by check_status()) once that
 // read-back has landed.  set_check(True) / check=True is the strict mode: synchronise and raise at once.
 #include <torch/extension.h>
+#include <atomic>
+#include <chrono>
 
 // PyTorch-ROCm presents its HIP devices under the "cuda" device type; these are the guard and
 // stream accessors that go with that.
@@ -138,6 +140,11 @@ torch::Tensor walk_cpu_leg(const torch::Tensor &row_ptr, const torch::Tensor &co
     return walks;
 }
 
+// Host-side cost of the last prepared-graph build (rw.prepare_timing): what the allocator took and what enqueueing the
+// kernels took -- beside the kernels' own time (trw_profile_prepare_last) that is all a prepare call is.
+static std::atomic<double> g_last_alloc_ms{0.0}, g_last_launch_ms{0.0};
+static std::atomic<long long> g_last_keep_bytes{0}, g_last_scratch_bytes{0};
+
 // ---- prepared graphs, kept across calls --------------------------------------------------------------------
 // What a walk derives from (row_ptr, col_idx) alone (uint32 shadow, fat entries, edge table, neighbourhood
 // masks: trw_prepare_csr_hip) is cached per graph, so the second and later walks over the same tensors start at
@@ -254,6 +261,7 @@ void build_blob(PreparedGraph &entry, const torch::Tensor &rp, const torch::Tens
                                    : trw_prepare_csr_persistent_bytes(n_nodes, nnz, w);
         const size_t scratch_bytes = elist ? 0 : trw_prepare_csr_scratch_bytes(n_nodes, nnz, w);
         torch::Tensor blob, scratch;
+        const auto t_alloc = std::chrono::steady_clock::now();
         try {
             blob = torch::empty({(int64_t)bytes}, rp.options().dtype(torch::kUInt8));
             if (scratch_bytes) scratch = torch::empty({(int64_t)scratch_bytes}, rp.options().dtype(torch::kUInt8));
@@ -261,12 +269,17 @@ void build_blob(PreparedGraph &entry, const torch::Tensor &rp, const torch::Tens
             if (k == 3) throw;
             continue;  // (the allocator has already given its cached blocks back before throwing)
         }
+        const auto t_launch = std::chrono::steady_clock::now();
         const int rc = elist ? trw_prepare_edge_list_hip(rp.data_ptr<int64_t>(), nnz, ci.data_ptr<int64_t>(), n_nodes,
                                                          entry.pad, w, blob.data_ptr(), bytes, stream)
                              : trw_prepare_csr_scratch_hip(rp.data_ptr<int64_t>(), n_nodes, ci.data_ptr<int64_t>(), nnz, w,
                                                            blob.data_ptr(), bytes, scratch_bytes ? scratch.data_ptr() : nullptr,
                                                            scratch_bytes, stream);
         TORCH_CHECK(rc == TRW_OK, "torch_rw prepare failed (", rc, "): ", trw_last_error());
+        g_last_alloc_ms = std::chrono::duration<double, std::milli>(t_launch - t_alloc).count();
+        g_last_launch_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_launch).count();
+        g_last_keep_bytes = (long long)bytes;
+        g_last_scratch_bytes = (long long)scratch_bytes;
         trw_event_destroy(entry.ready);
         entry.ready = trw_event_record(stream);
         entry.built_on = stream;
@@ -1059,6 +1072,14 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
         std::lock_guard<std::mutex> lock(g_cache_mu);
         g_cache.clear();
     });
+    m.def("prepare_timing", []() {
+        pybind11::dict d;
+        d["alloc_ms"] = g_last_alloc_ms.load();
+        d["launch_ms"] = g_last_launch_ms.load();
+        d["prepared_bytes"] = g_last_keep_bytes.load();
+        d["scratch_bytes"] = g_last_scratch_bytes.load();
+        return d;
+    }, "host-side cost of the last prepared-graph build: allocator, kernel launches; and its two sizes");
     m.def("cache_info", []() {
         std::lock_guard<std::mutex> lock(g_cache_mu);
         std::vector<std::tuple<int64_t, int64_t, int64_t, int64_t, int64_t>> out;

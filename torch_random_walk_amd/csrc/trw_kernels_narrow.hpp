@@ -759,8 +759,8 @@ __device__ __forceinline__ uint32_t edge_hash(uint32_t u, uint32_t v)
 
 // The edge set (round 4: 16 bytes per edge where the table of {u, v, first offset, multiplicity} slots took 78).
 // Keys of 8 bytes {u, v} (u == 0xFFFFFFFF: free) in BLOCKS of four -- 32 bytes, an aligned half of a cache line, what a
-// probe reads anyway -- `nb` blocks, any number (>= 2 keys per edge: load <= 0.5; the block of an edge is
-// mulhi(hash, nb), no power of two needed).  A key lives in the first free place of its home block or of the blocks
+// probe reads anyway -- `nb` blocks, any number (2.5 places per edge by default: load 0.4; TRW_HASH_SLACK tenths of a
+// place per edge, 12 at least; the block of an edge is mulhi(hash, nb), no power of two needed).  A key lives in the first free place of its home block or of the blocks
 // after it, so places fill in order: a lookup that meets a free place has seen everything its key could be behind.
 // Walkers only ever ask "is (a, b) an edge"; WHERE b sits in a's row -- the prepare pass wants it for rpos and for
 // the masks, the walk for the rare run of parallel edges that does not fit rpos -- is a bisection of the sorted row
@@ -940,25 +940,24 @@ __device__ __forceinline__ uint32_t row_find32_wide(const uint32_t *__restrict__
 // probe chain longer than the slot's counter -- as REAL calls: inlined, their loads shared registers with the pool's
 // gathers in flight, and the compiler put a full `s_waitcnt vmcnt(0)` in front of the issue pass's loads of every
 // iteration (walk 36.3 -> 40.4 ms on R-MAT 10M/110M).
-__device__ __attribute__((noinline)) uint32_t row_find32_cold(const uint32_t *col32, uint32_t start, uint32_t n, uint32_t x,
-                                                              uint32_t *run_out)
+// (Both return their two results packed in one uint64: through a pointer the caller's variable lived in scratch memory,
+// and the private segment was set up for every wave of the kernel for it -- 16 bytes a lane, round 4.)
+__device__ __attribute__((noinline)) uint64_t row_find32_cold(const uint32_t *col32, uint32_t start, uint32_t n, uint32_t x)
 {
     uint32_t run;
     const uint32_t lo = row_find32(col32, start, n, x, run);
-    *run_out = run;
-    return lo;
+    return ((uint64_t)run << 32) | lo;  // first offset | how many entries equal x
 }
-__device__ __attribute__((noinline)) bool edge_chain_cold(const uint32_t *table, uint32_t nb, uint32_t a, uint32_t b, uint32_t skip,
-                                                          uint32_t *probes)
+__device__ __attribute__((noinline)) uint64_t edge_chain_cold(const uint32_t *table, uint32_t nb, uint32_t a, uint32_t b, uint32_t skip)
 {
-    uint32_t blk = edge_block(a, b, nb);
+    uint32_t blk = edge_block(a, b, nb), probes = 0;
     for (uint32_t k = 0; k < skip; ++k) blk = blk + 1u == nb ? 0u : blk + 1u;
     while (true) {
         const u32x4_a16 g0 = *reinterpret_cast<const u32x4_a16 *>(table + 8 * (size_t)blk);
         const u32x4_a16 g1 = *reinterpret_cast<const u32x4_a16 *>(table + 8 * (size_t)blk + 4);
-        ++*probes;
-        if (half_has(g0, a, b) || half_has(g1, a, b)) return true;
-        if (half_ends(g0) || half_ends(g1)) return false;
+        ++probes;
+        if (half_has(g0, a, b) || half_has(g1, a, b)) return ((uint64_t)probes << 32) | 1u;  // found | blocks looked at
+        if (half_ends(g0) || half_ends(g1)) return (uint64_t)probes << 32;
         blk = blk + 1u == nb ? 0u : blk + 1u;
     }
 }
@@ -1939,8 +1938,8 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                             // t's run in x's row has too many parallel edges / starts too far in for the packed form:
                             // found here, by bisection (rare).  It goes where two mask words were; the mask then says
                             // "look" for every offset.
-                            uint32_t cnt = 0;
-                            const uint32_t lo = row_find32_cold(col32, e0.y, deg, prev, &cnt);
+                            const uint64_t found = row_find32_cold(col32, e0.y, deg, prev);
+                            const uint32_t lo = (uint32_t)found, cnt = (uint32_t)(found >> 32);
                             u32x4_a16 mm = M[slot];
                             mm.z = lo;
                             mm.w = cnt;
@@ -1964,10 +1963,10 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                     bool empty = !match && (half_ends(e0) || half_ends(e1));
                     if (!empty && !match && (flags & kPfProbe) == kPfProbe) {
                         // the chain is longer than the probe field counts: this lane walks the rest of it here
-                        uint32_t walked = 0;
-                        match = edge_chain_cold(table, tnb, ku, kv, 8u, &walked);
+                        const uint64_t chain = edge_chain_cold(table, tnb, ku, kv, 8u);
+                        match = (uint32_t)chain != 0u;
                         empty = !match;
-                        if (kCount) n_probes += walked;
+                        if (kCount) n_probes += (uint32_t)(chain >> 32);
                     }
                     if (!empty && !match) {
                         P[PF_FLAGS][slot] = flags + (1u << kPfProbeShift);

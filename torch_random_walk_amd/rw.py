@@ -119,6 +119,13 @@ def cache_info():
     return torch_rw_native.cache_info()
 
 
+def prepare_timing():
+    """Host-side cost of the last prepared-graph build of this process: ``{"alloc_ms": what the allocator took for
+    the prepared graph and the marking passes' scratch, "launch_ms": what enqueueing the kernels took,
+    "prepared_bytes", "scratch_bytes"}`` (the kernels' own time: ``trw_profile_prepare_last`` of the C ABI)."""
+    return torch_rw_native.prepare_timing()
+
+
 def set_rng_mode(mode):
     """Process-wide RNG mode used by ``walk`` (RNG_AUTO / RNG_GLIBC / RNG_WALKER)."""
     torch_rw_native.set_rng_mode(mode)
