@@ -66,7 +66,7 @@ for wl in argv[2:]:
         with open(path) as f:
             for row in csv.DictReader(f):
                 hit = [k for k in DOMINANT.get(wl, ()) if k + "<" in row["Kernel_Name"] or k + "(" in row["Kernel_Name"]]
-                counting = hit and (hit[0].startswith("biased") or hit[0] == "elist_pool_kernel") and (hit[0] + "<true>") in row["Kernel_Name"]
+                counting = hit and (hit[0].startswith("biased") or hit[0] == "elist_pool_kernel") and (hit[0] + "<true") in row["Kernel_Name"]
                 if hit and not counting:   # (biased_*_kernel<true> is the counting variant, not the timed kernel)
                     seen[hit[0]][row["Counter_Name"]].append(float(row["Counter_Value"]))
     # several candidates may have been launched (a kernel that finds the graph is not its kind returns at once):

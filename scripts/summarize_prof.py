@@ -13,7 +13,7 @@ out = sys.argv[1]
 def short(name):
     for k in ("uniform_glibc_rows_kernel", "uniform_glibc_ext_kernel", "uniform_glibc_kernel", "uniform_walker_kernel", "biased_walker_kernel", "glibc_windows_kernel",
               "csr_rows_sorted_kernel", "biased_glibc_seq_kernel", "transpose_rows_kernel", "csr_shadow_kernel",
-              "heavy_tile_kernel", "heavy_plan_kernel", "heavy_scatter_kernel", "biased_hash_kernel", "biased_mask_kernel", "biased_pool_kernel", "edge_table_build_kernel", "csr_ext32_heavy_kernel", "csr_ext32_kernel",
+              "tile_bloom_kernel", "entries_kernel", "marks_plan_kernel", "marks_scatter_kernel", "biased_hash_kernel", "biased_mask_kernel", "biased_pool_kernel", "edge_table_build_kernel",
               "csr_ext_kernel", "fill_kernel", "status_seed_kernel",
               "triples_windows_gather_kernel", "cbow_negative", "triples_glibc_seq_kernel", "elist_glibc_seq_kernel",
               "triples_walker_kernel", "triples_shadow_kernel", "elist_pool_kernel", "elist_ext_kernel", "elist_walk_kernel", "elist_shadow_kernel",

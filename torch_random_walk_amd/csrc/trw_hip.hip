@@ -607,8 +607,10 @@ int trw_prepare_csr_scratch_hip(const int64_t *row_ptr, int64_t n_nodes, const i
                                                                                header);
                 marks_scatter_kernel<<<stream_grid(n_nodes), kBlock, 0, stream>>>(row32, ext32, n_nodes, inline_cap, heavy_cap, in_off,
                                                                                   items, header);
-                // long tile rows: 4 096 entries of tile + 64 Ki bits of filter + the waves' queues, 35.6 KB, four workgroups
-                // of 8 waves per CU; short ones (up to 255 entries): a workgroup of ONE wave, 4.6 KB
+                // long tile rows: 2 048 entries of tile + 64 000 bits of filter + 3 KB of tables and survivor stack per wave:
+                // 40.9 KB, FOUR workgroups of 8 waves per CU (with a 4 096-entry tile it was three: 53.7 -> 47.5 ms for the
+                // whole pass on one box -- the pass waits for memory and for its own barriers, resident waves are what it
+                // is short of); short ones (up to 255 entries): a workgroup of ONE wave, 5.2 KB
                 tile_bloom_kernel<TRW_TILE_CAP, TRW_BLOOM_WORDS, 512, 8, TRW_BIG_GRAB, kStBigCount, kStBigNext, false>
                     <<<(unsigned)device_cu_count() * 4, 512, 0, stream>>>(row32, col32, ext32, items, tasks_big, pl.big_task_room,
                                                                           in_count, in_off, inline_cap, heavy_cap, header);

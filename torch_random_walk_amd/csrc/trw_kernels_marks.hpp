@@ -335,7 +335,7 @@ __device__ __forceinline__ uint32_t bloom_bits(uint32_t h)
 #endif
 }
 #ifndef TRW_TILE_CAP
-#define TRW_TILE_CAP 4096
+#define TRW_TILE_CAP 2048
 #endif
 #ifndef TRW_BIG_GRAB
 #define TRW_BIG_GRAB 16
@@ -344,7 +344,7 @@ __device__ __forceinline__ uint32_t bloom_bits(uint32_t h)
 #define TRW_SMALL_GRAB 16
 #endif
 #ifndef TRW_BLOOM_WORDS
-#define TRW_BLOOM_WORDS 2048
+#define TRW_BLOOM_WORDS 2000
 #endif
 
 // One kernel, two shapes.  The long rows': a workgroup of 8 waves shares the tile and the filter of one row; its waves
@@ -363,7 +363,7 @@ tile_bloom_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
     constexpr uint32_t kWaves = kThreads / 64;
     constexpr uint32_t kItems = kTileTaskItems;  // items of a task: one per lane
     constexpr uint32_t kQueue = 128;  // survivors waiting for a search, per wave (a stack: fewer than 64 wait when 64 elements arrive)
-    static_assert(kItems == 64 && kGrab <= 64 && (kCap & (kCap - 1)) == 0 && (kBloomWords & (kBloomWords - 1)) == 0, "layout");
+    static_assert(kItems == 64 && kGrab <= 64 && (kCap & (kCap - 1)) == 0 && kBloomWords >= 64, "layout");
     // per wave: its items' masks (4 words each), where their elements start in the wave's flat numbering (+ a sentinel),
     // where their rows start in col32, where the tile's node sits in them, and the stack of survivors {element, its flat number}
     constexpr uint32_t kWaveWords = kItems * 8 + 4 + 2 * kQueue;
@@ -411,6 +411,7 @@ tile_bloom_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
         while (pow2 < nb + 1u) pow2 <<= 1;
         bwords = 64u;
         while (bwords < n && bwords < kBloomWords) bwords <<= 1;
+        bwords = bwords < kBloomWords ? bwords : kBloomWords;  // (any number of words: an element's word is mulhi(hash, bwords))
         for (uint32_t i = threadIdx.x; i < bwords; i += kThreads) bloom[i] = 0u;
         for (uint32_t i = threadIdx.x; i < pow2; i += kThreads) {
             const uint32_t last = (i + 1u) * m < n ? (i + 1u) * m : n;  // one past block i's last entry
@@ -542,7 +543,11 @@ tile_bloom_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restrict
                 // "the item of element f" is "how many items start at or before f", a count of bits (below).
                 const uint64_t ne = __builtin_amdgcn_ballot_w64(len_j != 0u);
                 const uint32_t d_j = __builtin_amdgcn_mbcnt_hi((uint32_t)(ne >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ne, 0u));
-                acc[lane][0] = acc[lane][1] = acc[lane][2] = acc[lane][3] = 0u;
+                // (a zero made HERE: kept in four registers across the whole kernel it was the one value the register allocator
+                // spilled to scratch -- and the private segment is set up for every wave of a kernel that has any)
+                uint32_t zero;
+                asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+                acc[lane][0] = acc[lane][1] = acc[lane][2] = acc[lane][3] = zero;
                 rp_first[lane] = 0xFFFFFFFFu;
                 rp_cnt[lane] = 0u;
                 pfx[lane] = 0xFFFFFFFFu;  // (behind the last item: beyond every element)
