@@ -20,7 +20,7 @@
  * the entry works out itself (default 32; 8 when the tile pass follows);
  * TRW_HEAVY_MAX=k longest (shorter) row the marking passes take (default 256 / 1024);
  * TRW_PLAN_MARKS_AT / TRW_PLAN_FULL_AT=k steps per CSR entry from which ONE call is
- * planned with TRW_PREP_MARKS / _FULL (default 5 / 14).
+ * planned with TRW_PREP_MARKS / _FULL (default 0 / 9: the first level comes with the entries).
  * None of them changes a result.
  */
 #ifndef TRW_H
@@ -149,11 +149,12 @@ int trw_walk_csr_hip(const int64_t *row_ptr, int64_t n_nodes,
  *                       registers and the graph is read once per step.  Masks are worked out for entries one of
  *                       whose rows has at most 32 entries; the rest ask the edge set.
  *     TRW_PREP_MARKS    (implies BIASED) masks for every entry one of whose rows has at most 256 entries (the
- *                       tile pass: the longer row in LDS behind a Bloom filter): about 1.2x the prepare time, 40 %
- *                       faster walks -- worth it for a single call of 5 steps per CSR entry (trw_prepare_plan asks
- *                       for it then)
- *     TRW_PREP_MARKS_FULL (implies MARKS) ... at most 1024 entries: about 1.5x the prepare time, another 20 %
- *                       (planned from 14 steps per entry on)
+ *                       tile pass: the longer row in LDS behind a Bloom filter): CHEAPER to build than BIASED alone
+ *                       (the owning thread then keeps only rows of up to 8 entries) and 40 % faster to walk, at the
+ *                       price of 10 bytes per entry of scratch while it is built -- trw_prepare_plan asks for it
+ *                       whenever it asks for BIASED
+ *     TRW_PREP_MARKS_FULL (implies MARKS) ... at most 1024 entries: about 1.25x the prepare time, another 20 %
+ *                       (planned from 9 steps per entry on)
  *   or one of          TRW_PREP_ORDER_ONLY: no shadow, only the row-order probe the int64 biased kernels want;
  *                      TRW_PREP_NOTHING: header only (uniform walk on the per-walker stream)
  * trw_prepare_plan returns the `what` one call of the given shape is worth (what trw_walk_csr_hip builds).

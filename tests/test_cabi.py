@@ -78,7 +78,12 @@ def test_workspace_bytes():
     assert f(n, nnz, N, L, 1.0, 1.0, 2) == head                       # uniform on the walker stream: int64 kernels
     table = 32 * 256                                                  # edge set: 2.5 places of 8 bytes per edge in blocks of 4, >= 256 blocks
     fat = 32 * nnz                                                    # 32-byte entries of the biased walk
-    assert shadow + table + fat <= f(n, nnz, 1, L, 0.5, 2.0, 2) - head <= shadow + table + fat + 6 * 256   # 4 steps per entry
+    # a node2vec call worth the entries gets the masks of rows up to 256 entries with them (the tile pass makes them
+    # cheaper to build than doing without): + the marking passes' scratch (items for every entry, task records, two
+    # words per node)
+    scratch = lib.trw_prepare_csr_scratch_bytes(n, nnz, 2 | 4)
+    assert 8 * nnz < scratch < 8 * nnz + 8 * (n + 1) + 2 * 8 * 4096 + 12 * 256
+    assert shadow + table + fat + scratch <= f(n, nnz, 1, L, 0.5, 2.0, 2) - head <= shadow + table + fat + scratch + 6 * 256   # 4 steps per entry
     uniform = f(n, nnz, N, L, 1.0, 1.0, 0)                            # windows + shadow; rows written in place
     assert head + N * 124 + shadow <= uniform < head + N * 124 + shadow + stage
     assert f(2**31, nnz, N, L, 0.5, 2.0, 2) == head                   # too many nodes for the uint32 shadow
@@ -91,9 +96,11 @@ def test_workspace_bytes():
     w = lib.trw_walk_csr_prepared_workspace_bytes
     assert w(N, L, 0.5, 2.0, 2) == 256 and 256 + N * 124 <= w(N, L, 1.0, 1.0, 0) < 256 + N * 124 + 1024
     plan = lib.trw_prepare_plan
-    assert plan(n, nnz, 1, L, 0.5, 2.0, 2) == 2 and plan(1000, 10**6, 100, L, 0.5, 2.0, 2) == 0
-    # one call that makes 5 / 14 steps per entry brings the masks of rows up to 256 / 1 024 entries along
-    assert plan(n, nnz, 2, L, 0.5, 2.0, 2) == 2 | 4 and plan(n, nnz, N, L, 0.5, 2.0, 2) == 2 | 4 | 8
+    assert plan(n, nnz, 1, L, 0.5, 2.0, 2) == 2 | 4 and plan(1000, 10**6, 100, L, 0.5, 2.0, 2) == 0
+    # the masks of rows up to 256 entries come with the entries; one call that makes 9 steps per entry brings those of
+    # rows up to 1 024 along
+    assert plan(n, nnz, 2, L, 0.5, 2.0, 2) == 2 | 4 and plan(n, nnz, 3, L, 0.5, 2.0, 2) == 2 | 4 | 8
+    assert plan(n, nnz, N, L, 0.5, 2.0, 2) == 2 | 4 | 8
     assert plan(1000, 10**8, 5, 6, 0.5, 2.0, 1) == -1 and plan(n, nnz, N, L, 1.0, 1.0, 2) == -2
     assert plan(n, nnz, N, L, 0.5, 2.0, 1) == 2          # a serial replay of this many steps rides the prepared graph
     # a graph the size of BASELINE configs[3]: 20 bytes of edge set + 32 of entry + 4 of shadow per edge (it was a

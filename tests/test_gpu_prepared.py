@@ -32,20 +32,23 @@ def test_second_walk_reuses_the_prepared_graph_and_third_has_full_marks(rw, monk
     monkeypatch.setenv("TRW_PLAN_MARKS_AT", "1000000")   # (a call this size would bring the marks along by itself, see below)
     monkeypatch.setenv("TRW_PLAN_FULL_AT", "1000000")
     rp, ci = hub_graph(3000, 6)
-    tg = np.random.default_rng(2).integers(0, 3000, 20_000)
+    tg = np.random.default_rng(2).integers(0, 3000, 15_000)      # (30 steps per CSR entry a call)
     d_rp, d_ci, d_tg = _dev(rp, ci, tg)
     ref = O.walk(rp, ci, tg, 0.25, 4.0, 30, 10, rng_mode=O.RNG_WALKER)
     assert rw.cache_info() == []
     w1 = rw.walk(d_rp, d_ci, d_tg, 0.25, 4.0, 30, 10)
     info = rw.cache_info()
     assert len(info) == 1 and info[0][:2] == (3000, len(ci)) and info[0][2] == rw.PREP_BIASED and info[0][4] == 1
-    w2 = rw.walk(d_rp, d_ci, d_tg, 0.25, 4.0, 30, 10)            # second node2vec walk: upgrade to full marks
+    w2 = rw.walk(d_rp, d_ci, d_tg, 0.25, 4.0, 30, 10)            # second node2vec walk (30 steps per entry behind it): + marks
     info = rw.cache_info()
     assert len(info) == 1 and info[0][2] == rw.PREP_BIASED | rw.PREP_MARKS and info[0][4] == 2
+    w3 = rw.walk(d_rp, d_ci, d_tg, 0.25, 4.0, 30, 10)            # third (60 behind it): the masks of rows up to 1 024 too
+    info = rw.cache_info()
+    assert len(info) == 1 and info[0][2] == rw.PREP_BIASED | rw.PREP_MARKS | rw.PREP_MARKS_FULL and info[0][4] == 3
     blob_bytes = info[0][3]
-    w3 = rw.walk(d_rp, d_ci, d_tg, 0.25, 4.0, 30, 10)            # served from the cache as it is
-    assert rw.cache_info()[0][3] == blob_bytes and rw.cache_info()[0][4] == 3
-    for w in (w1, w2, w3):
+    w4 = rw.walk(d_rp, d_ci, d_tg, 0.25, 4.0, 30, 10)            # served from the cache as it is
+    assert rw.cache_info()[0][3] == blob_bytes and rw.cache_info()[0][4] == 4
+    for w in (w1, w2, w3, w4):
         assert (w.cpu().numpy() == ref).all()
     # a uniform walk over the same graph shares the entry (its shadow); fat entries join when they pay
     u = rw.walk(d_rp, d_ci, d_tg, 1.0, 1.0, 30, 10)
@@ -59,9 +62,10 @@ def test_second_walk_reuses_the_prepared_graph_and_third_has_full_marks(rw, monk
 
 
 def test_masks_of_longer_rows_join_with_the_steps_made_unless_prepared_by_hand(rw, monkeypatch):
-    """The wave-per-entry marking passes are built by the first node2vec walk that finds 6 (rows up to 256) / 55 (up to
+    """The wave-per-entry marking passes are built by the first node2vec walk that finds 6 (rows up to 256) / 40 (up to
     1 024) steps per CSR entry behind it on this graph -- never behind rw.prepare()'s back; by the first walk only when
-    that one call makes 5 / 14 steps per entry itself (trw_prepare_plan; the tile pass made the marks that cheap)."""
+    that one call is worth the entries at all (rows up to 256 come with them) / makes 9 steps per entry itself
+    (trw_prepare_plan; the tile pass made the marks that cheap)."""
     monkeypatch.setenv("TRW_PLAN_MARKS_AT", "1000000")
     monkeypatch.setenv("TRW_PLAN_FULL_AT", "1000000")
     rp, ci = hub_graph(1500, 6)
@@ -69,14 +73,14 @@ def test_masks_of_longer_rows_join_with_the_steps_made_unless_prepared_by_hand(r
     d_rp, d_ci, d_tg = _dev(rp, ci, tg)
     ref = O.walk(rp, ci, tg, 0.25, 4.0, 12, 4, rng_mode=O.RNG_WALKER)
     steps, nnz = len(tg) * 12, len(ci)
-    n_calls = 55 * nnz // steps + 3
+    n_calls = 40 * nnz // steps + 3
     seen = set()
     for k in range(n_calls):
         assert (rw.walk(d_rp, d_ci, d_tg, 0.25, 4.0, 12, 4).cpu().numpy() == ref).all()
         what = rw.cache_info()[0][2]
         behind = k * steps // nnz                                    # steps per entry made before this walk
         assert bool(what & rw.PREP_MARKS) == (k >= 1 and behind >= 6), (k, behind, what)
-        assert bool(what & rw.PREP_MARKS_FULL) == (behind >= 55), (k, behind, what)
+        assert bool(what & rw.PREP_MARKS_FULL) == (behind >= 40), (k, behind, what)
         seen.add(what)
     assert len(seen) == 3                                             # entries -> + marks -> + long-row marks
     rw.clear_cache()
@@ -88,8 +92,8 @@ def test_masks_of_longer_rows_join_with_the_steps_made_unless_prepared_by_hand(r
     # one call that makes enough steps by itself brings the marks along (the default plan)
     monkeypatch.delenv("TRW_PLAN_MARKS_AT")
     monkeypatch.delenv("TRW_PLAN_FULL_AT")
-    for walkers, want in ((nnz * 4 // 12, rw.PREP_BIASED), (nnz * 6 // 12, rw.PREP_BIASED | rw.PREP_MARKS),
-                          (nnz * 15 // 12, rw.PREP_BIASED | rw.PREP_MARKS | rw.PREP_MARKS_FULL)):
+    for walkers, want in ((nnz * 4 // 12, rw.PREP_BIASED | rw.PREP_MARKS), (nnz * 8 // 12, rw.PREP_BIASED | rw.PREP_MARKS),
+                          (nnz * 10 // 12, rw.PREP_BIASED | rw.PREP_MARKS | rw.PREP_MARKS_FULL)):
         rw.clear_cache()
         t = torch.as_tensor(np.resize(tg, walkers)).to(DEV)
         got = rw.walk_ex(d_rp, d_ci, t, 0.25, 4.0, 12, 4, rng_mode=rw.RNG_WALKER)   # (2 500 walkers: AUTO would replay the serial stream)
@@ -566,14 +570,15 @@ def test_prepare_is_repeatable_entry_for_entry(rw):
 
 def test_tile_pass_at_every_boundary_of_its_layout(rw):
     """Rows of exactly the lengths at which the marking passes change their ways -- 8 | 9 (the owning thread / the tile pass),
-    32 | 33, 63..65 (one group of lanes / two), 127..129 (exact mask / filter), 255..257 and 1 023..1 025 (the caps),
-    8 190..8 193 (a row that fits the tile whole / one that keeps every second entry in it), 16 384 and 20 000 (every third)
-    -- each pointing at each: every (length of u's row, length of v's row) pair occurs as an entry, in both orders.  The 32
-    bytes of sampled entries against numpy, for both cap levels."""
+    32 | 33, 63..65 (one task of 64 entries / two), 127..129 (exact mask / filter), 255..257 (the one-wave kernel / the
+    workgroup's; the first cap), 1 023..1 025 (the second cap), 2 046..2 049 (a row that fits the 2 048-entry tile whole / one
+    that keeps every second entry in it), 4 096, 8 193 and 20 000 (every third, fifth, tenth) -- each pointing at each: every
+    (length of u's row, length of v's row) pair occurs as an entry, in both orders.  The 32 bytes of sampled entries against
+    numpy, for both cap levels."""
     from torch_random_walk_amd import _native
     L = _native.cabi()
     rng = np.random.default_rng(11)
-    lens = [8, 9, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1023, 1024, 1025, 8190, 8191, 8192, 8193, 16384, 20000]
+    lens = [8, 9, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1023, 1024, 1025, 2046, 2047, 2048, 2049, 4096, 8193, 20000]
     k = len(lens)
     n = 30000
     rows = []

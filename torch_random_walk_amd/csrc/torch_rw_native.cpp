@@ -180,12 +180,11 @@ struct PreparedGraph {
 };
 
 // When a graph that is walked again gets more of its neighbourhood masks, in node2vec steps already made over it per
-// CSR entry.  The wave-per-entry pass for rows up to 256 entries costs 0.6 ns per entry and takes 0.05 ns off every
-// later step: it is built by the first walk that finds 6 steps per entry behind it -- the SECOND walk of a batch with one
-// 80-step walker per node of a graph of average degree 11, the eleventh of one GPU's eighth of such a batch, and not at
-// all by a stream of 400-walker batches (a 100 ms pass in front of a 3 ms walk).  Rows up to 1 024: 0.5 ns per entry
-// for 0.006 ns per step, from 55 steps per entry on (the ninth full batch).
-constexpr int64_t kMarksAfterStepsPerEntry = 6, kFullMarksAfterStepsPerEntry = 55;
+// CSR entry.  A first walk that is worth the entries brings the masks of rows up to 256 entries along (trw_prepare_plan);
+// those of rows up to 1 024 take a REBUILD of the prepared graph here -- 0.42 ns per entry on R-MAT 10M/110M (round 5) for
+// 0.011 ns off every later step: from 40 steps per entry on (the sixth batch of one 80-step walker per node of a graph of
+// average degree 11), and not at all by a stream of 400-walker batches (a 46 ms pass in front of a 3 ms walk).
+constexpr int64_t kMarksAfterStepsPerEntry = 6, kFullMarksAfterStepsPerEntry = 40;
 std::mutex g_cache_mu;
 std::list<std::shared_ptr<PreparedGraph>> g_cache;  // most recently used first
 std::atomic<int64_t> g_cache_capacity{2};

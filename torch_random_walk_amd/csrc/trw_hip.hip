@@ -243,12 +243,14 @@ int32_t plan_what(int64_t n_nodes, int64_t nnz, int64_t n_walkers, int32_t L, bo
     const __int128 steps = (__int128)n_walkers * L;
     const bool worth = steps >= (__int128)nnz / 2;
     if (!(forced == 1 || (forced == -1 && worth))) return 0;
-    // The masks of longer rows, since the tile pass made them cheap (R-MAT 10M/110M: 35 ms for table + entries, +23 ms
-    // for rows up to 256, +17 ms up to 1 024; a walk of 7.3 steps per entry: 82 / 47 / 37.5 ms): one call is worth
-    // the first from 5 steps per entry on, the second from 14.
+    // The masks of longer rows.  Measured on R-MAT 10M/110M (round 5, prepare ms -> walk ms of 7.3 / 2.2 steps per entry):
+    // entries + edge set alone, the owning thread marking rows up to 32 through the edge set: 42 -> 80 / 27; with the tile
+    // pass for rows up to 256 (TRW_PREP_MARKS): 37 -> 46 / 16 -- cheaper to BUILD than without it, because the owning thread
+    // then keeps only rows up to 8 --; up to 1 024 (TRW_PREP_MARKS_FULL): 46.5 -> 37.6 / 13.5.  So a call that is worth
+    // the entries at all gets the first level with them, and the second from 9 steps per entry on.
     int32_t what = TRW_PREP_BIASED;
-    if (steps >= (__int128)nnz * env_long("TRW_PLAN_MARKS_AT", 0, 1 << 20, 5)) what |= TRW_PREP_MARKS;
-    if (steps >= (__int128)nnz * env_long("TRW_PLAN_FULL_AT", 0, 1 << 20, 14)) what |= TRW_PREP_MARKS | TRW_PREP_MARKS_FULL;
+    if (steps >= (__int128)nnz * env_long("TRW_PLAN_MARKS_AT", 0, 1 << 20, 0)) what |= TRW_PREP_MARKS;
+    if (steps >= (__int128)nnz * env_long("TRW_PLAN_FULL_AT", 0, 1 << 20, 9)) what |= TRW_PREP_MARKS | TRW_PREP_MARKS_FULL;
     return what;
 }
 
