@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: PMC passes over the prepare kernels (scripts/tune_biased.py --what 14 --runs 1), condensed.
-# usage: scripts/pmc_prepare.sh [kernel-name-substring] [K=V env for the run ...]
+# usage: scripts/pmc_prepare.sh [kernel-name-substring[;substring...]] [K=V env for the run ...]   (several kernels: one section each)
 set -u
 KEY=${1:-heavy_tile_kernel}; shift
 O=gpurun_out/pmc_prep; rm -rf $O; mkdir -p $O
@@ -13,14 +13,19 @@ for PASS in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_
 done
 python3 - "$O" "$KEY" <<'PY'
 import csv, glob, sys, collections
-out, key = sys.argv[1], sys.argv[2]
-acc = collections.defaultdict(lambda: [0.0, 0])
+out, keys = sys.argv[1], sys.argv[2].split(";")
+rows = []
 for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
+    rows += list(csv.DictReader(open(f)))
+for key in keys:
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for r in rows:
         if key in r["Kernel_Name"]:
             a = acc[r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
-# one dispatch of the kernel per run: sums over the rows of that dispatch (rocprofv3 emits one row per counter)
-for k in sorted(acc):
-    print("%-34s %.4e" % (k, acc[k][0]))
+    if len(keys) > 1:
+        print("## " + key)
+    # one dispatch of the kernel per run: sums over the rows of that dispatch (rocprofv3 emits one row per counter)
+    for k in sorted(acc):
+        print("%-34s %.4e" % (k, acc[k][0]))
 PY
 rm -rf $O/pmc_*
