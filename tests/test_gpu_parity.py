@@ -334,6 +334,61 @@ def test_uniform_rows_any_alignment(rw, ext, monkeypatch):
         assert bool((buf[:guard + shift] == -7).all()) and bool((buf[guard + shift + N * (L + 1):] == -7).all())
 
 
+@pytest.mark.parametrize("width", [8, 4])
+def test_pool_rows_any_alignment(rw, width):
+    """The walker pool stores its columns in aligned groups of four (32 bytes of int64 columns, 16 of uint32 ones): a row's
+    head and tail are ragged, and which columns share a group depends on where the row starts.  Every row length modulo 4
+    from 1 up, every start offset of `out` modulo a group, batches that do and do not fill the pools, a start node
+    out of range (its row is filled), against the oracle -- and never a byte outside the rows."""
+    from torch_random_walk_amd import _native
+    lib = _native.cabi()
+    lib.trw_walk_csr_prepared_u32_hip.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64,
+                                                  ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                                  ctypes.c_double, ctypes.c_double, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    n = 300
+    rp, ci = hub_graph(n, 3)
+    d_rp, d_ci = _dev(rp, ci)
+    nnz = len(ci)
+    stream = torch.cuda.current_stream().cuda_stream
+    pb = lib.trw_prepare_csr_bytes(n, nnz, 14)
+    blob = torch.empty(pb, dtype=torch.uint8, device=DEV)
+    assert lib.trw_prepare_csr_hip(d_rp.data_ptr(), n, d_ci.data_ptr(), nnz, 14, blob.data_ptr(), pb, stream) == 0
+    rng = np.random.default_rng(9)
+    dt = torch.int64 if width == 8 else torch.int32
+    for L, N, shift in ((1, 70, 0), (1, 3, 1), (2, 65, 1), (2, 700, 2), (3, 130, 2), (3, 64, 3), (4, 300, 3), (5, 257, 0),
+                        (6, 191, 1), (7, 500, 2), (8, 63, 3), (9, 1000, 0), (10, 129, 5), (11, 40000, 6), (12, 777, 7),
+                        (80, 640, 1), (81, 100, 3)):
+        tg = rng.integers(0, n, N)
+        bad = N > 100
+        if bad:
+            tg[[7, N - 1]] = [n, -1]
+        d_tg = torch.as_tensor(tg, device=DEV)
+        guard = 16
+        buf = torch.full((N * (L + 1) + 2 * guard + 8,), -7, dtype=dt, device=DEV)
+        out = buf[guard + shift: guard + shift + N * (L + 1)]
+        wb = lib.trw_walk_csr_prepared_workspace_bytes(N, L, 0.25, 4.0, 2)
+        ws = torch.empty(wb, dtype=torch.uint8, device=DEV)
+        entry = lib.trw_walk_csr_prepared_hip if width == 8 else lib.trw_walk_csr_prepared_u32_hip
+        rc = entry(blob.data_ptr(), pb, 14, d_rp.data_ptr(), n, d_ci.data_ptr(), nnz, d_tg.data_ptr(), N, 5, 0.25, 4.0, L, 10, 2,
+                   out.data_ptr(), ws.data_ptr(), wb, stream)
+        assert rc == 0, lib.trw_last_error()
+        torch.cuda.synchronize()
+        fam = np.zeros(1, dtype=np.int64)
+        ok = np.ones(N, dtype=bool)
+        if bad:
+            ok[[7, N - 1]] = False
+        ref = O.walk(rp, ci, np.where(ok, tg, 0), 0.25, 4.0, L, 10, rng_mode=O.RNG_WALKER, walker_base=5)
+        got = out.view(N, L + 1).cpu().numpy()
+        if width == 4:
+            got = got.view(np.uint32).astype(np.int64)
+        assert (got[ok] == ref[ok]).all(), (L, N, shift)
+        if bad:  # a start node out of range fills its row
+            want = tg[~ok] if width == 8 else tg[~ok].astype(np.uint32).astype(np.int64)
+            assert (got[~ok] == want[:, None]).all(), (L, N, shift)
+        assert bool((buf[:guard + shift] == -7).all()) and bool((buf[guard + shift + N * (L + 1):] == -7).all()), (L, N, shift)
+
+
 def test_uniform_rows_bad_targets_fill_their_rows(rw):
     rp, ci = random_graph(100, 3, 2)
     tg = np.arange(100).repeat(3)

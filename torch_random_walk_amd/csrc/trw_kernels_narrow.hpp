@@ -1702,8 +1702,13 @@ biased_mask_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
 // A phase waits until its queue holds most of a wave (or nothing else can run), so its instructions execute
 // with most lanes active whatever the individual walkers are doing.  Same stream, same decisions, same rows as
 // biased_mask_kernel.
+// Columns leave the pool in aligned groups of four (see the adopt pass): one more word per slot, 120 slots for the same
+// four workgroups per CU.  HBM write traffic of the default workload 13.3 -> GB_QUAD GB; 37.1 -> 36.9 ms (0: pairs, 128 slots).
+#ifndef TRW_POOL_QUAD_STORES
+#define TRW_POOL_QUAD_STORES 1
+#endif
 #ifndef TRW_POOL_SLOTS
-#define TRW_POOL_SLOTS 128
+#define TRW_POOL_SLOTS (TRW_POOL_QUAD_STORES ? 120 : 128)
 #endif
 // Pairs of trials per visit of the burst: 2 while the pools stood a sixth empty (2 / 3: 41.7 / 41.7 ms), 3 since they
 // are kept full (2 / 3 / 4: 38.3 / 37.6 / 38.6 ms).
@@ -1794,7 +1799,7 @@ __device__ __forceinline__ void pool_fence()
 //     and a new walker enters the pool with its first entry gather queued (it was a special case inside every trial);
 //   * rejections are counted per pair, the runaway cap is looked at once per pair;
 //   * the Philox key schedule lives in vector registers (philox4x32_10_keyed).
-// 19 words per walker (15 + the 4 mask words): with 128 walkers per wave that is 9.9 KB of LDS, 39.6 KB per workgroup,
+// 20 words per walker (16 + the 4 mask words): with 120 walkers per wave that is 9.6 KB of LDS, 40.0 KB per workgroup,
 // FOUR workgroups per CU (160 KB) -- 22 words fitted three, and both the waves per SIMD and the walkers per wave pay.
 enum : int {
     PF_T = 0, PF_PREV, PF_START, PF_DEG, PF_Z,
@@ -1805,6 +1810,9 @@ enum : int {
     PF_W1, PF_W2, PF_W3, PF_BLK,  // words 1..3 of the walker's current Philox block, and its number
     PF_X,       // the candidate node a table probe asks about
     PF_AT,      // fat entry index to gather
+#if TRW_POOL_QUAD_STORES
+    PF_T2,      // the node before t: the fourth column of a 32-byte store
+#endif
     PF_COUNT
 };
 
@@ -1895,7 +1903,30 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                     int32_t s = (int32_t)P[PF_S][slot];
                     const uint32_t prev = P[PF_PREV][slot];
                     OutT *r = row_of(slot);
-#if TRW_POOL_PAIR_STORES
+#if TRW_POOL_QUAD_STORES
+                    // Columns leave in 32-byte ALIGNED groups of four (one HBM write sector, written once): column s with
+                    // the three before it -- the nodes the slot keeps anyway, PF_PREV, PF_T, and PF_T2 for this -- when
+                    // column s is the last of its group, not at all otherwise.  A row's ends are ragged (rows are
+                    // 8-byte aligned, 81 columns): the head of a row and its last group go out column by column.
+                    const uint32_t cm2 = P[PF_T][slot], cm3 = P[PF_T2][slot];
+                    const uint32_t a = (uint32_t)(((uintptr_t)(r + s) / sizeof(OutT)) & 3u);
+#ifndef TRW_DBG_NO_STORES
+                    if (a == 3u && s >= 3) {
+                        if (sizeof(OutT) == 8) {
+                            *reinterpret_cast<i64x2_a16 *>(r + s - 3) = i64x2_a16{(int64_t)cm3, (int64_t)cm2};
+                            *reinterpret_cast<i64x2_a16 *>(r + s - 1) = i64x2_a16{(int64_t)prev, (int64_t)x};
+                        } else {
+                            *reinterpret_cast<u32x4_a16 *>(r + s - 3) = u32x4_a16{cm3, cm2, prev, x};
+                        }
+                    } else if (a == 3u || s == L) {
+                        r[s] = (OutT)x;
+                        if (a >= 1u && s >= 1) r[s - 1] = (OutT)prev;
+                        if (a >= 2u && s >= 2) r[s - 2] = (OutT)cm2;
+                        if (a >= 3u && s >= 3) r[s - 3] = (OutT)cm3;
+                    }
+#endif
+                    P[PF_T2][slot] = cm2;
+#elif TRW_POOL_PAIR_STORES
                     // Columns leave in 16-byte ALIGNED pairs: column s together with column s-1 (the node being left, in
                     // the slot anyway) when its address is the upper half of a pair, not at all when it is the lower half
                     // (the next step stores it) -- half the store requests of a kernel that runs at the memory system's
@@ -1919,6 +1950,12 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                         to_free = true;
                     } else if (deg == 0) {  // dead end: reported, the walker stays
                         st |= TRW_ST_DEGREE0;
+#if TRW_POOL_QUAD_STORES
+                        if (a != 3u) {  // (the columns of x's group that were waiting for it)
+                            if (a >= 1u && s >= 2) r[s - 2] = (OutT)prev;
+                            if (a >= 2u && s >= 3) r[s - 3] = (OutT)cm2;
+                        }
+#endif
                         for (int32_t c = s - 1; c <= L; ++c) r[c] = (OutT)x;
                         to_free = true;
                     } else {
