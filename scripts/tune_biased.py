@@ -26,6 +26,7 @@ ap.add_argument("--q", type=float, default=4.0)
 ap.add_argument("--env", nargs="*", default=[])
 ap.add_argument("--tag", default="")
 ap.add_argument("--count", action="store_true")
+ap.add_argument("--narrow", action="store_true", help="uint32 rows straight from the walk kernel (trw_walk_csr_prepared_u32_hip)")
 args = ap.parse_args()
 for kv in args.env:
     k, v = kv.split("=", 1)
@@ -47,6 +48,7 @@ L.trw_walk_csr_prepared_workspace_bytes.argtypes = [i64, i32, dbl, dbl, i32]
 L.trw_walk_csr_prepared_workspace_bytes.restype = ctypes.c_size_t
 L.trw_walk_csr_prepared_hip.argtypes = [vp, ctypes.c_size_t, i32, vp, i64, vp, i64, vp, i64, i64, dbl, dbl, i32, i32,
                                         i32, vp, vp, ctypes.c_size_t, vp]
+L.trw_walk_csr_prepared_u32_hip.argtypes = L.trw_walk_csr_prepared_hip.argtypes
 L.trw_profile_enable.argtypes = [ctypes.c_int]
 L.trw_profile_last.argtypes = [ctypes.POINTER(dbl)] * 3
 L.trw_profile_prepare_last.argtypes = [ctypes.POINTER(dbl)]
@@ -69,19 +71,20 @@ pm = dbl()
 L.trw_profile_prepare_last(ctypes.byref(pm))
 wb = L.trw_walk_csr_prepared_workspace_bytes(B, args.L, args.p, args.q, 2)
 ws = torch.empty(wb, dtype=torch.uint8, device=dev)
-out = torch.empty((B, args.L + 1), dtype=torch.int64, device=dev)
+out = torch.empty((B, args.L + 1), dtype=torch.int32 if args.narrow else torch.int64, device=dev)
+walk_entry = L.trw_walk_csr_prepared_u32_hip if args.narrow else L.trw_walk_csr_prepared_hip
 times = []
 chk = None
 for r in range(args.runs):
     if args.count and r == args.runs - 1:
         L.trw_profile_enable(3)
-    rc = L.trw_walk_csr_prepared_hip(blob.data_ptr(), pb, args.what, rp.data_ptr(), n, ci.data_ptr(), nnz, tg.data_ptr(),
+    rc = walk_entry(blob.data_ptr(), pb, args.what, rp.data_ptr(), n, ci.data_ptr(), nnz, tg.data_ptr(),
                                      B, 0, args.p, args.q, args.L, 10, 2, out.data_ptr(), ws.data_ptr(), wb, stream)
     assert rc == 0, L.trw_last_error()
     a, b, c = dbl(), dbl(), dbl()
     assert L.trw_profile_last(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) == 0
     times.append(b.value)
-    s = int(out[:100000].sum()) ^ int(out[-100000:].sum())
+    s = int(out[:100000].long().sum()) ^ int(out[-100000:].long().sum())
     assert chk is None or chk == s, "runs differ"
     chk = s
 st = (i64 * 4)()

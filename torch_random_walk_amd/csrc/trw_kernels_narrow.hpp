@@ -1702,10 +1702,13 @@ biased_mask_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
 // A phase waits until its queue holds most of a wave (or nothing else can run), so its instructions execute
 // with most lanes active whatever the individual walkers are doing.  Same stream, same decisions, same rows as
 // biased_mask_kernel.
-// Columns leave the pool in aligned groups of four (see the adopt pass): one more word per slot, 120 slots for the same
-// four workgroups per CU.  HBM write traffic of the default workload 13.3 -> GB_QUAD GB; 37.1 -> 36.9 ms (0: pairs, 128 slots).
+// 1: columns leave the pool in aligned groups of FOUR (see the adopt pass) instead of pairs: one more word per slot, so
+// 120-slot pools for the same four workgroups per CU.  Measured (VERDICT r04 #2a; interleaved on one box, best of 5): L2 misses
+// per step 1.97 -> 1.71, bytes written to HBM 13.3 -> 7.0 GB, HBM traffic 87.8 -> 80.8 GB -- and the walk 36.0-36.3 -> 36.7 ms
+// (uint32 rows: 35.7 -> 36.2-36.3): the kernel is bound by its vector instructions (profiles/r05_pool_sq_counters.txt), the
+// extra slot word and the smaller pools cost more than the requests saved.  Off.
 #ifndef TRW_POOL_QUAD_STORES
-#define TRW_POOL_QUAD_STORES 1
+#define TRW_POOL_QUAD_STORES 0
 #endif
 #ifndef TRW_POOL_SLOTS
 #define TRW_POOL_SLOTS (TRW_POOL_QUAD_STORES ? 120 : 128)
@@ -1799,7 +1802,7 @@ __device__ __forceinline__ void pool_fence()
 //     and a new walker enters the pool with its first entry gather queued (it was a special case inside every trial);
 //   * rejections are counted per pair, the runaway cap is looked at once per pair;
 //   * the Philox key schedule lives in vector registers (philox4x32_10_keyed).
-// 20 words per walker (16 + the 4 mask words): with 120 walkers per wave that is 9.6 KB of LDS, 40.0 KB per workgroup,
+// 19 words per walker (15 + the 4 mask words): with 128 walkers per wave that is 9.9 KB of LDS, 39.6 KB per workgroup,
 // FOUR workgroups per CU (160 KB) -- 22 words fitted three, and both the waves per SIMD and the walkers per wave pay.
 enum : int {
     PF_T = 0, PF_PREV, PF_START, PF_DEG, PF_Z,
