@@ -866,7 +866,7 @@ static int walk_prepared(const void *prepared, size_t prepared_bytes, int32_t wh
         const bool pool_kernel = mask_kernel && n_walkers < ((int64_t)1 << 32) && env_long("TRW_POOL_KERNEL", 0, 1, 1) == 1;
         if (out32 && !pool_kernel) return fail(TRW_E_UNSUPPORTED, "narrow rows: only the walker-pool kernel writes them");
         if (pool_kernel) {
-            // 4 workgroups per CU: a wave's pool is 9.9 KB of LDS (kPoolSlots walkers x 19 words), 39.5 KB per workgroup
+            // 4 workgroups per CU: a wave's pool is 9.8 KB of LDS (kPoolSlots = 122 walkers x 20 words), 40.6 KB per workgroup
             // (a batch that does not even give every CU one workgroup of 64-walker waves is bound by latency: its grid is
             // sized for 64 walkers per wave instead of full pools -- 405 / 4 096 / 50 000 walkers: 2.0 / 2.1 / 2.3 ->
             // 1.7 / 1.8 / 2.0 ms; from 200 000 walkers on half-filled pools lose, 2.5 -> 2.8 ms)

@@ -656,12 +656,8 @@ elist_pool_kernel(const u32x4_a16 *__restrict__ nd, const u32x4_a16 *__restrict_
     const uint32_t v_clear = band_takes_near ? 0u : 1u, v_set = band_takes_near ? 1u : 0u;
     const int32_t cols = L + 1;
     // the Philox key schedule in vector registers (see philox4x32_10_keyed)
-    uint32_t key_r[10];
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        key_r[r] = seed + (uint32_t)r * 0x9E3779B9u;
-        asm volatile("" : "+v"(key_r[r]));
-    }
+    PhiloxKeysV key_r;
+    philox_keys_v(seed, key_r);
 
     uint32_t st = 0;
     uint32_t n_trials = 0, n_fetch = 0, n_tests = 0, n_probes = 0;

@@ -1703,15 +1703,15 @@ biased_mask_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
 // with most lanes active whatever the individual walkers are doing.  Same stream, same decisions, same rows as
 // biased_mask_kernel.
 // 1: columns leave the pool in aligned groups of FOUR (see the adopt pass) instead of pairs: one more word per slot, so
-// 120-slot pools for the same four workgroups per CU.  Measured (VERDICT r04 #2a; interleaved on one box, best of 5): L2 misses
-// per step 1.97 -> 1.71, bytes written to HBM 13.3 -> 7.0 GB, HBM traffic 87.8 -> 80.8 GB -- and the walk 36.0-36.3 -> 36.7 ms
-// (uint32 rows: 35.7 -> 36.2-36.3): the kernel is bound by its vector instructions (profiles/r05_pool_sq_counters.txt), the
-// extra slot word and the smaller pools cost more than the requests saved.  Off.
+// 122-slot pools for the same four workgroups per CU (320 bytes a slot + 1 600: 40 640 of the 40 960 a workgroup may have).
+// L2 misses per step 1.97 -> 1.71, bytes written to HBM 13.3 -> 7.0 GB, HBM traffic 87.8 -> 80.8 GB
+// (profiles/r05_pool_quad_stores.txt).  While the burst's Philox blocks were 40 v_xor_b32 each this was 0.5 ms SLOWER (the
+// kernel was bound by its vector instructions alone); with v_bitop3_b32 doing two of them at once it is 0.65 ms faster.
 #ifndef TRW_POOL_QUAD_STORES
-#define TRW_POOL_QUAD_STORES 0
+#define TRW_POOL_QUAD_STORES 1
 #endif
 #ifndef TRW_POOL_SLOTS
-#define TRW_POOL_SLOTS (TRW_POOL_QUAD_STORES ? 120 : 128)
+#define TRW_POOL_SLOTS (TRW_POOL_QUAD_STORES ? 122 : 128)
 #endif
 // Pairs of trials per visit of the burst: 2 while the pools stood a sixth empty (2 / 3: 41.7 / 41.7 ms), 3 since they
 // are kept full (2 / 3 / 4: 38.3 / 37.6 / 38.6 ms).
@@ -1802,7 +1802,7 @@ __device__ __forceinline__ void pool_fence()
 //     and a new walker enters the pool with its first entry gather queued (it was a special case inside every trial);
 //   * rejections are counted per pair, the runaway cap is looked at once per pair;
 //   * the Philox key schedule lives in vector registers (philox4x32_10_keyed).
-// 19 words per walker (15 + the 4 mask words): with 128 walkers per wave that is 9.9 KB of LDS, 39.6 KB per workgroup,
+// 20 words per walker (16 + the 4 mask words): with 122 walkers per wave that is 9.8 KB of LDS, 40.6 KB per workgroup,
 // FOUR workgroups per CU (160 KB) -- 22 words fitted three, and both the waves per SIMD and the walkers per wave pay.
 enum : int {
     PF_T = 0, PF_PREV, PF_START, PF_DEG, PF_Z,
@@ -1846,14 +1846,10 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
     const bool band_takes_near = bp.t1 > bp.t2;
     const int32_t cols = L + 1;
     // the Philox key schedule and the threshold of a return to t, in vector registers (see philox4x32_10_keyed)
-    uint32_t key_r[10];
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        key_r[r] = seed + (uint32_t)r * 0x9E3779B9u;
-        asm volatile("" : "+v"(key_r[r]));
-    }
-    uint32_t t0_v = bp.t0;
-    asm volatile("" : "+v"(t0_v));
+    PhiloxKeysV key_r;
+    philox_keys_v(seed, key_r);
+    uint32_t t0_v = bp.t0, t2_v = bp.t2;
+    asm volatile("" : "+v"(t0_v), "+v"(t2_v));
 
     uint32_t st = 0;
     uint32_t n_trials = 0, n_fetch = 0, n_tests = 0, n_probes = 0;
@@ -2212,7 +2208,7 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                 int32_t bitm;  // all ones iff mask bit idx & 127 is set
                 asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(bitm) : "v"(word), "v"(idx));
                 const uint32_t m = (uint32_t)bitm;
-                const uint32_t band_a = (thr_a & m) | (bp.t2 & ~m), band_r = (thr_r & m) | (bp.t2 & ~m);
+                const uint32_t band_a = select_bits(m, thr_a, t2_v), band_r = select_bits(m, thr_r, t2_v);
                 const bool in_run = idx - pos_lo < pos_cnt;
                 const uint32_t ta = in_run ? t0_v : band_a, tr = in_run ? t0_v : band_r;
                 acc = ru < ta;

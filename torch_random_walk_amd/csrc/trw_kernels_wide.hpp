@@ -115,18 +115,25 @@ __device__ __forceinline__ void mulhilo32(uint32_t a, uint32_t b, uint32_t &hi, 
     lo = (uint32_t)prod;
 }
 
+// hi1 ^ c1 ^ k: gfx950's three-input boolean v_bitop3_b32 (truth table 0x96 = a ^ b ^ c) runs at the rate of ONE v_xor_b32
+// between vector registers (2.6 cycles per wave, scripts/alu_probe2.hip -> profiles/r05_alu_probe2.txt; 4.35 with a scalar
+// operand, which is still less than the v_xor pair's 6.9)
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+// (a & b) | (~a & c): v_bfi_b32 at the fast rate when all three operands are vector registers
+__device__ __forceinline__ uint32_t select_bits(uint32_t mask, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(mask, b, c, 0xCA); }
+
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t (&o)[4])
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        // one v_mad_u64_u32 yields both halves of a 32x32 product; hipcc would issue a
+        // one v_mad_u64_u32 per product: the compiler's own lowering of a 32 x 32 -> 64 multiply by a constant is a
         // v_mul_hi_u32 and a v_mul_lo_u32 (both quarter rate) for the same thing
         uint32_t hi0, lo0, hi1, lo1;
         mulhilo32(0xD2511F53u, c0, hi0, lo0);
         mulhilo32(0xCD9E8D57u, c2, hi1, lo1);
-        const uint32_t n0 = hi1 ^ c1 ^ k0;
-        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        const uint32_t n0 = xor3(hi1, c1, k0);
+        const uint32_t n2 = xor3(hi0, c3, k1);
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
@@ -134,23 +141,32 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
 
-// The same ten rounds with the first key word's schedule handed in (seed + r * 0x9E3779B9, r = 0..9) -- by the
-// walker pools, which keep it in VECTOR registers: a v_xor_b32 with a scalar operand costs 4.3 cycles per wave where
-// one between vector registers or with a literal costs 2.6 (scripts/alu_probe2.hip), and a block has ten of them.
-// (The second key word is 0 + r * 0xBB67AE85: literals.)
-__device__ __forceinline__ void philox4x32_10_keyed(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                                    const uint32_t (&k0r)[10], uint32_t (&o)[4])
+// The same ten rounds with the key schedule handed in (k0r[r] = seed + r * 0x9E3779B9, k1r[r] = r * 0xBB67AE85, r = 0..9;
+// philox_keys_v) -- by the walker pools, which keep it in VECTOR registers: an operation with a scalar operand costs 4.3
+// cycles per wave where one between vector registers costs 2.6 (scripts/alu_probe2.hip), and a block has twenty of them.
+struct PhiloxKeysV {
+    uint32_t k0[10], k1[10];
+};
+__device__ __forceinline__ void philox_keys_v(uint32_t seed, PhiloxKeysV &k)
 {
-    uint32_t k1 = 0u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        k.k0[r] = seed + (uint32_t)r * 0x9E3779B9u;
+        k.k1[r] = (uint32_t)r * 0xBB67AE85u;
+        asm volatile("" : "+v"(k.k0[r]), "+v"(k.k1[r]));  // (pinned: the compiler would fold them back into scalars / literals)
+    }
+}
+__device__ __forceinline__ void philox4x32_10_keyed(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                    const PhiloxKeysV &k, uint32_t (&o)[4])
+{
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         uint32_t hi0, lo0, hi1, lo1;
         mulhilo32(0xD2511F53u, c0, hi0, lo0);
         mulhilo32(0xCD9E8D57u, c2, hi1, lo1);
-        const uint32_t n0 = hi1 ^ c1 ^ k0r[r];
-        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        const uint32_t n0 = xor3(hi1, c1, k.k0[r]);
+        const uint32_t n2 = r == 0 ? (hi0 ^ c3) : xor3(hi0, c3, k.k1[r]);  // (the second key word starts at 0)
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-        k1 += 0xBB67AE85u;
     }
     o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
