@@ -249,6 +249,40 @@ def test_errors_are_python_exceptions(rw, hash_path, monkeypatch):
     rw.check_status()                                                        # nothing pending from the above
 
 
+def test_runaway_rejection_loop_is_cut_and_reported(rw, monkeypatch):
+    """The reference's rejection loop (rw_cpu.cpp:166-195) has no exit but an accept: on a star with p = 1e9 a walker that
+    sits on a leaf may only return to the hub, with probability 1e-9 per trial.  Every kernel family cuts the loop after
+    2^20 rejections at one step, takes what the last trial drew (here: the hub, the leaf's only neighbour) and reports
+    TRW_ST_TRIAL_CAP -- the walk ends, the row is a valid walk, the caller hears about it."""
+    from torch_random_walk_amd import _native
+    lib = _native.cabi()
+    n = 40
+    rp = np.concatenate([[0, n - 1], n - 1 + np.arange(1, n)]).astype(np.int64)          # node 0: the hub
+    ci = np.concatenate([np.arange(1, n), np.zeros(n - 1)]).astype(np.int64)
+    d_rp, d_ci = _dev(rp, ci)
+    tg = torch.zeros(70, dtype=torch.int64, device=DEV)                                    # every walker starts on the hub
+    stream = torch.cuda.current_stream().cuda_stream
+    st = (ctypes.c_int64 * 4)()
+    lib.trw_walk_status.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]
+    for what, kind in ((14, "pool"), (6, "pool"), (2, "pool without masks"), (-1, "bisection"), (0, "bisection")):
+        pb = lib.trw_prepare_csr_bytes(n, len(ci), what)
+        blob = torch.empty(max(pb, 16), dtype=torch.uint8, device=DEV)
+        assert lib.trw_prepare_csr_hip(d_rp.data_ptr(), n, d_ci.data_ptr(), len(ci), what, blob.data_ptr(), pb, stream) == 0
+        wb = lib.trw_walk_csr_prepared_workspace_bytes(70, 3, 1e9, 1.0, 2)
+        ws = torch.empty(wb, dtype=torch.uint8, device=DEV)
+        out = torch.full((70, 4), -7, dtype=torch.int64, device=DEV)
+        rc = lib.trw_walk_csr_prepared_hip(blob.data_ptr(), pb, what, d_rp.data_ptr(), n, d_ci.data_ptr(), len(ci), tg.data_ptr(), 70, 0,
+                                           1e9, 1.0, 3, 10, 2, out.data_ptr(), ws.data_ptr(), wb, stream)
+        assert rc == 0, lib.trw_last_error()
+        assert lib.trw_walk_status(ws.data_ptr(), stream, st) == 0
+        assert st[0] == 8, (kind, what, st[0])                                            # TRW_ST_TRIAL_CAP and nothing else
+        rows = out.cpu().numpy()
+        assert (rows[:, 0] == 0).all() and (rows[:, 2] == 0).all(), (kind, what)
+        assert ((rows[:, 1] >= 1) & (rows[:, 1] < n)).all() and ((rows[:, 3] >= 1) & (rows[:, 3] < n)).all(), (kind, what)
+    with pytest.raises(RuntimeError, match="rejection loop"):
+        rw.walk_ex(d_rp, d_ci, tg, 1e9, 1.0, 3, 10, rng_mode=rw.RNG_WALKER, check=True)
+
+
 def test_default_call_does_not_synchronise_and_reports_faults_later(rw):
     """The default surface launches and returns like the reference's GPU entry point (rw_cuda.cu:223-245):
     a device-side data fault is read back asynchronously and raised by a LATER torch_rw call, or by

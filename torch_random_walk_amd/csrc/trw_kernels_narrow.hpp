@@ -2215,6 +2215,9 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                 tst = !acc && ru < tr;
             };
 
+            // (trials are not counted one by one: each moves the stream on by half a block, so a visit's trials are the
+            // distance between where the stream stood and where it stands -- see the write-back)
+            const uint32_t stood = 2u * blk_at + (odd ? 1u : 0u);
             bool running = busy;
 #if TRW_POOL_UNROLL
 #pragma unroll
@@ -2240,18 +2243,7 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
                     const bool f1 = acc1 || tst1;
                     bool fin = f1 || acc2 || tst2;
                     take = acc1 || (!f1 && acc2);
-                    uint32_t idx = f1 ? idx1 : idx2;
-                    rejected += f1 ? 0u : 1u;
-                    rejected += fin ? 0u : 1u;
-                    if (kCount) n_trials += f1 ? 1u : 2u;
-                    if (rejected >= kTrialCap) {  // runaway rejection loop: take what the pair's last trial drew
-                        st |= (uint32_t)kStTrialCap;
-                        if (!fin) {
-                            fin = true;
-                            take = true;
-                            idx = idx2;
-                        }
-                    }
+                    const uint32_t idx = f1 ? idx1 : idx2;
                     test = fin && !take;
                     at = t_start + idx;
                     // where the stream stands now: a pair used up moves on one block at the same parity; a step
@@ -2268,6 +2260,14 @@ biased_pool_kernel(const uint32_t *__restrict__ row32, const uint32_t *__restric
             // write back what moved
             bool to_issue = false, to_trial = false;
             if (busy) {
+                // every trial of the visit but the one that settled the step (if one did) was a rejection
+                const uint32_t trials = 2u * blk_at + (odd ? 1u : 0u) - stood;
+                rejected += trials - ((take || test) ? 1u : 0u);
+                if (kCount) n_trials += trials;
+                if (!(take || test) && rejected >= kTrialCap) {  // runaway rejection loop: take what the last trial drew
+                    st |= (uint32_t)kStTrialCap;
+                    take = true;
+                }
                 P[PF_W1][slot] = w1;
                 P[PF_W2][slot] = w2;
                 P[PF_W3][slot] = w3;
