@@ -25,3 +25,6 @@ run --gpus 2 --workload elist_rmat1m_biased
 run --gpus 2 --workload walk_windows_1m
 run --gpus 2 --workload windows_1m
 run --gpus 2 --workload rmat1m_biased --no-gather
+run --gpus 2 --workload rmat1m_biased --result int32
+run --gpus 3 --workload rmat1m_biased --result int32 --gather-chunks 3
+run --gpus 2 --workload rmat1m_uniform --result int32
