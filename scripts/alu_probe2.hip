@@ -79,6 +79,9 @@ __global__ void __launch_bounds__(256) alu_kernel(uint32_t *out, uint32_t seed, 
             if (kOp == 51) asm volatile("v_readfirstlane_b32 s21, %0\n v_readfirstlane_b32 s22, %1\n v_readfirstlane_b32 s23, %2\n v_readfirstlane_b32 s24, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "s21", "s22", "s23", "s24");
             if (kOp == 52) asm volatile("v_cmp_lt_u32_e64 s[12:13], %0, %4\n v_cmp_lt_u32_e64 s[14:15], %1, %4\n v_cndmask_b32_e64 %0, %0, %4, s[12:13]\n v_cndmask_b32_e64 %1, %1, %4, s[14:15]" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(m) : "s12", "s13", "s14", "s15");
             if (kOp == 54) asm volatile("v_bitop3_b32 %0, %0, s20, %1 bitop3:0x96\n v_bitop3_b32 %1, %1, s20, %2 bitop3:0x96\n v_bitop3_b32 %2, %2, s20, %3 bitop3:0x96\n v_bitop3_b32 %3, %3, s20, %0 bitop3:0x96" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(m));
+            if (kOp == 55) asm volatile("v_cndmask_b32_e64 %0, %0, %4, vcc\n v_cndmask_b32_e64 %1, %1, %4, vcc\n v_cndmask_b32_e64 %2, %2, %4, vcc\n v_cndmask_b32_e64 %3, %3, %4, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(m) : "vcc", "s10", "s11");
+            if (kOp == 56) { asm volatile("s_mov_b64 vcc, s[10:11]\n v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(m) : "vcc", "s10", "s11"); }
+            if (kOp == 57) { asm volatile("v_cmp_lt_u32 vcc, %0, %4\n v_cndmask_b32 %1, %1, %4, vcc\n v_cmp_lt_u32 vcc, %2, %4\n v_cndmask_b32 %3, %3, %4, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(m) : "vcc", "s10", "s11"); }
             if (kOp == 53) asm volatile("v_bitop3_b32 %0, %0, %4, %1 bitop3:0x96\n v_bitop3_b32 %1, %1, %4, %2 bitop3:0x96\n v_bitop3_b32 %2, %2, %4, %3 bitop3:0x96\n v_bitop3_b32 %3, %3, %4, %0 bitop3:0x96" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(m));
         }
     }
@@ -87,7 +90,7 @@ __global__ void __launch_bounds__(256) alu_kernel(uint32_t *out, uint32_t seed, 
     out[blockIdx.x * blockDim.x + threadIdx.x] = a ^ b ^ c ^ d ^ (uint32_t)wa ^ (uint32_t)wb ^ (uint32_t)wc ^ (uint32_t)wd;
 }
 
-static const char *kNames[] = {"v_xor_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xnor_b32", "v_lshrrev_b32", "v_lshlrev_b32", "v_lshrrev_b32(v)", "v_ashrrev_i32", "v_max_u32", "v_min_u32", "v_mov_b32", "v_not_b32", "v_add_co_u32", "v_bfe_u32", "v_bfe_i32", "v_bfi_b32", "v_alignbit_b32", "v_perm_b32", "v_mad_u32_u24", "v_mul_u32_u24", "v_mul_hi_u32_u24", "v_mul_lo_u32", "v_mul_hi_u32", "v_add3_u32", "v_lshl_or_b32", "v_lshl_add_u32", "v_add_lshl_u32", "v_and_or_b32", "v_or3_b32", "v_xad_u32", "v_med3_u32", "v_mbcnt_lo", "v_bcnt_u32", "v_ffbl_b32", "v_cndmask(vcc)", "v_cndmask(sgpr)", "v_cmp_lt_u32->vcc", "v_cmp_lt_u32->sgpr", "v_mov_dpp quad_perm", "v_add_u32_sdwa", "v_pk_add_u16", "v_dot4_u32_u8", "v_xor_b32(sgpr)", "v_xor_b32(lit)", "v_add_u32(lit)", "v_and_b32(lit)", "v_lshrrev_b64", "v_mad_u64_u32", "v_readfirstlane", "s_nop-free cmp+cndmask pair", "v_bitop3_b32 (a^b^c)", "v_bitop3_b32 (a^sgpr^c)"};
+static const char *kNames[] = {"v_xor_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xnor_b32", "v_lshrrev_b32", "v_lshlrev_b32", "v_lshrrev_b32(v)", "v_ashrrev_i32", "v_max_u32", "v_min_u32", "v_mov_b32", "v_not_b32", "v_add_co_u32", "v_bfe_u32", "v_bfe_i32", "v_bfi_b32", "v_alignbit_b32", "v_perm_b32", "v_mad_u32_u24", "v_mul_u32_u24", "v_mul_hi_u32_u24", "v_mul_lo_u32", "v_mul_hi_u32", "v_add3_u32", "v_lshl_or_b32", "v_lshl_add_u32", "v_add_lshl_u32", "v_and_or_b32", "v_or3_b32", "v_xad_u32", "v_med3_u32", "v_mbcnt_lo", "v_bcnt_u32", "v_ffbl_b32", "v_cndmask(vcc)", "v_cndmask(sgpr)", "v_cmp_lt_u32->vcc", "v_cmp_lt_u32->sgpr", "v_mov_dpp quad_perm", "v_add_u32_sdwa", "v_pk_add_u16", "v_dot4_u32_u8", "v_xor_b32(sgpr)", "v_xor_b32(lit)", "v_add_u32(lit)", "v_and_b32(lit)", "v_lshrrev_b64", "v_mad_u64_u32", "v_readfirstlane", "s_nop-free cmp+cndmask pair", "v_bitop3_b32 (a^b^c)", "v_bitop3_b32 (a^sgpr^c)", "v_cndmask_e64(vcc)", "s_mov vcc + 4 v_cndmask(vcc) [5 instr]", "cmp->vcc, cndmask(vcc) x2 [4 instr]"};
 
 template <int kOp>
 static void run(uint32_t *out, unsigned long long *cycles, int cus)
@@ -176,5 +179,8 @@ int main()
     run<52>(out, cycles, cus);
     run<53>(out, cycles, cus);
     run<54>(out, cycles, cus);
+    run<55>(out, cycles, cus);
+    run<56>(out, cycles, cus);
+    run<57>(out, cycles, cus);
     return 0;
 }
